@@ -1,0 +1,217 @@
+"""Test-side helpers: the CPU oracle (ctypes), synthetic lattices, and the
+LAMMPS-like harness (ghost atoms + full neighbour list).
+
+TEST INFRASTRUCTURE ONLY: nothing here is imported by the product package.
+bench.py imports it for its ``cpu_baseline`` leg and for input generation,
+__graft_entry__.smoke() for the check.
+"""
+import ctypes as C
+import gzip
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+FE_POT = os.path.join(GOLDEN, "potentials", "fe_annp_potential_2.ann")
+NI_POT = os.path.join(GOLDEN, "potentials", "ni_annp_potential_2.ann")
+
+MAXSF, MAXNOD, MAXLAY = 64, 64, 6
+KIND_FE, KIND_NI_COMPAT, KIND_NI_FIXED = 0, 1, 2
+LITERAL, FAST = 0, 1
+
+A_FE = 2.8553   # bcc Fe lattice constant used by the reference's own generator
+A_NI = 3.52
+
+
+class OraclePot(C.Structure):
+    _fields_ = [
+        ("nelements", C.c_int),
+        ("ntl", C.c_int), ("nhl", C.c_int), ("nnod", C.c_int),
+        ("nsf", C.c_int), ("npsf", C.c_int), ("ntsf", C.c_int),
+        ("flagsym", C.c_int),
+        ("flagact", C.c_int * MAXLAY),
+        ("has_symcoef", C.c_int),
+        ("cut", C.c_double), ("mass", C.c_double),
+        ("e_scale", C.c_double), ("e_shift", C.c_double), ("e_atom", C.c_double),
+        ("norm0", C.c_double * MAXSF),
+        ("norm1", C.c_double * MAXSF),
+        ("W", (C.c_double * (MAXNOD * MAXSF)) * MAXLAY),
+        ("B", (C.c_double * MAXNOD) * MAXLAY),
+        ("sym_rad", (C.c_double * 3) * MAXSF),
+        ("sym_ang", (C.c_double * 4) * MAXSF),
+        ("element", C.c_char * 16),
+    ]
+
+
+_lib = None
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libannp_oracle.so"])
+
+
+def oracle_lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORACLE_DIR, "libannp_oracle.so")
+        src_newer = (not os.path.exists(so)) or any(
+            os.path.getmtime(os.path.join(ORACLE_DIR, s)) > os.path.getmtime(so)
+            for s in ("annp_oracle.c", "annp_oracle.h", "lmp_harness.c"))
+        if src_newer:
+            build_oracle()
+        lib = C.CDLL(so)
+        dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_longlong)
+        lib.annp_oracle_read_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(OraclePot)]
+        lib.annp_oracle_read_file.restype = C.c_int
+        lib.annp_oracle_compute.argtypes = [
+            C.POINTER(OraclePot), C.c_int, C.c_int, C.c_int, dp, C.c_int, ip, ip, lp, ip,
+            C.c_double, C.c_int, dp, dp, dp, dp, dp, dp, C.c_int]
+        lib.annp_oracle_compute.restype = C.c_int
+        lib.annp_oracle_max_threads.restype = C.c_int
+        lib.harness_ghosts.argtypes = [C.c_int, dp, dp, ip, C.c_double, C.c_longlong, dp, ip]
+        lib.harness_ghosts.restype = C.c_longlong
+        lib.harness_neigh.argtypes = [C.c_int, C.c_int, dp, C.c_double, ip, lp, ip]
+        lib.harness_neigh.restype = C.c_longlong
+        _lib = lib
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int)) if a is not None else None
+
+
+def _lp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_longlong)) if a is not None else None
+
+
+def read_pot(path):
+    pot = OraclePot()
+    rc = oracle_lib().annp_oracle_read_file(path.encode(), 1, C.byref(pot))
+    if rc != 0:
+        raise RuntimeError("annp_oracle_read_file(%s) -> %d" % (path, rc))
+    return pot
+
+
+# ---------------------------------------------------------------- synthetic inputs
+def splitmix64(z):
+    """Counter-based generator: element-wise splitmix64 finaliser."""
+    z = (z + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def uniform_counter(n, seed):
+    """n doubles in [0,1) from counters 0..n-1."""
+    with np.errstate(over="ignore"):
+        z = splitmix64(np.arange(n, dtype=np.uint64) ^ np.uint64(seed))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def bcc(nx, ny, nz, a):
+    """bcc cells in cell-major order (both basis atoms of a cell adjacent)."""
+    i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    cells = np.stack([i.ravel(), j.ravel(), k.ravel()], axis=1).astype(np.float64)
+    x = np.empty((cells.shape[0], 2, 3))
+    x[:, 0, :] = cells
+    x[:, 1, :] = cells + 0.5
+    box = np.array([0, 0, 0, nx * a, ny * a, nz * a], dtype=np.float64)
+    return (x.reshape(-1, 3) * a).copy(), box
+
+
+def fcc(nx, ny, nz, a):
+    i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    cells = np.stack([i.ravel(), j.ravel(), k.ravel()], axis=1).astype(np.float64)
+    basis = np.array([[0, 0, 0], [0.5, 0.5, 0], [0.5, 0, 0.5], [0, 0.5, 0.5]])
+    x = cells[:, None, :] + basis[None, :, :]
+    box = np.array([0, 0, 0, nx * a, ny * a, nz * a], dtype=np.float64)
+    return (x.reshape(-1, 3) * a).copy(), box
+
+
+def perturb(x, seed=12345, amp=0.05):
+    u = uniform_counter(x.size, seed).reshape(x.shape)
+    return x + (2.0 * u - 1.0) * amp
+
+
+class System:
+    """What LAMMPS hands to Pair::compute(): owned + ghost positions and a full list."""
+
+    def __init__(self, x_local, box, periodic=(1, 1, 1), rc_list=8.5):
+        lib = oracle_lib()
+        x_local = np.ascontiguousarray(x_local, dtype=np.float64)
+        self.nlocal = n = x_local.shape[0]
+        self.box = np.ascontiguousarray(box, dtype=np.float64)
+        per = np.ascontiguousarray(periodic, dtype=np.int32)
+        ng = lib.harness_ghosts(n, _dp(x_local), _dp(self.box), _ip(per), rc_list, 0, None, None)
+        xg = np.empty((ng, 3))
+        self.owner = np.empty(ng, dtype=np.int32)
+        lib.harness_ghosts(n, _dp(x_local), _dp(self.box), _ip(per), rc_list, ng, _dp(xg), _ip(self.owner))
+        self.nghost = int(ng)
+        self.nall = n + self.nghost
+        self.x = np.ascontiguousarray(np.vstack([x_local, xg]))
+        self.type = np.ones(self.nall, dtype=np.int32)
+        self.numneigh = np.zeros(self.nall, dtype=np.int32)
+        tot = lib.harness_neigh(n, self.nall, _dp(self.x), rc_list, _ip(self.numneigh), None, None)
+        self.first = np.zeros(self.nall + 1, dtype=np.int64)
+        np.cumsum(self.numneigh, out=self.first[1:])
+        self.neigh = np.empty(max(int(tot), 1), dtype=np.int32)
+        lib.harness_neigh(n, self.nall, _dp(self.x), rc_list, _ip(self.numneigh), _lp(self.first), _ip(self.neigh))
+        self.ilist = np.arange(n, dtype=np.int32)
+        self.inum = n
+        self.rc_list = rc_list
+
+    def fold(self, f_all):
+        """reverse communication: add ghost forces onto their owners."""
+        f = f_all[: self.nlocal].copy()
+        if self.nghost:
+            np.add.at(f, self.owner, f_all[self.nlocal:])
+        return f
+
+    def refresh_ghosts(self, x_local):
+        """forward communication: new owned positions -> ghosts keep their image shift."""
+        shift = self.x[self.nlocal:] - self.x[: self.nlocal][self.owner]
+        self.x[: self.nlocal] = x_local
+        self.x[self.nlocal:] = x_local[self.owner] + shift
+
+
+def oracle_compute(pot, sysm, kind=KIND_FE, strategy=FAST, cutsq=None, ni_calls=1,
+                   want_virial=False, want_G=False, nthreads=0, inum=None):
+    lib = oracle_lib()
+    if cutsq is None:
+        cutsq = pot.cut * pot.cut
+    inum = sysm.inum if inum is None else inum
+    f = np.zeros((sysm.nall, 3))
+    eatom = np.zeros(sysm.nall)
+    eng = np.zeros(1)
+    vir = np.zeros(6) if want_virial else None
+    G = np.zeros((inum, pot.nsf)) if want_G else None
+    dEdG = np.zeros((inum, pot.nsf)) if want_G else None
+    rc = lib.annp_oracle_compute(C.byref(pot), kind, strategy, sysm.nall, _dp(sysm.x), inum,
+                                 _ip(sysm.ilist), _ip(sysm.numneigh), _lp(sysm.first), _ip(sysm.neigh),
+                                 cutsq, ni_calls, _dp(f), _dp(eatom), _dp(eng), _dp(vir), _dp(G), _dp(dEdG),
+                                 nthreads)
+    if rc != 0:
+        raise RuntimeError("annp_oracle_compute -> %d" % rc)
+    return dict(f_all=f, f=sysm.fold(f), eatom=eatom[: sysm.nlocal], energy=float(eng[0]),
+                virial=vir, G=G, dEdG=dEdG)
+
+
+def load_fe_st():
+    """The reference's own benchmark configuration (perf zip fe_st.dat): positions, box."""
+    with gzip.open(os.path.join(GOLDEN, "fe_st.dat.gz"), "rt") as fh:
+        lines = fh.read().split("\n")
+    n = int(lines[1].split()[0])
+    xlo, xhi = map(float, lines[3].split()[:2])
+    ylo, yhi = map(float, lines[4].split()[:2])
+    zlo, zhi = map(float, lines[5].split()[:2])
+    start = next(i for i, l in enumerate(lines) if l.startswith("Atoms")) + 2
+    arr = np.loadtxt(lines[start:start + n])
+    x = np.ascontiguousarray(arr[np.argsort(arr[:, 0]), 2:5])
+    return x, np.array([xlo, ylo, zlo, xhi, yhi, zhi])

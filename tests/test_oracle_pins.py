@@ -1,0 +1,132 @@
+"""Pins the CPU oracle (oracle/annp_oracle.c) to the reference.
+
+The reference ships no tests.  What pins results for this path:
+  1. the reference's own run log for its own data file
+     (annp-gpu-lammps/fe_v2/performance test.zip -> log_relaxing_new.lammps:109,118-120
+      and log_relaxing_old.lammps:120-122): step-0 E_pair, force 2-norm, max force
+     component and pressure of fe_st.dat (152 880 atoms), printed by the reference's
+     mixed-precision GPU build;
+  2. the perfect-lattice energies of SURVEY.md Appendix B, recorded from the
+     reference CPU translation units in fp64.
+"""
+import numpy as np
+import pytest
+
+from annp_testlib import (A_FE, A_NI, FAST, KIND_FE, KIND_NI_COMPAT, KIND_NI_FIXED, LITERAL,
+                          System, bcc, fcc, load_fe_st, oracle_compute, perturb)
+
+# SURVEY.md Appendix B
+FE_KAT = [(2.80, -4479.873964205), (2.8553, -4479.881765560), (2.90, -4479.854951283)]
+NI_KAT = [(3.45, 0.758728589), (3.52, 0.757588583), (3.60, 0.758551200)]
+
+
+@pytest.mark.parametrize("a,e_ref", FE_KAT)
+@pytest.mark.parametrize("strategy", [LITERAL, FAST])
+def test_fe_perfect_lattice_energy(fe_pot, a, e_ref, strategy):
+    x, box = bcc(5, 5, 5, a)
+    s = System(x, box)
+    r = oracle_compute(fe_pot, s, KIND_FE, strategy)
+    assert abs(r["energy"] / s.nlocal - e_ref) < 1e-9       # 9 printed decimals
+    assert np.abs(r["f"]).max() < 1e-11                     # perfect lattice: zero force
+    assert np.allclose(r["eatom"], r["energy"] / s.nlocal, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("a,e_ref", NI_KAT)
+@pytest.mark.parametrize("kind", [KIND_NI_COMPAT, KIND_NI_FIXED])
+def test_ni_perfect_lattice_energy(ni_pot, a, e_ref, kind):
+    x, box = fcc(3, 3, 3, a)
+    s = System(x, box)
+    r = oracle_compute(ni_pot, s, kind, LITERAL)
+    assert abs(r["energy"] / s.nlocal - e_ref) < 1e-9
+    fmax = np.abs(r["f"]).max()
+    if kind == KIND_NI_FIXED:
+        assert fmax < 1e-11
+    elif a == 3.52:
+        # signature of ni/src/pair_annp.cpp:737-738 recorded in SURVEY.md Appendix B
+        assert abs(fmax - 1.87e-3) < 0.01e-3
+
+
+def test_fe_published_log_kat(fe_pot):
+    """fe_st.dat through the oracle vs the numbers the reference printed for it."""
+    x, box = load_fe_st()
+    assert x.shape == (152880, 3)
+    s = System(x, box, periodic=(0, 1, 0))                  # in.st_test: boundary m p m
+    assert abs(s.numneigh[: s.nlocal].mean() - 217.6) < 0.05  # log: "Ave neighs/atom"
+    r = oracle_compute(fe_pot, s, KIND_FE, FAST, want_virial=True)
+    e_new, e_old = -684876292.365723, -684876292.28418      # mixed-precision GPU builds
+    assert abs(r["energy"] - e_new) / abs(e_new) < 1e-8      # observed 4.9e-9 (3.4 eV of 6.8e8)
+    assert abs(e_new - e_old) / abs(e_new) < 1e-8            # the two reference builds themselves
+    fn = np.linalg.norm(r["f"])
+    assert abs(fn - 39.623051) / 39.623051 < 5e-6            # observed 2.3e-6 (old log: 39.623117)
+    assert abs(np.abs(r["f"]).max() - 0.93490135) < 5e-5     # observed 1.9e-5 (old log: 0.93490485)
+    # pressure at step 0 (T = 0): trace(virial) / 3V * nktv2p, V and P from the log line 109
+    p = r["virial"][:3].sum() / (3 * 1773495.9) * 1.6021765e6
+    assert abs(p - (-40423.638)) / 40423.638 < 2e-4
+    # pairwise tally == F.r over owned+ghost atoms (virial_fdotr_compute)
+    fdotr = (s.x * r["f_all"]).sum(0)
+    assert np.allclose(fdotr, r["virial"][:3], rtol=1e-9)
+
+
+def test_fe_fast_matches_literal(fe_pot):
+    x, box = bcc(4, 4, 4, A_FE)
+    s = System(perturb(x, 12345, 0.05), box)
+    a = oracle_compute(fe_pot, s, KIND_FE, LITERAL, want_virial=True, want_G=True)
+    b = oracle_compute(fe_pot, s, KIND_FE, FAST, want_virial=True, want_G=True)
+    assert np.abs(a["f"] - b["f"]).max() < 1e-12
+    assert np.abs(a["eatom"] - b["eatom"]).max() < 1e-11
+    assert np.abs(a["G"] - b["G"]).max() < 1e-11
+    assert np.abs(a["dEdG"] - b["dEdG"]).max() < 1e-13
+    assert np.abs(a["virial"] - b["virial"]).max() < 1e-10
+    assert np.abs(a["f"].sum(0)).max() < 1e-12               # Newton's third law
+
+
+@pytest.mark.parametrize("kind", [KIND_NI_COMPAT, KIND_NI_FIXED])
+def test_ni_fast_matches_literal(ni_pot, kind):
+    x, box = fcc(3, 3, 3, A_NI)
+    s = System(perturb(x, 777, 0.05), box)
+    a = oracle_compute(ni_pot, s, kind, LITERAL, want_G=True)
+    b = oracle_compute(ni_pot, s, kind, FAST, want_G=True)
+    assert np.abs(a["f"] - b["f"]).max() < 1e-12
+    assert np.abs(a["eatom"] - b["eatom"]).max() < 1e-12
+    assert np.abs(a["G"] - b["G"]).max() < 1e-12
+
+
+def _fd_check(pot, kind, x, box, idx, h=1e-4):
+    s = System(x, box)
+    r0 = oracle_compute(pot, s, kind, FAST)
+    # Ni: E in raw network units (Hartree), dG/dx taken per Bohr, F multiplied by CFFORCE
+    scale = 51.422515 / 1.889726 if kind != KIND_FE else 1.0
+    err = 0.0
+    for (i, d) in idx:
+        e = []
+        for sgn in (+1, -1):
+            xp = x.copy()
+            xp[i, d] += sgn * h
+            sp = System(xp, box)
+            e.append(oracle_compute(pot, sp, kind, FAST)["eatom"])
+        fd = -np.sum(e[0] - e[1]) / (2 * h) * scale         # per-atom differences: no 1e5 eV cancellation
+        err = max(err, abs(fd - r0["f"][i, d]))
+    return err
+
+
+def test_fe_forces_are_energy_gradient(fe_pot):
+    x, box = bcc(4, 4, 4, A_FE)
+    x = perturb(x, 12345, 0.05)
+    assert _fd_check(fe_pot, KIND_FE, x, box, [(0, 0), (5, 1), (77, 2)]) < 2e-6
+
+
+def test_ni_fixed_is_gradient_compat_is_not(ni_pot):
+    x, box = fcc(3, 3, 3, A_NI)
+    x = perturb(x, 777, 0.05)
+    idx = [(0, 0), (5, 1), (50, 2)]
+    assert _fd_check(ni_pot, KIND_NI_FIXED, x, box, idx) < 2e-6
+    assert _fd_check(ni_pot, KIND_NI_COMPAT, x, box, idx) > 1e-4   # ni:737-738
+
+
+def test_ni_repeated_calls_drift(ni_pot):
+    """ni/src/pair_annp.cpp:99-101 mutates sf_max on every compute() call."""
+    x, box = fcc(3, 3, 3, A_NI)
+    s = System(x, box)
+    e = [oracle_compute(ni_pot, s, KIND_NI_COMPAT, FAST, ni_calls=c)["energy"] for c in (1, 2, 3)]
+    assert abs(e[0] / s.nlocal - 0.757588583) < 1e-9
+    assert abs(e[1] - e[0]) > 1e-3 and abs(e[2] - e[1]) > 1e-3
