@@ -1,0 +1,174 @@
+/* annp_hip.h -- C ABI of libannp_hip.so: the MI355X (gfx950) evaluation of the
+ * LAMMPS `pair_style annp` hot path (descriptor build, per-atom network,
+ * chain-rule forces).
+ *
+ * This header is the drop-in boundary.  It replaces the five free functions a
+ * LAMMPS `src/GPU` pair style binds in `lib/gpu` for this potential:
+ *
+ *   reference (C++ linkage, static singleton)              here (C linkage, handle)
+ *   ---------------------------------------------------   -------------------------
+ *   annp_gpu_init      fe_v2/src/pair_annp_gpu.cpp:31-39   annp_hip_init
+ *                      fe_v2/lib/lal_annp_ext.cpp:25-99
+ *                      (ni adds cofsymrad/cofsymang:
+ *                       ni/src/pair_annp_gpu.cpp:31-40)
+ *   annp_gpu_compute   fe_v2/src/pair_annp_gpu.cpp:52-57   annp_hip_compute
+ *                      fe_v2/lib/lal_annp_ext.cpp:110-119
+ *   annp_gpu_compute_n fe_v2/src/pair_annp_gpu.cpp:44-49   annp_hip_compute_n
+ *                      fe_v2/lib/lal_annp_ext.cpp:98-108
+ *   annp_gpu_clear     fe_v2/lib/lal_annp_ext.cpp:94-96     annp_hip_clear
+ *   annp_gpu_bytes     fe_v2/lib/lal_annp_ext.cpp:121-123   annp_hip_bytes
+ *
+ * plus device-resident entry points (annp_hip_compute_device,
+ * annp_hip_neigh_build_device) for callers that already keep atoms in HBM
+ * (KOKKOS/GPU-package style callers, the in-repo multi-GPU driver, bench.py).
+ *
+ * Conventions:
+ *   - all host arrays are borrowed for the duration of the call; parameters are
+ *     copied at init; device memory is owned by the handle.
+ *   - forces ACCUMULATE into f (CPU pair_annp semantics, fe_v2/src/pair_annp.cpp:199,211),
+ *     ghosts included (newton_pair on); eng_vdwl and eatom accumulate too.
+ *   - neighbour indices are masked with NEIGHMASK (0x1FFFFFFF) as fe_v2:136 does.
+ *   - return value 0 = ok; negative = error, same numbering as the reference's
+ *     init codes (fe_v2/lib/lal_annp.h:28-33): -1 bad argument / not initialised,
+ *     -3 out of device memory, -4 no usable gfx950 device / HIP runtime failure,
+ *     -5 double precision unsupported, -7 neighbour capacity exceeded,
+ *     -9 unsupported network / descriptor shape.  annp_hip_last_error() gives text.
+ *     Nothing throws or exits across this boundary.
+ *   - one caller thread per handle; several handles per process are fine.
+ */
+#ifndef ANNP_HIP_H
+#define ANNP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANNP_HIP_ABI_VERSION 1
+
+#define ANNP_HIP_OK 0
+#define ANNP_HIP_EARG (-1)
+#define ANNP_HIP_ENOMEM (-3)
+#define ANNP_HIP_EDEVICE (-4)
+#define ANNP_HIP_ENODOUBLE (-5)
+#define ANNP_HIP_ENEIGHCAP (-7)
+#define ANNP_HIP_ESHAPE (-9)
+
+/* which reference translation unit's arithmetic is evaluated */
+#define ANNP_HIP_DESC_CHEBYSHEV 0   /* fe, fe_v2: fe_v2/src/pair_annp.cpp:633-695         */
+#define ANNP_HIP_DESC_BEHLER 1      /* ni: G2/G4 in atomic units, ni/src/pair_annp.cpp:686-767 */
+
+typedef struct annp_hip_handle annp_hip_handle;
+
+/* Flat image of the arguments of annp_gpu_init.  Pointers are read during
+ * annp_hip_init only. */
+typedef struct annp_hip_params {
+    int struct_bytes;       /* sizeof(annp_hip_params), ABI check                      */
+    int descriptor;         /* ANNP_HIP_DESC_*                                          */
+    int ntypes;             /* LAMMPS atom->ntypes                                      */
+    int ntl, nhl, nnod;     /* total layers, hidden layers, nodes per hidden layer      */
+    int nsf, npsf, ntsf;    /* symmetry functions: all, radial, angular                 */
+    int flagsym;            /* as parsed (informational; `descriptor` decides)          */
+    int ni_compat;          /* BEHLER only: 1 = reproduce ni/src/pair_annp.cpp:737-738
+                               (rik_m in place of rjk_m), 0 = the gradient-consistent
+                               form of the reference GPU kernel ni/lib/lal_annp.cu:409-414 */
+    const int *flagact;     /* [ntl-1] activation per weight layer: 0 linear, 1 tanh,
+                               2 1/(1+exp(+a)), 3 1.7159 tanh(2a/3), 4 = 3 + 0.1a;
+                               BEHLER: 3 and 4 are plain tanh (ni/src/pair_annp.cpp:781-808) */
+    double e_scale, e_shift, e_atom;
+    double cut;             /* cutmax from the potential file                           */
+    const double *sfnor_scal; /* [nsf] CHEBYSHEV: 1/sqrt(cov-avg^2) (pair_annp_gpu.cpp:207-216)
+                                       BEHLER: sf_max - sf_min (ni pair_annp_gpu.cpp:231-235) */
+    const double *sfnor_avg;  /* [nsf] CHEBYSHEV: sfnor_avg;  BEHLER: sf_min               */
+    const double *cutsq;      /* [(ntypes+1)*(ntypes+1)] LAMMPS cutsq, row-major            */
+    const int *map;           /* [ntypes+1] LAMMPS type -> element, -1 = not mapped         */
+    const double *const *weight_all; /* [ntl-1] pointers, layer l row-major [nrow][ncol]:
+                                        (nnod x nsf), (nnod x nnod)..., (1 x nnod); element 0 */
+    const double *const *bias_all;   /* [ntl-1] pointers, [nnod] ... [1]                     */
+    const double *cofsymrad;  /* BEHLER: [npsf*3] eta, Rs, Rc(Bohr); else NULL              */
+    const double *cofsymang;  /* BEHLER: [ntsf*4] eta, lambda, zeta, Rc(Bohr); else NULL    */
+} annp_hip_params;
+
+/* Replaces annp_gpu_init.  device = HIP device ordinal.  nlocal/nall/max_nbors are
+ * sizing hints exactly as in the reference (buffers grow on demand). */
+int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *params, int device,
+                  int nlocal_hint, int nall_hint, int max_nbors_hint);
+
+/* Replaces annp_gpu_compute (neighbour list built by LAMMPS on the host).
+ *   ago        neighbor->ago: 0 = list was rebuilt, re-upload it
+ *   host_x     LAMMPS atom->x[0]: nall*3 doubles;  host_type: nall ints
+ *   ilist/numj/firstneigh: LAMMPS NeighList (full list), numj and firstneigh indexed by atom
+ *   f          atom->f[0]: nall*3 doubles, accumulated into
+ *   eng_vdwl   accumulated when eflag;  eatom [nall] accumulated when eatom_flag (nullable)
+ *   virial     6 doubles xx yy zz xy xz yz accumulated when vflag: the ev_tally_xyz
+ *              contraction of fe_v2/src/pair_annp.cpp:201-209 (nullable)
+ *   vatom      reserved (per-atom virial), must be NULL */
+int annp_hip_compute(annp_hip_handle *handle, int ago, int inum, int nall, int nghost,
+                     const double *host_x, const int *host_type,
+                     const int *ilist, const int *numj, const int *const *firstneigh,
+                     int eflag, int vflag, int eatom_flag, int vatom_flag,
+                     double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom);
+
+/* Replaces annp_gpu_compute_n (neighbour list built on the device from host_x
+ * when ago == 0).  sublo/subhi bound the owned atoms; cutneigh = cutoff + skin.
+ * Owned atoms are the first inum entries of host_x, ghosts follow.  Atomic
+ * systems only (no special-bond exclusions), like the potential itself. */
+int annp_hip_compute_n(annp_hip_handle *handle, int ago, int inum, int nall, int nghost,
+                       const double *host_x, const int *host_type,
+                       const double *sublo, const double *subhi, double cutneigh,
+                       int eflag, int vflag, int eatom_flag, int vatom_flag,
+                       double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom);
+
+/* Device-resident evaluation: every pointer is a device pointer on the handle's GPU.
+ *   d_x [nall*3], d_type [nall] (nullable = all type 1), d_ilist [inum] (nullable = 0..inum-1)
+ *   neighbours of atom i: d_neigh[d_first[i] .. d_first[i]+d_numneigh[i])
+ *   d_f [nall*3] accumulated;  d_eatom [nall] accumulated (nullable)
+ *   d_eng: 1 double accumulated (nullable);  d_virial: 6 doubles accumulated (nullable)
+ *   stream: hipStream_t (NULL = default stream).  Asynchronous: returns after enqueue. */
+int annp_hip_compute_device(annp_hip_handle *handle, int inum, int nall,
+                            const double *d_x, const int *d_type, const int *d_ilist,
+                            const int *d_numneigh, const long long *d_first, const int *d_neigh,
+                            int max_numneigh,
+                            double *d_f, double *d_eatom, double *d_eng, double *d_virial,
+                            void *stream);
+
+/* Device neighbour-list build (binned, full list, r^2 <= cutneigh^2) for the
+ * first nlocal of nall atoms at d_x.  The list lives in handle-owned memory and
+ * stays valid until the next build or annp_hip_clear. */
+int annp_hip_neigh_build_device(annp_hip_handle *handle, int nlocal, int nall, const double *d_x,
+                                double cutneigh,
+                                const int **d_numneigh, const long long **d_first, const int **d_neigh,
+                                int *max_numneigh, void *stream);
+
+/* Blocks until the handle's enqueued work is done and reports deferred device-side
+ * errors (e.g. ANNP_HIP_ENEIGHCAP). */
+int annp_hip_sync(annp_hip_handle *handle);
+
+/* Kernel timing with HIP events recorded on the stream the kernels are launched on.
+ * annp_hip_set_timing(h, 1) starts recording (and resets the sample count); every
+ * evaluation then records four events.  ms4 = milliseconds of [0] descriptor pass,
+ * [1] network pass, [2] force pass, [3] whole evaluation.
+ *   annp_hip_last_timing   the most recent evaluation
+ *   annp_hip_timing_stats  mean over the evaluations since enabling (the last 64 at most) */
+int annp_hip_set_timing(annp_hip_handle *handle, int enable);
+int annp_hip_last_timing(annp_hip_handle *handle, double *ms4);
+int annp_hip_timing_stats(annp_hip_handle *handle, double *ms4_mean, int *nsamples);
+
+/* In-cutoff neighbour counts of the last evaluation (one int per list entry ii),
+ * copied to the host: the n that SURVEY.md 8d's flop formula is evaluated with. */
+int annp_hip_last_counts(annp_hip_handle *handle, int *counts, int inum);
+
+/* Replaces annp_gpu_clear: frees everything; the handle is invalid afterwards. NULL ok. */
+void annp_hip_clear(annp_hip_handle *handle);
+
+/* Replaces annp_gpu_bytes: bytes of device + pinned host memory held by the handle. */
+double annp_hip_bytes(const annp_hip_handle *handle);
+
+/* Text of the last error on this handle (or of the last failed init when NULL). */
+const char *annp_hip_last_error(const annp_hip_handle *handle);
+
+int annp_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

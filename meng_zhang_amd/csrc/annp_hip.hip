@@ -1,0 +1,591 @@
+// annp_hip.hip -- C ABI of libannp_hip.so (see include/annp_hip.h).
+//
+// Host driver for the gfx950 kernels.  Behaviour mirrors what a LAMMPS GPU-package
+// pair style expects from lib/gpu (reference: annp-gpu-lammps/fe_v2/lib/lal_annp.cpp
+// init 41-216, compute 259-370, loop_annp 517-607) without reproducing its design:
+// no Geryon, no atom-chunk loop, no materialised dG, no single-block force update.
+// Per call: descriptor pass -> network pass (FP64 MFMA) -> force pass, all on one
+// stream, buffers owned by the handle.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/annp_hip.h"
+#include "annp_common.hpp"
+#include "fe_kernels.hpp"
+#include "mlp_kernels.hpp"
+#include "neigh_kernels.hpp"
+#include "ni_kernels.hpp"
+
+using namespace annp;
+
+namespace {
+
+std::string g_init_error;
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;   // elements
+};
+
+}  // namespace
+
+struct annp_hip_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;       // used by the host-pointer entry points
+    std::string err;
+    // parameters (copied at init)
+    int descriptor = 0, ntypes = 1, ntl = 0, nhl = 0, nnod = 0, nsf = 0, npsf = 0, ntsf = 0, nl = 0;
+    int ni_compat = 0;
+    int flagact[MLP_MAXL] = {0, 0, 0, 0};
+    double e_scale = 0, e_shift = 0, e_atom = 0, cut = 0, cutsq = 0;
+    double *dW[MLP_MAXL] = {nullptr, nullptr, nullptr, nullptr};
+    double *dB[MLP_MAXL] = {nullptr, nullptr, nullptr, nullptr};
+    double *d_norm = nullptr;           // nmul | nsub | nden | cmul, ANNP_GPAD each
+    double *d_sym = nullptr;            // BEHLER: rad[npsf*3] then ang[ntsf*4]
+    std::vector<double> sym_rad, sym_ang;
+    // work buffers
+    DevBuf<double> G, coef, x, f, eatom;
+    DevBuf<int> type, ilist, numneigh, neigh, ncount;
+    DevBuf<long long> first;
+    double *d_scalars = nullptr;        // [0] energy, [1..6] virial
+    int *d_flags = nullptr;             // [0] capacity-overflow max n, [1] max in-cutoff n
+    int *h_flags = nullptr;             // pinned mirror
+    double *h_scalars = nullptr;        // pinned mirror
+    // neighbour list built on device
+    NeighBuild nb;
+    // host-list cache
+    std::vector<long long> h_first;
+    std::vector<int> h_numneigh, h_neigh;
+    int list_max = 0;                   // max numneigh of the uploaded list
+    bool list_valid = false;
+    size_t bytes = 0;
+    // timing
+    bool timing = false;
+    static constexpr int kRing = 64;      // evaluations kept for annp_hip_timing_stats
+    std::vector<hipEvent_t> evring;       // kRing x 4 events, created on first enable
+    hipEvent_t *ev = nullptr;             // the four events of the evaluation being enqueued
+    long long ev_count = 0;               // evaluations recorded since timing was enabled
+    int deferred_error = 0;
+};
+
+namespace {
+
+int fail(annp_hip_handle *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_init_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(h, e_ == hipErrorOutOfMemory ? ANNP_HIP_ENOMEM : ANNP_HIP_EDEVICE,       \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int ensure(annp_hip_handle *h, DevBuf<T> &b, size_t n)
+{
+    if (n <= b.cap) return 0;
+    size_t want = n + n / 8 + 64;
+    if (b.p) { h->bytes -= b.cap * sizeof(T); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    HIP_TRY(h, hipMalloc((void **)&b.p, want * sizeof(T)));
+    b.cap = want;
+    h->bytes += want * sizeof(T);
+    return 0;
+}
+
+template <typename T>
+void release(annp_hip_handle *h, DevBuf<T> &b)
+{
+    if (b.p) { (void)hipFree(b.p); h->bytes -= b.cap * sizeof(T); }
+    b.p = nullptr; b.cap = 0;
+}
+
+// ---- network pass dispatch --------------------------------------------------------
+template <int KS0, int MT, int NL>
+int launch_mlp(annp_hip_handle *h, const MlpArgs &a, hipStream_t s)
+{
+    static bool attr_done = false;
+    const size_t lds = mlp_lds_bytes<KS0, MT, NL>();
+    if (!attr_done) {
+        HIP_TRY(h, hipFuncSetAttribute((const void *)annp_mlp_mfma<KS0, MT, NL>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int ntiles = (a.inum + 15) / 16;
+    int blocks = (ntiles + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK;
+    blocks = std::max(1, std::min(blocks, 256 * 4));
+    hipLaunchKernelGGL((annp_mlp_mfma<KS0, MT, NL>), dim3(blocks), dim3(256), lds, s, a);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int run_mlp(annp_hip_handle *h, const MlpArgs &a, hipStream_t s)
+{
+    const int ks0 = (h->nsf + 3) / 4, mt = (h->nnod + 15) / 16;
+    if (h->nl == 3 && ks0 == 7 && mt == 1) return launch_mlp<7, 1, 3>(h, a, s);
+    if (h->nl == 3 && ks0 == 7 && mt == 2) return launch_mlp<7, 2, 3>(h, a, s);
+    if (h->nl == 3 && ks0 == 8 && mt == 1) return launch_mlp<8, 1, 3>(h, a, s);
+    if (h->nl == 3 && ks0 == 8 && mt == 2) return launch_mlp<8, 2, 3>(h, a, s);
+    return fail(h, ANNP_HIP_ESHAPE, "no network kernel for nsf=%d nnod=%d layers=%d", h->nsf, h->nnod, h->nl);
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- one evaluation on device-resident data ----------------------------------------
+int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_x, const int *d_ilist,
+                        const int *d_numneigh, const long long *d_first, const int *d_neigh, int max_numneigh,
+                        double *d_f, double *d_eatom, double *d_eng, double *d_virial, hipStream_t s)
+{
+    if (inum <= 0) return 0;
+    int rc;
+    if ((rc = ensure(h, h->G, (size_t)inum * ANNP_GPAD))) return rc;
+    if ((rc = ensure(h, h->coef, (size_t)inum * ANNP_CPAD))) return rc;
+    if ((rc = ensure(h, h->ncount, (size_t)inum))) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, 2 * sizeof(int), s));
+    if (h->timing) {
+        h->ev = h->evring.data() + 4 * (size_t)(h->ev_count % annp_hip_handle::kRing);
+        HIP_TRY(h, hipEventRecord(h->ev[0], s));
+    }
+
+    const int blocks = (inum + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK;
+    const int cap_list = std::max(16, round_up(max_numneigh, 16));
+
+    MlpArgs m{};
+    m.inum = inum; m.ilist = d_ilist; m.nsf = h->nsf; m.nnod = h->nnod; m.nl = h->nl;
+    for (int l = 0; l < h->nl; l++) { m.act[l] = h->flagact[l]; m.W[l] = h->dW[l]; m.B[l] = h->dB[l]; }
+    m.nmul = h->d_norm; m.nsub = h->d_norm + ANNP_GPAD; m.nden = h->d_norm + 2 * ANNP_GPAD; m.cmul = h->d_norm + 3 * ANNP_GPAD;
+    m.e_scale = h->e_scale; m.e_shift = h->e_shift; m.e_atom = h->e_atom;
+    m.G = h->G.p; m.coef = h->coef.p; m.eatom = d_eatom; m.eng = d_eng;
+    m.np = h->npsf; m.nt = h->ntsf;
+
+    if (h->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
+        if (!(h->npsf == 9 && h->ntsf == 19))
+            return fail(h, ANNP_HIP_ESHAPE, "Chebyshev kernels are built for npsf=9 ntsf=19 (got %d %d)", h->npsf, h->ntsf);
+        FeArgs a{};
+        a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
+        a.cutsq = h->cutsq; a.rc_list = std::sqrt(h->cutsq); a.rc_par = h->cut;
+        a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.ncount = h->ncount.p;
+        a.errflag = h->d_flags;
+        // pass 1: capacity = list length (upper bound of the in-cutoff count)
+        a.n_cap = cap_list;
+        size_t lds1 = fe_desc_lds_per_wave(a.n_cap) * ANNP_WAVES_PER_BLOCK;
+        if (lds1 > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "neighbour list too long for LDS (%d)", max_numneigh);
+        hipLaunchKernelGGL((annp_fe_desc<9, 19>), dim3(blocks), dim3(256), lds1, s, a);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(annp_max_int, dim3(std::min(1024, (inum + 255) / 256)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
+        HIP_TRY(h, hipGetLastError());
+        if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
+        // pass 2
+        m.act_plain = 0; m.energy_raw = 0; m.mode = 0;
+        if ((rc = run_mlp(h, m, s))) return rc;
+        if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
+        // pass 3: size the LDS records by the in-cutoff maximum just measured
+        HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (h->h_flags[0] > 0)
+            return fail(h, ANNP_HIP_ENEIGHCAP, "in-cutoff neighbours %d exceed capacity %d", h->h_flags[0], a.n_cap);
+        a.n_cap = std::max(16, round_up(h->h_flags[1], 16));
+        size_t lds3 = fe_force_lds_per_wave(a.n_cap) * ANNP_WAVES_PER_BLOCK;
+        if (lds3 > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "too many in-cutoff neighbours for LDS (%d)", h->h_flags[1]);
+        if (d_virial) hipLaunchKernelGGL((annp_fe_force<9, 19, true>), dim3(blocks), dim3(256), lds3, s, a);
+        else hipLaunchKernelGGL((annp_fe_force<9, 19, false>), dim3(blocks), dim3(256), lds3, s, a);
+        HIP_TRY(h, hipGetLastError());
+    } else {
+        NiArgs a{};
+        a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
+        a.npsf = h->npsf; a.ntsf = h->ntsf; a.sym = h->d_sym; a.compat = h->ni_compat;
+        a.rc_rad = h->sym_rad[2]; a.rc_ang = h->sym_ang[3];
+        a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.ncount = h->ncount.p; a.errflag = h->d_flags;
+        a.n_cap = NI_NCAP;
+        int rcn = ni_launch_desc(a, blocks, s);
+        if (rcn) return fail(h, ANNP_HIP_ESHAPE, "Behler kernels support npsf<=%d ntsf<=%d", NI_MAXP, NI_MAXT);
+        HIP_TRY(h, hipGetLastError());
+        if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
+        m.act_plain = 1; m.energy_raw = 1; m.mode = 1;
+        if ((rc = run_mlp(h, m, s))) return rc;
+        if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
+        ni_launch_force(a, blocks, d_virial != nullptr, s);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[3], s)); h->ev_count++; }
+    (void)nall;
+    return 0;
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+int annp_hip_abi_version(void) { return ANNP_HIP_ABI_VERSION; }
+
+const char *annp_hip_last_error(const annp_hip_handle *h) { return h ? h->err.c_str() : g_init_error.c_str(); }
+
+double annp_hip_bytes(const annp_hip_handle *h) { return h ? (double)h->bytes : 0.0; }
+
+void annp_hip_clear(annp_hip_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int l = 0; l < MLP_MAXL; l++) { if (h->dW[l]) (void)hipFree(h->dW[l]); if (h->dB[l]) (void)hipFree(h->dB[l]); }
+    if (h->d_norm) (void)hipFree(h->d_norm);
+    if (h->d_sym) (void)hipFree(h->d_sym);
+    release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom);
+    release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount);
+    release(h, h->first);
+    neigh_release(h->nb);
+    if (h->d_scalars) (void)hipFree(h->d_scalars);
+    if (h->d_flags) (void)hipFree(h->d_flags);
+    if (h->h_flags) (void)hipHostFree(h->h_flags);
+    if (h->h_scalars) (void)hipHostFree(h->h_scalars);
+    for (hipEvent_t e : h->evring) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device,
+                  int nlocal_hint, int nall_hint, int max_nbors_hint)
+{
+    if (!handle || !p) return fail(nullptr, ANNP_HIP_EARG, "null argument");
+    *handle = nullptr;
+    if (p->struct_bytes != (int)sizeof(annp_hip_params))
+        return fail(nullptr, ANNP_HIP_EARG, "annp_hip_params size mismatch (%d vs %d)", p->struct_bytes, (int)sizeof(annp_hip_params));
+    const int nl = p->ntl - 1;
+    if (nl < 2 || nl > MLP_MAXL || p->nsf < 1 || p->nsf > ANNP_GPAD || p->nnod < 1 || p->nnod > 32 ||
+        p->npsf + p->ntsf != p->nsf || !p->flagact || !p->sfnor_scal || !p->sfnor_avg || !p->weight_all || !p->bias_all)
+        return fail(nullptr, ANNP_HIP_ESHAPE, "unsupported network shape ntl=%d nnod=%d nsf=%d (%d+%d)", p->ntl, p->nnod, p->nsf, p->npsf, p->ntsf);
+    if (p->descriptor == ANNP_HIP_DESC_BEHLER && (!p->cofsymrad || !p->cofsymang))
+        return fail(nullptr, ANNP_HIP_EARG, "Behler descriptor needs cofsymrad/cofsymang");
+    if (p->map) {
+        for (int t = 1; t <= p->ntypes; t++)
+            if (p->map[t] != 0) return fail(nullptr, ANNP_HIP_ESHAPE, "every atom type must map to the potential's single element");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, ANNP_HIP_EDEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(nullptr, ANNP_HIP_EDEVICE, "device %d out of range (%d visible)", device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, ANNP_HIP_EDEVICE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, ANNP_HIP_EDEVICE, "device %d is %s; this library carries gfx950 code objects only", device, prop.gcnArchName);
+
+    annp_hip_handle *h = new (std::nothrow) annp_hip_handle();
+    if (!h) return fail(nullptr, ANNP_HIP_ENOMEM, "host allocation failed");
+    h->device = device;
+    auto bail = [&](int code) { g_init_error = h->err; annp_hip_clear(h); return code; };
+#define INIT_TRY(call)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            fail(h, 0, "%s failed: %s", #call, hipGetErrorString(e_));                                   \
+            return bail(e_ == hipErrorOutOfMemory ? ANNP_HIP_ENOMEM : ANNP_HIP_EDEVICE);                 \
+        }                                                                                                \
+    } while (0)
+    INIT_TRY(hipSetDevice(device));
+    INIT_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->descriptor = p->descriptor; h->ntypes = p->ntypes; h->ntl = p->ntl; h->nhl = p->nhl; h->nnod = p->nnod;
+    h->nsf = p->nsf; h->npsf = p->npsf; h->ntsf = p->ntsf; h->nl = nl; h->ni_compat = p->ni_compat;
+    h->e_scale = p->e_scale; h->e_shift = p->e_shift; h->e_atom = p->e_atom; h->cut = p->cut;
+    h->cutsq = p->cutsq ? p->cutsq[(p->ntypes + 1) * 1 + 1] : p->cut * p->cut;
+    for (int l = 0; l < nl; l++) h->flagact[l] = p->flagact[l];
+
+    for (int l = 0; l < nl; l++) {
+        const int nr = (l == nl - 1) ? 1 : p->nnod, nc = (l == 0) ? p->nsf : p->nnod;
+        INIT_TRY(hipMalloc((void **)&h->dW[l], sizeof(double) * nr * nc));
+        INIT_TRY(hipMalloc((void **)&h->dB[l], sizeof(double) * nr));
+        INIT_TRY(hipMemcpy(h->dW[l], p->weight_all[l], sizeof(double) * nr * nc, hipMemcpyHostToDevice));
+        INIT_TRY(hipMemcpy(h->dB[l], p->bias_all[l], sizeof(double) * nr, hipMemcpyHostToDevice));
+        h->bytes += sizeof(double) * (nr * nc + nr);
+    }
+    {   // normalisation / coefficient tables
+        std::vector<double> t(4 * ANNP_GPAD, 0.0);
+        for (int k = 0; k < ANNP_GPAD; k++) { t[k] = 0.0; t[ANNP_GPAD + k] = 0.0; t[2 * ANNP_GPAD + k] = 1.0; t[3 * ANNP_GPAD + k] = 0.0; }
+        for (int k = 0; k < p->nsf; k++) {
+            if (p->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
+                // G_k = s_k * sum  (fe:647,678);  Ghat = G - s_k avg_k (fe:178-180);  c_k = e_scale s_k dE/dGhat_k (fe:197)
+                t[k] = p->sfnor_scal[k];
+                t[ANNP_GPAD + k] = p->sfnor_scal[k] * p->sfnor_avg[k];
+                t[2 * ANNP_GPAD + k] = 1.0;
+                t[3 * ANNP_GPAD + k] = p->e_scale * p->sfnor_scal[k];
+            } else {
+                // Ghat = (G - sf_min)/(sf_max - sf_min) (ni:168-170);  F = -dE/dGhat dG / (sf_max-sf_min) * CFFORCE (ni:186-189)
+                t[k] = 1.0;
+                t[ANNP_GPAD + k] = p->sfnor_avg[k];
+                t[2 * ANNP_GPAD + k] = p->sfnor_scal[k];
+                t[3 * ANNP_GPAD + k] = 1.0 / p->sfnor_scal[k];
+            }
+        }
+        INIT_TRY(hipMalloc((void **)&h->d_norm, sizeof(double) * t.size()));
+        INIT_TRY(hipMemcpy(h->d_norm, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+        h->bytes += sizeof(double) * t.size();
+    }
+    if (p->descriptor == ANNP_HIP_DESC_BEHLER) {
+        h->sym_rad.assign(p->cofsymrad, p->cofsymrad + 3 * p->npsf);
+        h->sym_ang.assign(p->cofsymang, p->cofsymang + 4 * p->ntsf);
+        std::vector<double> t(h->sym_rad);
+        t.insert(t.end(), h->sym_ang.begin(), h->sym_ang.end());
+        INIT_TRY(hipMalloc((void **)&h->d_sym, sizeof(double) * t.size()));
+        INIT_TRY(hipMemcpy(h->d_sym, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+        h->bytes += sizeof(double) * t.size();
+    }
+    INIT_TRY(hipMalloc((void **)&h->d_scalars, 8 * sizeof(double)));
+    INIT_TRY(hipMalloc((void **)&h->d_flags, 4 * sizeof(int)));
+    INIT_TRY(hipHostMalloc((void **)&h->h_flags, 4 * sizeof(int)));
+    INIT_TRY(hipHostMalloc((void **)&h->h_scalars, 8 * sizeof(double)));
+    h->bytes += 8 * sizeof(double) + 4 * sizeof(int);
+    // kernels may ask for the whole LDS
+    {
+        const int full = 160 * 1024;
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc<9, 19>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+    }
+    // sizing hints, as annp_gpu_init takes them (buffers still grow on demand)
+    if (nlocal_hint > 0) {
+        if (ensure(h, h->G, (size_t)nlocal_hint * ANNP_GPAD) || ensure(h, h->coef, (size_t)nlocal_hint * ANNP_CPAD) ||
+            ensure(h, h->ncount, (size_t)nlocal_hint))
+            return bail(ANNP_HIP_ENOMEM);
+    }
+    (void)nall_hint; (void)max_nbors_hint;
+#undef INIT_TRY
+    *handle = h;
+    return ANNP_HIP_OK;
+}
+
+int annp_hip_set_timing(annp_hip_handle *h, int enable)
+{
+    if (!h) return ANNP_HIP_EARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (enable && h->evring.empty()) {
+        h->evring.assign((size_t)annp_hip_handle::kRing * 4, nullptr);
+        for (hipEvent_t &e : h->evring) HIP_TRY(h, hipEventCreate(&e));
+    }
+    h->timing = enable != 0;
+    h->ev_count = 0;
+    return 0;
+}
+
+static int timing_slot(annp_hip_handle *h, long long k, double *ms4)
+{
+    hipEvent_t *ev = h->evring.data() + 4 * (size_t)(k % annp_hip_handle::kRing);
+    HIP_TRY(h, hipEventSynchronize(ev[3]));
+    float a = 0, b = 0, c = 0, d = 0;
+    HIP_TRY(h, hipEventElapsedTime(&a, ev[0], ev[1]));
+    HIP_TRY(h, hipEventElapsedTime(&b, ev[1], ev[2]));
+    HIP_TRY(h, hipEventElapsedTime(&c, ev[2], ev[3]));
+    HIP_TRY(h, hipEventElapsedTime(&d, ev[0], ev[3]));
+    ms4[0] = a; ms4[1] = b; ms4[2] = c; ms4[3] = d;
+    return 0;
+}
+
+int annp_hip_last_timing(annp_hip_handle *h, double *ms4)
+{
+    if (!h || !ms4) return ANNP_HIP_EARG;
+    if (h->ev_count == 0) return fail(h, ANNP_HIP_EARG, "no timed evaluation recorded");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return timing_slot(h, h->ev_count - 1, ms4);
+}
+
+int annp_hip_timing_stats(annp_hip_handle *h, double *ms4_mean, int *nsamples)
+{
+    if (!h || !ms4_mean) return ANNP_HIP_EARG;
+    if (h->ev_count == 0) return fail(h, ANNP_HIP_EARG, "no timed evaluation recorded");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const long long n = std::min<long long>(h->ev_count, annp_hip_handle::kRing);
+    double acc[4] = {0, 0, 0, 0};
+    for (long long k = h->ev_count - n; k < h->ev_count; k++) {
+        double t[4];
+        int rc = timing_slot(h, k, t);
+        if (rc) return rc;
+        for (int q = 0; q < 4; q++) acc[q] += t[q];
+    }
+    for (int q = 0; q < 4; q++) ms4_mean[q] = acc[q] / (double)n;
+    if (nsamples) *nsamples = (int)n;
+    return 0;
+}
+
+int annp_hip_last_counts(annp_hip_handle *h, int *counts, int inum)
+{
+    if (!h || !counts || inum < 0 || (size_t)inum > h->ncount.cap) return h ? fail(h, ANNP_HIP_EARG, "last_counts: bad argument") : ANNP_HIP_EARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(counts, h->ncount.p, sizeof(int) * (size_t)inum, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int annp_hip_sync(annp_hip_handle *h)
+{
+    if (!h) return ANNP_HIP_EARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    int e = h->deferred_error;
+    h->deferred_error = 0;
+    return e;
+}
+
+int annp_hip_compute_device(annp_hip_handle *h, int inum, int nall,
+                            const double *d_x, const int *d_type, const int *d_ilist,
+                            const int *d_numneigh, const long long *d_first, const int *d_neigh,
+                            int max_numneigh,
+                            double *d_f, double *d_eatom, double *d_eng, double *d_virial, void *stream)
+{
+    if (!h) return ANNP_HIP_EARG;
+    if (inum < 0 || nall < inum || !d_x || !d_f || (inum > 0 && (!d_numneigh || !d_first || !d_neigh)))
+        return fail(h, ANNP_HIP_EARG, "annp_hip_compute_device: bad argument");
+    (void)d_type;   // single-element potentials: the type never enters the arithmetic
+    HIP_TRY(h, hipSetDevice(h->device));
+    return compute_device_impl(h, inum, nall, d_x, d_ilist, d_numneigh, d_first, d_neigh, max_numneigh,
+                               d_f, d_eatom, d_eng, d_virial, (hipStream_t)stream);
+}
+
+int annp_hip_neigh_build_device(annp_hip_handle *h, int nlocal, int nall, const double *d_x, double cutneigh,
+                                const int **d_numneigh, const long long **d_first, const int **d_neigh,
+                                int *max_numneigh, void *stream)
+{
+    if (!h || !d_x || nlocal < 0 || nall < nlocal || cutneigh <= 0) return h ? fail(h, ANNP_HIP_EARG, "neigh_build: bad argument") : ANNP_HIP_EARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::string msg;
+    size_t before = h->nb.bytes;
+    int rc = neigh_build(h->nb, nlocal, nall, d_x, cutneigh, (hipStream_t)stream, msg);
+    h->bytes += h->nb.bytes - before;
+    if (rc) return fail(h, rc, "%s", msg.c_str());
+    if (d_numneigh) *d_numneigh = h->nb.numneigh;
+    if (d_first) *d_first = h->nb.first;
+    if (d_neigh) *d_neigh = h->nb.neigh;
+    if (max_numneigh) *max_numneigh = h->nb.max_numneigh;
+    return 0;
+}
+
+// ---- host-pointer entry points --------------------------------------------------------
+static int host_finish(annp_hip_handle *h, int inum, int nall, int eflag, int vflag, int eatom_flag,
+                       double *f, double *eng_vdwl, double *eatom, double *virial,
+                       std::vector<double> &hf, std::vector<double> &he)
+{
+    hipStream_t s = h->stream;
+    hf.resize((size_t)nall * 3);
+    HIP_TRY(h, hipMemcpyAsync(hf.data(), h->f.p, sizeof(double) * nall * 3, hipMemcpyDeviceToHost, s));
+    if (eflag && eatom_flag && eatom) {
+        he.resize((size_t)nall);
+        HIP_TRY(h, hipMemcpyAsync(he.data(), h->eatom.p, sizeof(double) * nall, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->h_scalars, h->d_scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    for (size_t k = 0; k < (size_t)nall * 3; k++) f[k] += hf[k];                  // fe:199,211: += / -=
+    if (eflag && eng_vdwl) *eng_vdwl += h->h_scalars[0];                          // fe:185
+    if (eflag && eatom_flag && eatom) for (int k = 0; k < nall; k++) eatom[k] += he[k];   // fe:186
+    if (vflag && virial) for (int k = 0; k < 6; k++) virial[k] += h->h_scalars[1 + k];
+    (void)inum;
+    return 0;
+}
+
+int annp_hip_compute(annp_hip_handle *h, int ago, int inum, int nall, int nghost,
+                     const double *host_x, const int *host_type,
+                     const int *ilist, const int *numj, const int *const *firstneigh,
+                     int eflag, int vflag, int eatom_flag, int vatom_flag,
+                     double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom)
+{
+    if (!h) return ANNP_HIP_EARG;
+    if (inum < 0 || nall < inum || nghost < 0 || !host_x || !f || (inum > 0 && (!ilist || !numj || !firstneigh)))
+        return fail(h, ANNP_HIP_EARG, "annp_hip_compute: bad argument");
+    if (vatom_flag || vatom) return fail(h, ANNP_HIP_ESHAPE, "per-atom virial is not implemented");
+    (void)host_type;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    // neighbour list: re-packed to CSR and uploaded when LAMMPS rebuilt it (ago == 0)
+    if (ago == 0 || !h->list_valid) {
+        h->h_first.assign((size_t)nall + 1, 0);
+        h->h_numneigh.assign((size_t)nall, 0);
+        long long tot = 0;
+        int mx = 0;
+        for (int ii = 0; ii < inum; ii++) {
+            const int i = ilist[ii];
+            if (i < 0 || i >= nall) return fail(h, ANNP_HIP_EARG, "ilist[%d]=%d out of range", ii, i);
+            h->h_first[i] = tot;
+            h->h_numneigh[i] = numj[i];
+            tot += numj[i];
+            mx = std::max(mx, numj[i]);
+        }
+        h->h_neigh.resize((size_t)std::max<long long>(tot, 1));
+        for (int ii = 0; ii < inum; ii++) {
+            const int i = ilist[ii];
+            if (numj[i] > 0) std::memcpy(h->h_neigh.data() + h->h_first[i], firstneigh[i], sizeof(int) * (size_t)numj[i]);
+        }
+        if ((rc = ensure(h, h->first, (size_t)nall + 1)) || (rc = ensure(h, h->numneigh, (size_t)nall)) ||
+            (rc = ensure(h, h->neigh, h->h_neigh.size())) || (rc = ensure(h, h->ilist, (size_t)std::max(inum, 1))))
+            return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->first.p, h->h_first.data(), sizeof(long long) * ((size_t)nall + 1), hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(h->numneigh.p, h->h_numneigh.data(), sizeof(int) * (size_t)nall, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(h->neigh.p, h->h_neigh.data(), sizeof(int) * h->h_neigh.size(), hipMemcpyHostToDevice, s));
+        if (inum > 0) HIP_TRY(h, hipMemcpyAsync(h->ilist.p, ilist, sizeof(int) * (size_t)inum, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipStreamSynchronize(s));     // h_* are reused next rebuild
+        h->list_max = mx;
+        h->list_valid = true;
+    }
+    if ((rc = ensure(h, h->x, (size_t)nall * 3)) || (rc = ensure(h, h->f, (size_t)nall * 3)) || (rc = ensure(h, h->eatom, (size_t)nall)))
+        return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->x.p, host_x, sizeof(double) * (size_t)nall * 3, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemsetAsync(h->f.p, 0, sizeof(double) * (size_t)nall * 3, s));
+    HIP_TRY(h, hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), s));
+    const bool want_eatom = eflag && eatom_flag && eatom;
+    if (want_eatom) HIP_TRY(h, hipMemsetAsync(h->eatom.p, 0, sizeof(double) * (size_t)nall, s));
+    rc = compute_device_impl(h, inum, nall, h->x.p, h->ilist.p, h->numneigh.p, h->first.p, h->neigh.p, h->list_max,
+                             h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr, s);
+    if (rc) return rc;
+    std::vector<double> hf, he;
+    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, hf, he);
+}
+
+int annp_hip_compute_n(annp_hip_handle *h, int ago, int inum, int nall, int nghost,
+                       const double *host_x, const int *host_type,
+                       const double *sublo, const double *subhi, double cutneigh,
+                       int eflag, int vflag, int eatom_flag, int vatom_flag,
+                       double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom)
+{
+    if (!h) return ANNP_HIP_EARG;
+    if (inum < 0 || nall < inum || nghost < 0 || !host_x || !f || cutneigh <= 0)
+        return fail(h, ANNP_HIP_EARG, "annp_hip_compute_n: bad argument");
+    if (vatom_flag || vatom) return fail(h, ANNP_HIP_ESHAPE, "per-atom virial is not implemented");
+    (void)host_type; (void)sublo; (void)subhi;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = ensure(h, h->x, (size_t)nall * 3)) || (rc = ensure(h, h->f, (size_t)nall * 3)) || (rc = ensure(h, h->eatom, (size_t)nall)))
+        return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->x.p, host_x, sizeof(double) * (size_t)nall * 3, hipMemcpyHostToDevice, s));
+    if (ago == 0 || !h->nb.valid || h->nb.nlocal != inum || h->nb.nall != nall) {
+        std::string msg;
+        size_t before = h->nb.bytes;
+        rc = neigh_build(h->nb, inum, nall, h->x.p, cutneigh, s, msg);
+        h->bytes += h->nb.bytes - before;
+        if (rc) return fail(h, rc, "%s", msg.c_str());
+    }
+    HIP_TRY(h, hipMemsetAsync(h->f.p, 0, sizeof(double) * (size_t)nall * 3, s));
+    HIP_TRY(h, hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), s));
+    const bool want_eatom = eflag && eatom_flag && eatom;
+    if (want_eatom) HIP_TRY(h, hipMemsetAsync(h->eatom.p, 0, sizeof(double) * (size_t)nall, s));
+    rc = compute_device_impl(h, inum, nall, h->x.p, nullptr, h->nb.numneigh, h->nb.first, h->nb.neigh, h->nb.max_numneigh,
+                             h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr, s);
+    if (rc) return rc;
+    std::vector<double> hf, he;
+    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, hf, he);
+}
+
+}  // extern "C"

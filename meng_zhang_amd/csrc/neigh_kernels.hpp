@@ -1,0 +1,279 @@
+// neigh_kernels.hpp -- binned full neighbour list built on the device.
+//
+// Plays the role of the reference's device-side neighbouring
+// (annp_gpu_compute_n -> lal_base_annp.cpp build_nbor_list, which calls LAMMPS
+// lib/gpu's Neighbor class): full list, r^2 <= cutneigh^2, owned atoms first,
+// ghosts after, no special-bond exclusions.  Output is CSR (numneigh, first, neigh);
+// neighbours of an atom come out in a fixed order (bins in raster order, atoms in
+// a bin by ascending index), so a rebuild of the same positions is bit-identical.
+#pragma once
+#include <string>
+
+#include "annp_common.hpp"
+
+namespace annp {
+
+struct NeighBuild {
+    // outputs
+    int *numneigh = nullptr;
+    long long *first = nullptr;
+    int *neigh = nullptr;
+    int max_numneigh = 0;
+    int nlocal = 0, nall = 0;
+    bool valid = false;
+    // scratch
+    int *binof = nullptr, *bincount = nullptr, *binstart = nullptr, *binfill = nullptr, *binitems = nullptr;
+    long long *blocksum = nullptr;
+    double *bbox = nullptr;         // device: lo[3], hi[3]
+    int *dmax = nullptr;
+    size_t cap_atoms = 0, cap_bins = 0, cap_neigh = 0, cap_local = 0;
+    size_t bytes = 0;
+};
+
+inline void neigh_release(NeighBuild &nb)
+{
+    void *ptrs[] = {nb.numneigh, nb.first, nb.neigh, nb.binof, nb.bincount, nb.binstart, nb.binfill, nb.binitems, nb.blocksum, nb.bbox, nb.dmax};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    nb = NeighBuild();
+}
+
+__global__ void annp_max_int(const int *v, int n, int *out)
+{
+    int m = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) m = max(m, v[k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
+__global__ __launch_bounds__(1024) void annp_bbox(const double *x, int n, double *bbox)
+{
+    __shared__ double slo[3][16], shi[3][16];
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int k = threadIdx.x; k < n; k += blockDim.x)
+        for (int d = 0; d < 3; d++) { const double v = x[3 * (size_t)k + d]; lo[d] = fmin(lo[d], v); hi[d] = fmax(hi[d], v); }
+    for (int d = 0; d < 3; d++) {
+        for (int off = 32; off > 0; off >>= 1) { lo[d] = fmin(lo[d], __shfl_xor(lo[d], off, 64)); hi[d] = fmax(hi[d], __shfl_xor(hi[d], off, 64)); }
+        if ((threadIdx.x & 63) == 0) { slo[d][threadIdx.x >> 6] = lo[d]; shi[d][threadIdx.x >> 6] = hi[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        double l = 1e300, hh = -1e300;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) { l = fmin(l, slo[d][w]); hh = fmax(hh, shi[d][w]); }
+        bbox[d] = l; bbox[3 + d] = hh;
+    }
+}
+
+struct BinGeom { double lo[3]; double inv; int nb[3]; };
+
+__device__ __forceinline__ int bin_of(const BinGeom &g, double px, double py, double pz)
+{
+    int c0 = (int)floor((px - g.lo[0]) * g.inv), c1 = (int)floor((py - g.lo[1]) * g.inv), c2 = (int)floor((pz - g.lo[2]) * g.inv);
+    c0 = min(max(c0, 0), g.nb[0] - 1); c1 = min(max(c1, 0), g.nb[1] - 1); c2 = min(max(c2, 0), g.nb[2] - 1);
+    return (c2 * g.nb[1] + c1) * g.nb[0] + c0;
+}
+
+__global__ void annp_bin_count(const double *x, int n, BinGeom g, int *binof, int *bincount)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int b = bin_of(g, x[3 * (size_t)k], x[3 * (size_t)k + 1], x[3 * (size_t)k + 2]);
+    binof[k] = b;
+    atomicAdd(&bincount[b], 1);
+}
+
+// exclusive scan of up to a few 10^5 ints by one block (bins are few)
+__global__ __launch_bounds__(1024) void annp_scan_bins(const int *cnt, int n, int *start)
+{
+    __shared__ int part[1024];
+    const int per = (n + 1023) / 1024;
+    const int b0 = threadIdx.x * per, b1 = min(n, b0 + per);
+    int s = 0;
+    for (int k = b0; k < b1; k++) s += cnt[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int k = 0; k < 1024; k++) { const int t = part[k]; part[k] = run; run += t; } start[n] = run; }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int k = b0; k < b1; k++) { start[k] = run; run += cnt[k]; }
+}
+
+__global__ void annp_bin_fill(int n, const int *binof, const int *binstart, int *binfill, int *binitems)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int b = binof[k];
+    binitems[binstart[b] + atomicAdd(&binfill[b], 1)] = k;
+}
+
+// make the order inside every bin deterministic (ascending atom index)
+__global__ void annp_bin_sort(int nbins, const int *binstart, int *binitems)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbins) return;
+    const int s = binstart[b], e = binstart[b + 1];
+    for (int i = s + 1; i < e; i++) {
+        const int v = binitems[i];
+        int j = i - 1;
+        while (j >= s && binitems[j] > v) { binitems[j + 1] = binitems[j]; j--; }
+        binitems[j + 1] = v;
+    }
+}
+
+// one wave per owned atom; FILL=false counts, FILL=true writes
+template <bool FILL>
+__global__ __launch_bounds__(256) void annp_neigh_pass(const double *x, int nlocal, BinGeom g, double rc2,
+                                                       const int *binof, const int *binstart, const int *binitems,
+                                                       int *numneigh, const long long *first, int *neigh)
+{
+    const int lane = lane_id();
+    const int i = uniform(blockIdx.x * ANNP_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (i >= nlocal) return;
+    const double xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
+    const int b = binof[i];
+    const int c0 = b % g.nb[0], c1 = (b / g.nb[0]) % g.nb[1], c2 = b / (g.nb[0] * g.nb[1]);
+    int cnt = 0;
+    int *out = FILL ? neigh + first[i] : nullptr;
+    for (int z = c2 - 1; z <= c2 + 1; z++) {
+        if (z < 0 || z >= g.nb[2]) continue;
+        for (int y = c1 - 1; y <= c1 + 1; y++) {
+            if (y < 0 || y >= g.nb[1]) continue;
+            const int x0 = max(c0 - 1, 0), x1 = min(c0 + 1, g.nb[0] - 1);
+            // the x-run of bins is contiguous in binitems
+            const int s = binstart[(z * g.nb[1] + y) * g.nb[0] + x0], e = binstart[(z * g.nb[1] + y) * g.nb[0] + x1 + 1];
+            for (int k0 = s; k0 < e; k0 += 64) {
+                const int k = k0 + lane;
+                bool in = false;
+                int j = 0;
+                if (k < e) {
+                    j = binitems[k];
+                    const double dx = xi - x[3 * (size_t)j], dy = yi - x[3 * (size_t)j + 1], dz = zi - x[3 * (size_t)j + 2];
+                    in = (j != i) && (dx * dx + dy * dy + dz * dz <= rc2);
+                }
+                const unsigned long long m = __ballot(in);
+                if (FILL && in) out[cnt + __popcll(m & ((1ull << lane) - 1ull))] = j;
+                cnt += __popcll(m);
+            }
+        }
+    }
+    if (!FILL && lane == 0) numneigh[i] = cnt;
+}
+
+// exclusive scan of numneigh -> first (int64), three small kernels
+__global__ __launch_bounds__(1024) void annp_scan_block_sums(const int *v, int n, long long *bs)
+{
+    __shared__ long long sh[16];
+    const int k = blockIdx.x * 1024 + threadIdx.x;
+    long long s = (k < n) ? v[k] : 0;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { long long t = 0; for (int w = 0; w < 16; w++) t += sh[w]; bs[blockIdx.x] = t; }
+}
+__global__ void annp_scan_block_offsets(long long *bs, int nblocks, long long *total)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        long long run = 0;
+        for (int k = 0; k < nblocks; k++) { const long long t = bs[k]; bs[k] = run; run += t; }
+        *total = run;
+    }
+}
+__global__ __launch_bounds__(1024) void annp_scan_finish(const int *v, int n, const long long *bs, long long *first)
+{
+    __shared__ long long sh[1024];
+    const int k = blockIdx.x * 1024 + threadIdx.x;
+    sh[threadIdx.x] = (k < n) ? v[k] : 0;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {      // Hillis-Steele inclusive scan
+        long long t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (k < n) first[k] = bs[blockIdx.x] + sh[threadIdx.x] - v[k];
+}
+
+template <typename T>
+inline int nb_alloc(T *&p, size_t &cap, size_t n, size_t &bytes, std::string &msg)
+{
+    if (n <= cap && p) return 0;
+    if (p) { (void)hipFree(p); bytes -= cap * sizeof(T); p = nullptr; }
+    const size_t want = n + n / 8 + 64;
+    if (hipMalloc((void **)&p, want * sizeof(T)) != hipSuccess) { msg = "neighbour build: out of device memory"; cap = 0; return -3; }
+    cap = want;
+    bytes += want * sizeof(T);
+    return 0;
+}
+
+inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, double cutneigh, hipStream_t s, std::string &msg)
+{
+#define NB_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { msg = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? -3 : -4; } } while (0)
+    nb.valid = false;
+    if (nall <= 0 || nlocal <= 0) { nb.nlocal = nlocal; nb.nall = nall; nb.max_numneigh = 0; return 0; }
+    if (!nb.bbox) { NB_TRY(hipMalloc((void **)&nb.bbox, 6 * sizeof(double))); NB_TRY(hipMalloc((void **)&nb.dmax, 4 * sizeof(long long))); nb.bytes += 6 * sizeof(double) + 4 * sizeof(long long); }
+    size_t cap;
+    cap = nb.cap_atoms; if (nb_alloc(nb.binof, cap, (size_t)nall, nb.bytes, msg)) return -3;
+    cap = nb.cap_atoms; if (nb_alloc(nb.binitems, cap, (size_t)nall, nb.bytes, msg)) return -3;
+    nb.cap_atoms = cap;
+    hipLaunchKernelGGL(annp_bbox, dim3(1), dim3(1024), 0, s, d_x, nall, nb.bbox);
+    double hb[6];
+    NB_TRY(hipMemcpyAsync(hb, nb.bbox, sizeof(hb), hipMemcpyDeviceToHost, s));
+    NB_TRY(hipStreamSynchronize(s));
+    BinGeom g;
+    long long nbins = 1;
+    for (int d = 0; d < 3; d++) {
+        g.lo[d] = hb[d];
+        g.nb[d] = (int)std::floor((hb[3 + d] - hb[d]) / cutneigh) + 1;
+        if (g.nb[d] < 1) g.nb[d] = 1;
+        nbins *= g.nb[d];
+    }
+    g.inv = 1.0 / cutneigh;
+    if (nbins > (1ll << 27)) { msg = "neighbour build: too many bins"; return -1; }
+    cap = nb.cap_bins; if (nb_alloc(nb.bincount, cap, (size_t)nbins + 1, nb.bytes, msg)) return -3;
+    cap = nb.cap_bins; if (nb_alloc(nb.binstart, cap, (size_t)nbins + 1, nb.bytes, msg)) return -3;
+    cap = nb.cap_bins; if (nb_alloc(nb.binfill, cap, (size_t)nbins + 1, nb.bytes, msg)) return -3;
+    nb.cap_bins = cap;
+    NB_TRY(hipMemsetAsync(nb.bincount, 0, sizeof(int) * (nbins + 1), s));
+    NB_TRY(hipMemsetAsync(nb.binfill, 0, sizeof(int) * (nbins + 1), s));
+    const int tb = 256, gb = (nall + tb - 1) / tb;
+    hipLaunchKernelGGL(annp_bin_count, dim3(gb), dim3(tb), 0, s, d_x, nall, g, nb.binof, nb.bincount);
+    hipLaunchKernelGGL(annp_scan_bins, dim3(1), dim3(1024), 0, s, nb.bincount, (int)nbins, nb.binstart);
+    hipLaunchKernelGGL(annp_bin_fill, dim3(gb), dim3(tb), 0, s, nall, nb.binof, nb.binstart, nb.binfill, nb.binitems);
+    hipLaunchKernelGGL(annp_bin_sort, dim3((int)((nbins + tb - 1) / tb)), dim3(tb), 0, s, (int)nbins, nb.binstart, nb.binitems);
+    // count
+    cap = nb.cap_local; if (nb_alloc(nb.numneigh, cap, (size_t)nall, nb.bytes, msg)) return -3;
+    cap = nb.cap_local; if (nb_alloc(nb.first, cap, (size_t)nall + 1, nb.bytes, msg)) return -3;
+    {
+        size_t c2 = nb.blocksum ? nb.cap_local : 0;
+        if (nb_alloc(nb.blocksum, c2, (size_t)(nall / 1024 + 2), nb.bytes, msg)) return -3;
+    }
+    nb.cap_local = cap;
+    NB_TRY(hipMemsetAsync(nb.numneigh, 0, sizeof(int) * (size_t)nall, s));
+    const int wb = (nlocal + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK;
+    const double rc2 = cutneigh * cutneigh;
+    hipLaunchKernelGGL((annp_neigh_pass<false>), dim3(wb), dim3(256), 0, s, d_x, nlocal, g, rc2, nb.binof, nb.binstart, nb.binitems,
+                       nb.numneigh, (const long long *)nullptr, (int *)nullptr);
+    const int nblk = (nlocal + 1023) / 1024;
+    long long *dtot = reinterpret_cast<long long *>(nb.dmax) + 1;
+    NB_TRY(hipMemsetAsync(nb.dmax, 0, 4 * sizeof(long long), s));
+    hipLaunchKernelGGL(annp_scan_block_sums, dim3(nblk), dim3(1024), 0, s, nb.numneigh, nlocal, nb.blocksum);
+    hipLaunchKernelGGL(annp_scan_block_offsets, dim3(1), dim3(64), 0, s, nb.blocksum, nblk, dtot);
+    hipLaunchKernelGGL(annp_scan_finish, dim3(nblk), dim3(1024), 0, s, nb.numneigh, nlocal, nb.blocksum, nb.first);
+    hipLaunchKernelGGL(annp_max_int, dim3(std::min(1024, (nlocal + 255) / 256)), dim3(256), 0, s, nb.numneigh, nlocal, nb.dmax);
+    long long hres[2];
+    NB_TRY(hipMemcpyAsync(hres, nb.dmax, sizeof(hres), hipMemcpyDeviceToHost, s));
+    NB_TRY(hipStreamSynchronize(s));
+    nb.max_numneigh = (int)(hres[0] & 0xffffffffll);
+    const long long total = hres[1];
+    cap = nb.cap_neigh; if (nb_alloc(nb.neigh, cap, (size_t)std::max<long long>(total, 1), nb.bytes, msg)) return -3;
+    nb.cap_neigh = cap;
+    hipLaunchKernelGGL((annp_neigh_pass<true>), dim3(wb), dim3(256), 0, s, d_x, nlocal, g, rc2, nb.binof, nb.binstart, nb.binitems,
+                       nb.numneigh, (const long long *)nb.first, nb.neigh);
+    NB_TRY(hipGetLastError());
+    nb.nlocal = nlocal; nb.nall = nall; nb.valid = true;
+    return 0;
+#undef NB_TRY
+}
+
+}  // namespace annp
