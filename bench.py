@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- atom-steps/s of the pair_style annp hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json): bcc-Fe ANNP, 80x80x80 cells x 2 = 1 024 000 atoms, fully
+periodic, a = 2.8553 A, every coordinate displaced by U(-0.05, 0.05) A from a
+counter-based generator, neighbour list cutoff 6.5 + 2.0 A.  With N ranks the box is
+cut into N slabs along x (strong scaling: total work fixed); ghosts travel by
+point-to-point halo exchange over RCCL (meng_zhang_amd/domain.py).
+
+One step = what one MD step asks of the path: positions -> ghosts (forward halo),
+one force evaluation of every owned atom (descriptor pass, FP64-MFMA network pass,
+force pass), ghost forces -> owners (reverse halo), energy all-reduce, and the
+velocity-Verlet update of the owned atoms.  Inputs are resident in HBM before the
+timed region; the neighbour list is built once on the device before it.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the force pass),
+timed with HIP events on its own stream inside the timed region; `cpu_baseline` is the
+CPU oracle ("port" of the reference CPU pair style) timed on this host on a bounded
+sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# per-unit algorithmic work, SURVEY.md 8d (fp64, FMA = 2 flop); split per pass in DESIGN.md
+FLOP_PAIR_DESC, FLOP_NBR_DESC = 86.0, 65.0        # pass 1
+FLOP_PAIR_FORCE, FLOP_NBR_FORCE = 264.0, 110.0    # pass 3 (dominant kernel)
+FLOP_MLP = 1600.0
+BYTES_ATOM_STEP = 9960.0                          # gathered bytes per atom-step
+PEAK_FP64_VECTOR = 78.6                           # TFLOP/s, MI355X (MI355X_MICROARCH.md: half of FP32 vector 157.3)
+PEAK_HBM = 8000.0                                 # GB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cells", type=int, default=80, help="bcc cells per edge (80 -> 1 024 000 atoms)")
+    ap.add_argument("--cpu-sample", type=int, default=65536, help="atoms in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--dt", type=float, default=0.001, help="ps")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from annp_testlib import A_FE, FAST, FE_POT, KIND_FE, System, bcc, oracle_compute, oracle_lib, perturb, read_pot
+    from meng_zhang_amd import PairANNP
+    from meng_zhang_amd.domain import Domain, HaloPlan
+    from meng_zhang_amd.lib import load_library
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- workload -------------------------------------------------------------------
+    rc_list = 8.5
+    x0, box = bcc(args.cells, args.cells, args.cells, A_FE)
+    xg = perturb(x0, 12345, 0.05)
+    natoms = xg.shape[0]
+    plan = HaloPlan(x0, box, (1, 1, 1), rc_list, world, rank)
+    dom = Domain(plan, xg, dev, dist if world > 1 else _NoDist())
+    nlocal, nall = plan.nlocal, plan.nall
+
+    lib = load_library()
+    pair = PairANNP(ntypes=1, device=local_rank)
+    pair.settings([])
+    pair.coeff(["*", "*", FE_POT, "Fe"])
+    pair.init_style()
+    h = pair.handle
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def check(rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, lib.annp_hip_last_error(h).decode()))
+
+    # neighbour list on the device, once (annp_gpu_compute_n analogue), from resident positions
+    p_num, p_first, p_neigh, mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    check(lib.annp_hip_neigh_build_device(h, nlocal, nall, dom.x.data_ptr(), rc_list, C.byref(p_num), C.byref(p_first),
+                                          C.byref(p_neigh), C.byref(mx), stream), "neigh_build")
+    eng = torch.zeros(1, dtype=torch.float64, device=dev)
+    vel = torch.zeros((nlocal, 3), dtype=torch.float64, device=dev)
+    mass = 55.847
+    ftm2v = 1.0 / 1.0364269e-4          # LAMMPS metal units: (eV/A)/(g/mol) -> A/ps^2
+    dtf = 0.5 * args.dt * ftm2v / mass
+
+    def force_eval():
+        dom.f.zero_()
+        eng.zero_()
+        check(lib.annp_hip_compute_device(h, nlocal, nall, dom.x.data_ptr(), None, None, p_num, p_first, p_neigh, mx.value,
+                                          dom.f.data_ptr(), None, eng.data_ptr(), None, stream), "compute_device")
+
+    def step():
+        xo, fo = dom.x[:nlocal], dom.f[:nlocal]
+        vel.add_(fo, alpha=dtf)             # velocity-Verlet, first half
+        xo.add_(vel, alpha=args.dt)
+        dom.forward()                       # Comm::forward_comm
+        force_eval()                        # Pair::compute
+        dom.reverse()                       # Comm::reverse_comm
+        if world > 1:
+            dist.all_reduce(eng)            # thermo: total E_pair
+        vel.add_(fo, alpha=dtf)             # second half
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    dom.forward()
+    force_eval()
+    dom.reverse()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    check(lib.annp_hip_set_timing(h, 1), "set_timing")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt_wall = time.perf_counter() - t0
+    ms4 = np.zeros(4)
+    ns = C.c_int(0)
+    check(lib.annp_hip_timing_stats(h, ms4.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ns)), "timing_stats")
+    lib.annp_hip_set_timing(h, 0)
+    if world > 1:
+        t = torch.tensor([dt_wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_wall = float(t.item())
+    e_total = float(eng.item())
+
+    # ---- algorithmic work of this rank's launches (actual in-cutoff counts) ------------
+    counts = np.zeros(nlocal, dtype=np.int32)
+    check(lib.annp_hip_last_counts(h, counts.ctypes.data_as(C.POINTER(C.c_int)), nlocal), "last_counts")
+    n = counts.astype(np.float64)
+    pairs = float((n * (n - 1) / 2).sum())
+    nbrs = float(n.sum())
+    flop_force = pairs * FLOP_PAIR_FORCE + nbrs * FLOP_NBR_FORCE
+    flop_desc = pairs * FLOP_PAIR_DESC + nbrs * FLOP_NBR_DESC
+    force_ms, desc_ms, mlp_ms = float(ms4[2]), float(ms4[0]), float(ms4[1])
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    value = natoms * args.steps / dt_wall
+    achieved = flop_force / (force_ms * 1e-3) / 1e12
+    out = {
+        "metric": "atom-steps/sec (whole node), bcc-Fe ANNP",
+        "value": value,
+        "unit": "atom-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt_wall / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%d-atom bcc-Fe ANNP (%d^3 cells x2, a=2.8553, +-0.05 A displacements), "
+                        "fe_annp_potential_2.ann, list cutoff 8.5 A, x-slab decomposition" % (natoms, args.cells),
+            "atoms": natoms, "atoms_rank0": nlocal, "ghosts_rank0": plan.nghost,
+            "neighbors_in_cutoff_mean": float(n.mean()), "list_neighbors_max": int(mx.value),
+            "parallelism": "spatial x%d, halo p2p" % world,
+            "step": "verlet + forward halo + force evaluation + reverse halo",
+        },
+        "energy_per_atom_eV": e_total / natoms,
+        "kernel_ms": {"descriptor": desc_ms, "network": mlp_ms, "force": force_ms, "evaluation": float(ms4[3]), "samples": int(ns.value)},
+        "roofline": {
+            "kernel": "annp_fe_force<9,19>",
+            "bound": "fp64_valu",
+            "achieved": achieved,
+            "peak": PEAK_FP64_VECTOR,
+            "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP64_VECTOR,
+            "traffic": None,
+            "algorithmic_flop_per_launch": flop_force,
+            "descriptor_pass": {"achieved": flop_desc / (desc_ms * 1e-3) / 1e12, "frac": flop_desc / (desc_ms * 1e-3) / 1e12 / PEAK_FP64_VECTOR},
+            "hbm": {"achieved_GBps": nlocal * BYTES_ATOM_STEP / (float(ms4[3]) * 1e-3) / 1e9, "peak_GBps": PEAK_HBM,
+                    "note": "9.96 KB gathered per atom-step over the whole evaluation; the path is FP64-VALU bound, not HBM bound"},
+        },
+    }
+    # ---- CPU baseline (rank 0, N = 1 only) ------------------------------------------------
+    if world == 1 and args.cpu_sample > 0:
+        m = min(args.cpu_sample, nlocal)
+        xs = dom.x.cpu().numpy()
+        s = _sample_system(lib, h, xs, nlocal, nall, m, rc_list)
+        pot = read_pot(FE_POT)
+        nthreads = oracle_lib().annp_oracle_max_threads()
+        oracle_compute(pot, s, KIND_FE, FAST, inum=min(m, 256))           # warm
+        t1 = time.perf_counter()
+        oracle_compute(pot, s, KIND_FE, FAST, inum=m)
+        tc = time.perf_counter() - t1
+        out["cpu_baseline"] = {
+            "value": m / tc, "unit": "atom-steps/s", "cores": int(nthreads), "kind": "port",
+            "sample": "1 force evaluation of the first %d of %d atoms of the same box (same neighbour list), "
+                      "oracle FAST strategy, OpenMP" % (m, natoms),
+            "seconds": tc,
+        }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+class _NoDist:
+    """single rank: no peers, nothing to exchange"""
+    P2POp = None
+
+    @staticmethod
+    def batch_isend_irecv(ops):
+        return []
+
+
+def _sample_system(lib, h, x_all, nlocal, nall, m, rc_list):
+    """Host copy of positions + neighbour list rows of the first m atoms (for the oracle)."""
+    from annp_testlib import System
+    s = System.__new__(System)
+    s.nlocal, s.nall, s.nghost = nlocal, nall, nall - nlocal
+    s.x = np.ascontiguousarray(x_all)
+    s.type = np.ones(nall, dtype=np.int32)
+    # build the sample's rows with the harness builder on the host (same criterion r^2 <= rc^2)
+    from annp_testlib import _dp, _ip, _lp, oracle_lib
+    ol = oracle_lib()
+    s.numneigh = np.zeros(nall, dtype=np.int32)
+    tot = ol.harness_neigh(m, nall, _dp(s.x), rc_list, _ip(s.numneigh), None, None)
+    s.first = np.zeros(nall + 1, dtype=np.int64)
+    np.cumsum(s.numneigh, out=s.first[1:])
+    s.neigh = np.empty(max(int(tot), 1), dtype=np.int32)
+    ol.harness_neigh(m, nall, _dp(s.x), rc_list, _ip(s.numneigh), _lp(s.first), _ip(s.neigh))
+    s.ilist = np.arange(m, dtype=np.int32)
+    s.inum = m
+    s.owner = np.zeros(s.nghost, dtype=np.int32)
+    s.rc_list = rc_list
+    return s
+
+
+if __name__ == "__main__":
+    main()

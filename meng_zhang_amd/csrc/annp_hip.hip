@@ -51,6 +51,7 @@ struct annp_hip_handle {
     double *dB[MLP_MAXL] = {nullptr, nullptr, nullptr, nullptr};
     double *d_norm = nullptr;           // nmul | nsub | nden | cmul, ANNP_GPAD each
     double *d_sym = nullptr;            // BEHLER: rad[npsf*3] then ang[ntsf*4]
+    double *d_cheb2mono = nullptr;      // CHEBYSHEV: [ntsf][ntsf] T_n((z+1)/2) -> powers of z
     std::vector<double> sym_rad, sym_ang;
     // work buffers
     DevBuf<double> G, coef, x, f, eatom;
@@ -173,7 +174,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     m.nmul = h->d_norm; m.nsub = h->d_norm + ANNP_GPAD; m.nden = h->d_norm + 2 * ANNP_GPAD; m.cmul = h->d_norm + 3 * ANNP_GPAD;
     m.e_scale = h->e_scale; m.e_shift = h->e_shift; m.e_atom = h->e_atom;
     m.G = h->G.p; m.coef = h->coef.p; m.eatom = d_eatom; m.eng = d_eng;
-    m.np = h->npsf; m.nt = h->ntsf;
+    m.np = h->npsf; m.nt = h->ntsf; m.cheb2mono = h->d_cheb2mono;
 
     if (h->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
         if (!(h->npsf == 9 && h->ntsf == 19))
@@ -248,6 +249,7 @@ void annp_hip_clear(annp_hip_handle *h)
     for (int l = 0; l < MLP_MAXL; l++) { if (h->dW[l]) (void)hipFree(h->dW[l]); if (h->dB[l]) (void)hipFree(h->dB[l]); }
     if (h->d_norm) (void)hipFree(h->d_norm);
     if (h->d_sym) (void)hipFree(h->d_sym);
+    if (h->d_cheb2mono) (void)hipFree(h->d_cheb2mono);
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom);
     release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount);
     release(h, h->first);
@@ -335,6 +337,24 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         INIT_TRY(hipMalloc((void **)&h->d_norm, sizeof(double) * t.size()));
         INIT_TRY(hipMemcpy(h->d_norm, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
         h->bytes += sizeof(double) * t.size();
+    }
+    if (p->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
+        // coefficients of z^k in T_n((z+1)/2): T_0 = 1, T_1 = (1+z)/2, T_n = (1+z) T_{n-1} - T_{n-2}.
+        // All entries are dyadic rationals below 2^53, so this fp64 recurrence is exact.
+        const int nt = p->ntsf;
+        std::vector<double> M((size_t)nt * nt, 0.0);       // M[k*nt + n]
+        std::vector<double> a(nt, 0.0), b(nt, 0.0), t(nt, 0.0);
+        a[0] = 1.0;
+        for (int k = 0; k < nt; k++) M[(size_t)k * nt + 0] = a[k];
+        if (nt > 1) { b[0] = 0.5; b[1] = 0.5; for (int k = 0; k < nt; k++) M[(size_t)k * nt + 1] = b[k]; }
+        for (int n = 2; n < nt; n++) {
+            for (int k = 0; k < nt; k++) t[k] = b[k] + (k > 0 ? b[k - 1] : 0.0) - a[k];
+            a = b; b = t;
+            for (int k = 0; k < nt; k++) M[(size_t)k * nt + n] = b[k];
+        }
+        INIT_TRY(hipMalloc((void **)&h->d_cheb2mono, sizeof(double) * M.size()));
+        INIT_TRY(hipMemcpy(h->d_cheb2mono, M.data(), sizeof(double) * M.size(), hipMemcpyHostToDevice));
+        h->bytes += sizeof(double) * M.size();
     }
     if (p->descriptor == ANNP_HIP_DESC_BEHLER) {
         h->sym_rad.assign(p->cofsymrad, p->cofsymrad + 3 * p->npsf);

@@ -21,6 +21,10 @@
 #pragma once
 #include "annp_common.hpp"
 
+#ifndef ANNP_VARIANT
+#define ANNP_VARIANT 0
+#endif
+
 namespace annp {
 
 constexpr int FE_Q = 4;  // chunks per tournament row
@@ -50,9 +54,10 @@ __host__ __device__ inline size_t fe_desc_lds_per_wave(int n_cap)
     size_t rec = (size_t)(n_cap + 1) * 32;
     return rec < 4096 ? 4096 : rec;
 }
+constexpr int FE_DUMP = 16;   // dump slots behind the records: where masked-off pair steps scatter to
 __host__ __device__ inline size_t fe_force_lds_per_wave(int n_cap)
 {
-    return (size_t)(n_cap + 1) * (32 + 40 + 24 + 8);
+    return (size_t)(n_cap + FE_DUMP) * (32 + 40 + 24 + 8);
 }
 
 // ---------------------------------------------------------------------------------
@@ -136,10 +141,12 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
     const int L = (H + FE_Q - 1) / FE_Q;
     const int nitems = n * FE_Q;
     const bool even = (n & 1) == 0;
+    // item it -> (row a = it mod n, chunk q = it div n): the 64 lanes of a step hold
+    // consecutive rows of one chunk, hence consecutive, distinct partners b
+    int a = lane, q = 0;
+    while (a >= n && q < FE_Q) { a -= n; q++; }
     for (int it0 = 0; it0 < nitems; it0 += 64) {
-        const int it = it0 + lane;
-        const bool act = it < nitems;
-        const int a = it / FE_Q, q = it % FE_Q;
+        const bool act = q < FE_Q;
         const int t0 = 1 + q * L;
         int t1 = min(H, t0 + L - 1);
         if (even && a >= H && t1 == H) t1 = H - 1;
@@ -148,9 +155,14 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
         const double2 A0 = recA[ar], A1 = recB[ar];
         int b = a + t0;
         if (b >= n) b -= n;
+        int bi = (0 <= smax) ? b : p.n_cap;
+        double2 B0 = recA[bi], B1 = recB[bi];
         for (int s = 0; s < L; ++s) {
-            const int bi = (s <= smax) ? b : p.n_cap;
-            const double2 B0 = recA[bi], B1 = recB[bi];
+            // prefetch the next partner while this one is being worked on
+            b++;
+            if (b == n) b = 0;
+            const int bn = (s + 1 <= smax) ? b : p.n_cap;
+            const double2 N0 = recA[bn], N1 = recB[bn];
             const double c = fma(A1.x, B1.x, fma(A0.y, B0.y, A0.x * B0.x));
             const double w = A1.y * B1.y;
             const double y = c + 1.0;            // 2x with x = (cos+1)/2  (fe:671)
@@ -164,9 +176,10 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
                 ga[mm] = fma(t, w, ga[mm]);
                 tm2 = tm1; tm1 = t;
             }
-            b++;
-            if (b == n) b = 0;
+            B0 = N0; B1 = N1;
         }
+        a += 64;
+        while (a >= n && q < FE_Q) { a -= n; q++; }
     }
     wave_lds_sync();    // records are dead from here; the area becomes reduction scratch
 
@@ -204,9 +217,9 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
 // ---------------------------------------------------------------------------------
 // pass 2: forces
 //   coef[ii]: [0,NP)            c_m                 radial weights
-//             [NP, NP+NT)       e_0..e_{NT-1}       U-series of P(x)   = sum c_{NP+n} T_n(x)
-//             [NP+NT, NP+2NT-1) d_0..d_{NT-2}       U-series of P'(x)/2
-//   (T_n = (U_n - U_{n-2})/2, T'_n = n U_{n-1}: one Chebyshev-U recurrence serves both sums)
+//             [NP, NP+NT)       p_0..p_{NT-1}       P(z) = sum_n c_{NP+n} T_n((z+1)/2) = sum_k p_k z^k
+//             [NP+NT, NP+2NT-1) d_0..d_{NT-2}       dP/dz = sum_k d_k z^k
+//   with z = cos(theta_jik); written by the network pass (mlp_kernels.hpp epilogue)
 // ---------------------------------------------------------------------------------
 template <int NP, int NT, bool VIRIAL>
 __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     const int wave = uniform(threadIdx.x >> 6);
     const int ii = uniform(blockIdx.x * ANNP_WAVES_PER_BLOCK + wave);
     if (ii >= p.inum) return;
-    const int n1 = p.n_cap + 1;
+    const int n1 = p.n_cap + FE_DUMP;
     unsigned char *wbase = lds_raw + (size_t)wave * fe_force_lds_per_wave(p.n_cap);
     double2 *recA = reinterpret_cast<double2 *>(wbase);          // e.x e.y
     double2 *recB = recA + n1;                                    // e.z fc
@@ -306,10 +319,11 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     const int L = (H + FE_Q - 1) / FE_Q;
     const int nitems = n * FE_Q;
     const bool even = (n & 1) == 0;
+    const int dump = p.n_cap + (lane & (FE_DUMP - 1));
+    int a = lane, q = 0;
+    while (a >= n && q < FE_Q) { a -= n; q++; }
     for (int it0 = 0; it0 < nitems; it0 += 64) {
-        const int it = it0 + lane;
-        const bool act = it < nitems;
-        const int a = it / FE_Q, q = it % FE_Q;
+        const bool act = q < FE_Q;
         const int t0 = 1 + q * L;
         int t1 = min(H, t0 + L - 1);
         if (even && a >= H && t1 == H) t1 = H - 1;
@@ -319,21 +333,25 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
         double va0 = 0.0, va1 = 0.0, va2 = 0.0, sa = 0.0, ca = 0.0;
         int b = a + t0;
         if (b >= n) b -= n;
+        int bi = (0 <= smax) ? b : p.n_cap;
+        double2 B0 = recA[bi], B1 = recB[bi];
+        // land the first record before the loop: inside it only the prefetch and the
+        // (result-less) atomics are in flight, so the loop needs one counted wait per step
+        asm volatile("" : "+v"(B0.x), "+v"(B0.y), "+v"(B1.x), "+v"(B1.y));
         for (int s = 0; s < L; ++s) {
-            const int bi = (s <= smax) ? b : p.n_cap;
-            const double2 B0 = recA[bi], B1 = recB[bi];
+            b++;
+            if (b == n) b = 0;
+            const int bn = (s + 1 <= smax) ? b : p.n_cap;
+            const double2 N0 = recA[bn], N1 = recB[bn];      // prefetch, issued first
+            __builtin_amdgcn_sched_barrier(0);
             const double c = fma(A1.x, B1.x, fma(A0.y, B0.y, A0.x * B0.x));
-            const double y = c + 1.0;
-            // U_0 = 1, U_1 = y, U_m = y U_{m-1} - U_{m-2}
-            double um2 = 1.0, um1 = y;
-            double P = fma(ce[1], y, ce[0]);
-            double Pd = fma(cd[1], y, cd[0]);
+            // P(z) and dP/dz by Horner, z = cos(theta)
+            double P = ce[NT - 1];
+            double Pd = cd[NT - 2];
 #pragma unroll
-            for (int mm = 2; mm < NT; mm++) {
-                const double u = fma(y, um1, -um2);
-                P = fma(ce[mm], u, P);
-                if (mm < NT - 1) Pd = fma(cd[mm], u, Pd);
-                um2 = um1; um1 = u;
+            for (int mm = NT - 2; mm >= 0; mm--) {
+                P = fma(P, c, ce[mm]);
+                if (mm < NT - 2) Pd = fma(Pd, c, cd[mm]);
             }
             const double w = A1.y * B1.y;          // fc_a fc_b
             const double al = Pd * w;              // (P'/2) fc_a fc_b
@@ -341,19 +359,31 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
             va0 = fma(al, B0.x, va0); va1 = fma(al, B0.y, va1); va2 = fma(al, B1.x, va2);
             sa = fma(P, B1.y, sa);
             ca += alc;
-            atomicAdd(&accV0[bi], al * A0.x);
-            atomicAdd(&accV1[bi], al * A0.y);
-            atomicAdd(&accV2[bi], al * A1.x);
-            atomicAdd(&accS[bi], P * A1.y);
-            atomicAdd(&accC[bi], alc);
-            b++;
-            if (b == n) b = 0;
+#if ANNP_VARIANT != 3
+            {   // unconditional: masked-off steps carry zero weight and land in a dump slot,
+                // so the scatter needs no branch and the prefetch above keeps a counted wait
+                const int bt = (bi == p.n_cap) ? dump : bi;
+                atomicAdd(&accV0[bt], al * A0.x);
+                atomicAdd(&accV1[bt], al * A0.y);
+                atomicAdd(&accV2[bt], al * A1.x);
+                atomicAdd(&accS[bt], P * A1.y);
+                atomicAdd(&accC[bt], alc);
+            }
+#else
+            asm volatile("" ::"v"(al * A0.x), "v"(al * A0.y), "v"(al * A1.x), "v"(P * A1.y));
+#endif
+            B0 = N0; B1 = N1; bi = bn;
         }
-        atomicAdd(&accV0[ar], va0);
-        atomicAdd(&accV1[ar], va1);
-        atomicAdd(&accV2[ar], va2);
-        atomicAdd(&accS[ar], sa);
-        atomicAdd(&accC[ar], ca);
+        {
+            const int at = act ? ar : dump;
+            atomicAdd(&accV0[at], va0);
+            atomicAdd(&accV1[at], va1);
+            atomicAdd(&accV2[at], va2);
+            atomicAdd(&accS[at], sa);
+            atomicAdd(&accC[at], ca);
+        }
+        a += 64;
+        while (a >= n && q < FE_Q) { a -= n; q++; }
     }
     wave_lds_sync();
 

@@ -16,7 +16,11 @@
 // ever moves between lanes or through LDS between layers.
 //
 // The epilogue turns dE/dG into what the force pass consumes
-// (fe_kernels.hpp / ni_kernels.hpp) and writes per-atom energies.
+// (fe_kernels.hpp / ni_kernels.hpp) and writes per-atom energies.  For the Chebyshev
+// descriptor that is the angular polynomial of the atom, P(z) = sum_n c_n T_n((z+1)/2),
+// re-expanded in powers of z = cos(theta) (exact dyadic conversion matrix; the
+// monomial form is well conditioned on [-1,1] here: |p_k| <= ~120 max|c_n|), so the
+// force pass evaluates P and dP/dz by Horner instead of running a recurrence.
 #pragma once
 #include "annp_common.hpp"
 
@@ -40,6 +44,7 @@ struct MlpArgs {
     int energy_raw;               // ni: E_i = network output (ni:858-860)
     int mode;                     // 0: Chebyshev epilogue (np radial, nt angular)   1: plain c_k
     int np, nt;
+    const double *cheb2mono;      // mode 0: [nt][nt], row k = coefficients of z^k in T_n((z+1)/2), n = 0..nt-1
     const double *G;              // [inum][ANNP_GPAD]
     double *coef;                 // [inum][ANNP_CPAD]
     double *eatom;                // nullable, indexed by atom
@@ -249,14 +254,15 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
                 if (o < nsf) v = c[o];
             } else if (o < np) {
                 v = c[o];
-            } else if (o < np + nt) {                 // e_m = c_m/2 - c_{m+2}/2 ; e_0 = c_0 - c_2/2
-                const int m = o - np;
-                const double cm = c[np + m];
-                const double cm2 = (m + 2 < nt) ? c[np + m + 2] : 0.0;
-                v = (m == 0) ? (cm - 0.5 * cm2) : 0.5 * (cm - cm2);
-            } else if (o < np + 2 * nt - 1) {         // d_m = (m+1) c_{m+1} / 2
-                const int m = o - np - nt;
-                v = 0.5 * (double)(m + 1) * c[np + m + 1];
+            } else if (o < np + nt) {                 // p_k: P(z) = sum_n c_n T_n((z+1)/2) = sum_k p_k z^k
+                const int k = o - np;
+                const double *row = p.cheb2mono + (size_t)k * nt;
+                for (int m = k; m < nt; m++) v = fma(row[m], c[np + m], v);      // T_n has no z^k for n < k
+            } else if (o < np + 2 * nt - 1) {         // d_k = (k+1) p_{k+1}:  dP/dz
+                const int k = o - np - nt;
+                const double *row = p.cheb2mono + (size_t)(k + 1) * nt;
+                for (int m = k + 1; m < nt; m++) v = fma(row[m], c[np + m], v);
+                v *= (double)(k + 1);
             }
             p.coef[(size_t)ia2 * ANNP_CPAD + o] = v;
         }

@@ -21,7 +21,8 @@ PAIR_SYMBOLS = [
 
 
 def library_path():
-    return os.path.join(_HERE, "libannp_hip.so")
+    # ANNP_HIP_LIBRARY: developer switch for A/B-ing kernel variants (tools/build_variants.sh)
+    return os.environ.get("ANNP_HIP_LIBRARY") or os.path.join(_HERE, "libannp_hip.so")
 
 
 def load_library():

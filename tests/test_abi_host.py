@@ -1,0 +1,126 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports everything
+include/annp_hip.h declares, the host-side pair style parses potential files the way
+the reference does, and there is no silent fallback when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from annp_testlib import FE_POT, NI_POT, ROOT, read_pot
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from meng_zhang_amd.lib import load_library
+    return load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "annp_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(annp_hip_[a-z_]+)\s*\(", hdr)))
+    assert len(declared) >= 14
+    for name in declared:
+        assert getattr(lib, name) is not None, name
+    from meng_zhang_amd.lib import ABI_SYMBOLS
+    assert sorted(ABI_SYMBOLS) == declared
+    assert lib.annp_hip_abi_version() == 1
+
+
+def test_pair_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "meng_zhang_amd", "host", "annp_pair.h")).read()
+    declared = sorted(set(re.findall(r"\b(annp_pair_[a-z_]+)\s*\(", hdr)))
+    for name in declared:
+        assert getattr(lib, name) is not None, name
+
+
+def test_library_carries_gfx950_code_only():
+    from meng_zhang_amd.lib import library_path
+    blob = open(library_path(), "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx90a", b"gfx942", b"sm_80", b"sm_90"):
+        assert other not in blob
+
+
+def _potential(path, elem):
+    from meng_zhang_amd import PairANNP
+    p = PairANNP(ntypes=1)
+    p.settings([])
+    p.coeff(["*", "*", path, elem])
+    return p
+
+
+@pytest.mark.parametrize("path,elem", [(FE_POT, "Fe"), (NI_POT, "Ni")])
+def test_parser_matches_oracle_parser(path, elem):
+    p = _potential(path, elem)
+    q, o = p.potential(), read_pot(path)
+    for k in ("ntl", "nhl", "nnod", "nsf", "npsf", "ntsf", "flagsym", "has_symcoef"):
+        assert q[k] == getattr(o, k), k
+    for k in ("cut", "e_scale", "e_shift", "e_atom", "mass"):
+        assert q[k] == getattr(o, k), k
+    nl, nsf, nnod = q["ntl"] - 1, q["nsf"], q["nnod"]
+    assert list(q["flagact"]) == list(o.flagact)[:nl] == [4, 4, 0]      # "tanh" -> 4 (fe_v2/src/pair_annp.cpp:423)
+    assert np.array_equal(q["norm_a"], np.array(o.norm0[:nsf]))
+    assert np.array_equal(q["norm_b"], np.array(o.norm1[:nsf]))
+    for l in range(nl):
+        nr = 1 if l == nl - 1 else nnod
+        nc = nsf if l == 0 else nnod
+        assert np.array_equal(q["W"][l].ravel(), np.array(o.W[l][: nr * nc]))
+        assert np.array_equal(q["B"][l], np.array(o.B[l][:nr]))
+    if q["has_symcoef"]:
+        assert np.array_equal(q["sym_rad"], np.array([list(r) for r in o.sym_rad][: q["npsf"]]))
+        assert np.array_equal(q["sym_ang"], np.array([list(r) for r in o.sym_ang][: q["ntsf"]]))
+        assert q["sym_ang"][7].tolist() == [0.01, 1.0, 16.0, 7.3699319]
+    p.close()
+
+
+def test_fe_file_values():
+    q = _potential(FE_POT, "Fe").potential()
+    assert (q["ntl"], q["nhl"], q["nnod"], q["nsf"], q["npsf"], q["ntsf"]) == (4, 2, 10, 28, 9, 19)
+    assert q["cut"] == 6.5 and q["mass"] == 55.847
+    assert q["e_scale"] == 0.80684104305538540 and q["e_shift"] == -1019.0781365280557 and q["e_atom"] == -3460.0
+    assert q["W"][0][0, 0] == -0.146897379 and q["norm_a"][0] == 347.367726795125 and q["norm_b"][1] == 1.905601370294
+
+
+def test_reference_error_behaviour():
+    from meng_zhang_amd import PairANNP
+    p = PairANNP(ntypes=1)
+    with pytest.raises(RuntimeError, match="Illegal pair_style command"):          # fe_v2/src/pair_annp.cpp:251
+        p.settings(["6.5"])
+    with pytest.raises(RuntimeError, match="Incorrect args for pair coefficients"):   # :263-266
+        p.coeff(["*", "*", FE_POT])
+    with pytest.raises(RuntimeError, match="Incorrect args for pair coefficients"):
+        p.coeff(["1", "*", FE_POT, "Fe"])
+    with pytest.raises(RuntimeError, match="Cannot open neural network potential file"):   # :341
+        p.coeff(["*", "*", "/nonexistent.ann", "Fe"])
+    with pytest.raises(RuntimeError, match="All pair coeffs are not set"):          # :325
+        p.init_one(1, 1)
+    p.coeff(["*", "*", FE_POT, "Fe"])
+    assert p.init_one(1, 1) == 6.5
+    p.newton_pair = 0
+    with pytest.raises(RuntimeError, match="requires newton pair on"):               # :311-312
+        p.init_style()
+    p.close()
+
+
+def test_no_silent_fallback_without_gpu():
+    """On a box without an MI355X the product must refuse, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = _potential(FE_POT, "Fe")
+    with pytest.raises(RuntimeError, match="code -4"):
+        p.init_style()
+    assert p.handle is None
+    p.close()
+
+
+def test_product_does_not_reference_the_oracle():
+    """Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may touch oracle/."""
+    pkg = os.path.join(ROOT, "meng_zhang_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hpp", ".hip")) or f == "Makefile":
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                assert "annp_oracle" not in txt and "annp_testlib" not in txt and "oracle/" not in txt, os.path.join(d, f)

@@ -1,0 +1,131 @@
+"""Spatial decomposition + halo exchange (meng_zhang_amd/domain.py) on CPU.
+
+The decomposition must not change the physics: forces of a box cut into slabs, after
+the reverse halo exchange, equal the single-domain forces.  Here the force engine is the
+CPU oracle (test infrastructure) so the N>1 path is covered without a GPU:
+world_size 2 over gloo, plus a single-process check of the plan for 1, 2, 3 ranks.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from annp_testlib import (A_FE, FAST, FE_POT, KIND_FE, System, _dp, _ip, _lp, bcc, oracle_compute, oracle_lib, perturb,
+                          read_pot)
+
+RC_LIST = 8.5
+
+
+def local_system(x_local_all, nlocal):
+    """harness neighbour list for [owned | ghost] positions of one rank"""
+    ol = oracle_lib()
+    s = System.__new__(System)
+    s.nlocal, s.nall = nlocal, x_local_all.shape[0]
+    s.nghost = s.nall - nlocal
+    s.x = np.ascontiguousarray(x_local_all)
+    s.type = np.ones(s.nall, dtype=np.int32)
+    s.numneigh = np.zeros(s.nall, dtype=np.int32)
+    tot = ol.harness_neigh(nlocal, s.nall, _dp(s.x), RC_LIST, _ip(s.numneigh), None, None)
+    s.first = np.zeros(s.nall + 1, dtype=np.int64)
+    np.cumsum(s.numneigh, out=s.first[1:])
+    s.neigh = np.empty(max(int(tot), 1), dtype=np.int32)
+    ol.harness_neigh(nlocal, s.nall, _dp(s.x), RC_LIST, _ip(s.numneigh), _lp(s.first), _ip(s.neigh))
+    s.ilist = np.arange(nlocal, dtype=np.int32)
+    s.inum = nlocal
+    s.owner = np.zeros(s.nghost, dtype=np.int32)
+    s.rc_list = RC_LIST
+    return s
+
+
+def reference_forces(xg, box):
+    s = System(xg, box)
+    r = oracle_compute(read_pot(FE_POT), s, KIND_FE, FAST)
+    return r["f"], r["energy"]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_plan_reproduces_single_domain(world):
+    """All ranks emulated in one process: ghosts of every rank + owner-side force return."""
+    from meng_zhang_amd.domain import HaloPlan
+    x0, box = bcc(10 if world == 3 else 8, 3, 3, A_FE)
+    xg = perturb(x0, 4242, 0.05)
+    f_ref, e_ref = reference_forces(xg, box)
+    pot = read_pot(FE_POT)
+    plans = [HaloPlan(x0, box, (1, 1, 1), RC_LIST, world, r) for r in range(world)]
+    assert sum(p.nlocal for p in plans) == xg.shape[0]
+    f = np.zeros_like(xg)
+    e = 0.0
+    for r, p in enumerate(plans):
+        # what rank r would send must be exactly what its peers expect
+        for q, pq in enumerate(plans):
+            assert p.send_counts[q] == pq.recv_counts[r]
+        xl = p.local_positions(xg)
+        s = local_system(xl, p.nlocal)
+        out = oracle_compute(pot, s, KIND_FE, FAST)
+        e += out["energy"]
+        fl = out["f_all"]
+        np.add.at(f, p.own_ids[r], fl[: p.nlocal])
+        # reverse comm: ghost forces to owners
+        np.add.at(f, np.concatenate([plans[q].own_ids[q][p.ghost_owner_local[p.ghost_owner == q]] for q in range(world)])
+                  if p.nghost else np.zeros(0, dtype=np.int64), fl[p.nlocal:])
+    assert abs(e - e_ref) < 1e-8
+    assert np.abs(f - f_ref).max() < 1e-11
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from meng_zhang_amd.domain import Domain, HaloPlan
+        x0, box = bcc(8, 3, 3, A_FE)
+        xg = perturb(x0, 4242, 0.05)
+        plan = HaloPlan(x0, box, (1, 1, 1), RC_LIST, world, rank)
+        dom = Domain(plan, x0, torch.device("cpu"), dist)          # start from the ideal lattice ...
+        own = torch.from_numpy(xg[plan.own_ids[rank]])
+        dom.x[: plan.nlocal] = own                                 # ... move the owned atoms ...
+        dom.forward()                                              # ... ghosts must follow through the wire
+        assert np.abs(dom.x.numpy() - plan.local_positions(xg)).max() < 1e-12
+        s = local_system(dom.x.numpy(), plan.nlocal)
+        out = oracle_compute(read_pot(FE_POT), s, KIND_FE, FAST, nthreads=2)
+        dom.f.copy_(torch.from_numpy(out["f_all"]))
+        dom.reverse()
+        e = torch.tensor([out["energy"]], dtype=torch.float64)
+        dist.all_reduce(e)
+        q.put((rank, plan.own_ids[rank], dom.f[: plan.nlocal].numpy().copy(), float(e.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x0, box = bcc(8, 3, 3, A_FE)
+    xg = perturb(x0, 4242, 0.05)
+    f_ref, e_ref = reference_forces(xg, box)
+    f = np.zeros_like(xg)
+    for rank, ids, fl, e in res:
+        f[ids] = fl
+        assert abs(e - e_ref) < 1e-8
+    assert np.abs(f - f_ref).max() < 1e-11
