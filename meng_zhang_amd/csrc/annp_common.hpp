@@ -39,6 +39,51 @@ __device__ __forceinline__ void cutoff_fc(double r, double pi_over_rc, double &f
     dfc = -0.5 * pi_over_rc * sn;
 }
 
+// sin(t), cos(t) for t in [0, pi] (the only range the cutoff function sees: 0 < r <= Rc).
+// t = pi/2 + h with |h| <= pi/2: cos t = -sin h, sin t = cos h; Taylor-Horner in h^2,
+// truncation below 2e-18.  ~30 fp64 instructions instead of libm's general-range sincos.
+__device__ __forceinline__ void sincos_0_pi(double t, double &sn, double &cs)
+{
+    const double h = t - 1.57079632679489661923;
+    const double h2 = h * h;
+    double ps = -1.0 / 51090942171709440000.0;             // -1/21!
+    ps = fma(ps, h2, 1.0 / 121645100408832000.0);          //  1/19!
+    ps = fma(ps, h2, -1.0 / 355687428096000.0);            // -1/17!
+    ps = fma(ps, h2, 1.0 / 1307674368000.0);               //  1/15!
+    ps = fma(ps, h2, -1.0 / 6227020800.0);                 // -1/13!
+    ps = fma(ps, h2, 1.0 / 39916800.0);                    //  1/11!
+    ps = fma(ps, h2, -1.0 / 362880.0);                     // -1/9!
+    ps = fma(ps, h2, 1.0 / 5040.0);                        //  1/7!
+    ps = fma(ps, h2, -1.0 / 120.0);                        // -1/5!
+    ps = fma(ps, h2, 1.0 / 6.0);                           //  1/3!   (sign folded below)
+    double pc = 1.0 / 1124000727777607680000.0;            //  1/22!
+    pc = fma(pc, h2, -1.0 / 2432902008176640000.0);        // -1/20!
+    pc = fma(pc, h2, 1.0 / 6402373705728000.0);            //  1/18!
+    pc = fma(pc, h2, -1.0 / 20922789888000.0);             // -1/16!
+    pc = fma(pc, h2, 1.0 / 87178291200.0);                 //  1/14!
+    pc = fma(pc, h2, -1.0 / 479001600.0);                  // -1/12!
+    pc = fma(pc, h2, 1.0 / 3628800.0);                     //  1/10!
+    pc = fma(pc, h2, -1.0 / 40320.0);                      // -1/8!
+    pc = fma(pc, h2, 1.0 / 720.0);                         //  1/6!
+    pc = fma(pc, h2, -1.0 / 24.0);                         // -1/4!
+    pc = fma(pc, h2, 0.5);                                 //  1/2!
+    const double sin_h = fma(-(h * h2), ps, h);            // h - h^3 (1/3! - h^2/5! + ...)
+    const double cos_h = fma(-h2, pc, 1.0);                // 1 - h^2 (1/2! - h^2/4! + ...)
+    sn = cos_h;
+    cs = -sin_h;
+}
+
+// 1/sqrt(x) to ~1 ulp: hardware estimate + two Newton steps (x is a squared distance, far from
+// the subnormal / overflow ranges the libm version guards against)
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    y = y * fma(-hx * y, y, 1.5);
+    return y;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll

@@ -12,12 +12,17 @@
 //   pass 1 (annp_fe_desc):   G_n            = sum over neighbours / pairs
 //   pass 2 (annp_fe_force):  F_a = -sum_n c_n dG_n/dx_a   with c_n = e_scale s_n dE/dG_n
 //
-// Work decomposition (both passes): one 64-lane wave per central atom.  The n
-// in-cutoff neighbours are compacted into LDS records; the n(n-1)/2 unordered
-// pairs are enumerated as a round-robin tournament: pair (a, a+t mod n) for
-// t = 1..floor(n/2).  A row a is cut into Q=4 chunks of t, giving 4n work items
-// dealt round-robin to lanes, so at any step the 64 lanes hold 64 different
-// partners b (conflict-free LDS reads, and in pass 2 collision-free LDS atomics).
+// Work decomposition (both passes): one 64-lane wave per central atom.
+//   stage A  the list row is scanned 64 candidates at a time; in-cutoff ones are
+//            ballot-compacted into LDS as raw (dx,dy,dz,r^2); a second sweep over the
+//            compacted n entries does the expensive per-neighbour math (1/r, fc, fc',
+//            radial Chebyshev) once and leaves records (e_x,e_y | e_z,fc).
+//   stage B  the n(n-1)/2 unordered pairs are enumerated as a round-robin tournament:
+//            pair (a, a+t mod n), t = 1..floor(n/2).  A row a is cut into Q=4 chunks of
+//            t; the 4n (row, chunk) items are dealt to lanes so that the 64 lanes of a
+//            step hold consecutive rows of one chunk, hence 64 consecutive, distinct
+//            partners b: conflict-free ds_read_b128, collision-free LDS atomics.
+//            Steps that fall outside a row's range read a null record (fc = 0).
 #pragma once
 #include "annp_common.hpp"
 
@@ -27,7 +32,8 @@
 
 namespace annp {
 
-constexpr int FE_Q = 4;  // chunks per tournament row
+constexpr int FE_Q = 4;       // chunks per tournament row
+constexpr int FE_DUMP = 16;   // dump slots behind the records: where masked-off pair steps scatter to
 
 struct FeArgs {
     int inum;
@@ -52,12 +58,71 @@ struct FeArgs {
 __host__ __device__ inline size_t fe_desc_lds_per_wave(int n_cap)
 {
     size_t rec = (size_t)(n_cap + 1) * 32;
-    return rec < 4096 ? 4096 : rec;
+    return rec < 4096 + 512 ? 4096 + 512 : rec;     // reduction scratch [8][64] + [64] results
 }
-constexpr int FE_DUMP = 16;   // dump slots behind the records: where masked-off pair steps scatter to
 __host__ __device__ inline size_t fe_force_lds_per_wave(int n_cap)
 {
     return (size_t)(n_cap + FE_DUMP) * (32 + 40 + 24 + 8);
+}
+
+// ---- stage A, first sweep: candidates -> compacted raw entries (dx,dy | dz,r^2) [+ index]
+template <bool WITH_J>
+__device__ __forceinline__ int fe_compact(const FeArgs &p, int i, int lane, double2 *recA, double2 *recB, int *auxJ)
+{
+    const double xi = p.x[3 * (size_t)i], yi = p.x[3 * (size_t)i + 1], zi = p.x[3 * (size_t)i + 2];
+    const long long base = p.first[i];
+    const int jn = p.numneigh[i];
+    int n = 0;
+    for (int c0 = 0; c0 < jn; c0 += 64) {
+        const int jj = c0 + lane;
+        const bool valid = jj < jn;
+        const int j = valid ? (p.neigh[base + jj] & ANNP_NEIGHMASK) : i;
+        const double dx = xi - p.x[3 * (size_t)j], dy = yi - p.x[3 * (size_t)j + 1], dz = zi - p.x[3 * (size_t)j + 2];
+        const double rsq = dx * dx + dy * dy + dz * dz;
+        const bool in = valid && !(rsq > p.cutsq) && !(rsq < 1.0e-12);        // fe:144
+        const unsigned long long m = __ballot(in);
+        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+        if (in && pos < p.n_cap) {
+            recA[pos] = make_double2(dx, dy);
+            recB[pos] = make_double2(dz, rsq);
+            if (WITH_J) auxJ[pos] = j;
+        }
+        n += __popcll(m);
+    }
+    return uniform(n);
+}
+
+// per-neighbour geometry from a raw entry: unit vector e = (xi-xj)/r, r, 1/r, fc, fc'
+struct FeNbr { double ex, ey, ez, r, rinv, fc, dfc; };
+__device__ __forceinline__ FeNbr fe_geometry(double2 R0, double2 R1, double pi_over_rc)
+{
+    FeNbr g;
+    g.rinv = fast_rsqrt(R1.y);
+    g.r = R1.y * g.rinv;
+    g.ex = R0.x * g.rinv; g.ey = R0.y * g.rinv; g.ez = R1.x * g.rinv;
+    double sn, cs;
+    sincos_0_pi(pi_over_rc * g.r, sn, cs);
+    g.fc = 0.5 * (cs + 1.0);                    // fe:592
+    g.dfc = -0.5 * pi_over_rc * sn;             // fe:593
+    return g;
+}
+
+// item -> (row a, chunk q) bookkeeping of the tournament, one item per lane per round
+struct FeItem {
+    int a, q;          // row, chunk (q == FE_Q: no item)
+    __device__ __forceinline__ void init(int lane, int n) { a = lane; q = 0; norm(n); }
+    __device__ __forceinline__ void next(int n) { a += 64; norm(n); }
+    __device__ __forceinline__ void norm(int n) { while (a >= n && q < FE_Q) { a -= n; q++; } }
+};
+
+// range of a round: every active lane of it has at least Lm valid steps (uniform value).
+// Chunk lengths shrink with q, so the round's largest chunk index decides.
+__device__ __forceinline__ int fe_round_min_steps(int q_lane, int H, int L, bool even)
+{
+    const int q63 = min(__builtin_amdgcn_readlane(q_lane, 63), FE_Q - 1);
+    const int lenq = min(L, max(0, H - q63 * L));
+    const bool hasH = (q63 * L + lenq == H);
+    return max(0, lenq - ((even && hasH) ? 1 : 0));
 }
 
 // ---------------------------------------------------------------------------------
@@ -66,6 +131,7 @@ __host__ __device__ inline size_t fe_force_lds_per_wave(int n_cap)
 template <int NP, int NT>
 __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
 {
+    static_assert(NT >= 3, "angular closed forms assume at least T_0..T_2");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
@@ -75,57 +141,47 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
     unsigned char *wbase = lds_raw + (size_t)wave * fe_desc_lds_per_wave(p.n_cap);
     double2 *recA = reinterpret_cast<double2 *>(wbase);          // e.x e.y
     double2 *recB = recA + n1;                                    // e.z fc
-    double *scratch = reinterpret_cast<double *>(wbase);          // reused after the pair loop
+    double *scratch = reinterpret_cast<double *>(wbase);          // reused after the pair loop: [8][64]
+    double *red = scratch + 8 * 64;                               // [64] reduced sums
 
     const int i = p.ilist ? p.ilist[ii] : ii;
-    const double xi = p.x[3 * (size_t)i], yi = p.x[3 * (size_t)i + 1], zi = p.x[3 * (size_t)i + 2];
-    const long long base = p.first[i];
-    const int jn = p.numneigh[i];
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
     const double two_over_rcp = 2.0 / p.rc_par;
 
-    // ---- stage A: compact in-cutoff neighbours into LDS, radial sums on the fly
-    double gr[NP];
-#pragma unroll
-    for (int m = 0; m < NP; m++) gr[m] = 0.0;
-    int n = 0;
-    for (int c0 = 0; c0 < jn; c0 += 64) {
-        const int jj = c0 + lane;
-        const bool valid = jj < jn;
-        const int j = valid ? (p.neigh[base + jj] & ANNP_NEIGHMASK) : i;
-        const double dx = xi - p.x[3 * (size_t)j], dy = yi - p.x[3 * (size_t)j + 1], dz = zi - p.x[3 * (size_t)j + 2];
-        const double rsq = dx * dx + dy * dy + dz * dz;
-        const bool in = valid && !(rsq > p.cutsq) && !(rsq < 1.0e-12);
-        const unsigned long long m = __ballot(in);
-        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-        if (in && pos < p.n_cap) {
-            const double r = sqrt(rsq);
-            const double rinv = 1.0 / r;
-            double fc, dfc;
-            cutoff_fc(r, pi_over_rc, fc, dfc);
-            recA[pos] = make_double2(dx * rinv, dy * rinv);
-            recB[pos] = make_double2(dz * rinv, fc);
-            // radial Chebyshev, x = 2r/Rc - 1
-            const double xr = r * two_over_rcp - 1.0;
-            const double y2 = 2.0 * xr;
-            double tm2 = 1.0, tm1 = xr;
-            gr[0] += fc;
-            if (NP > 1) gr[1] = fma(xr, fc, gr[1]);
-#pragma unroll
-            for (int mm = 2; mm < NP; mm++) {
-                const double t = fma(y2, tm1, -tm2);
-                gr[mm] = fma(t, fc, gr[mm]);
-                tm2 = tm1; tm1 = t;
-            }
-        }
-        n += __popcll(m);
-    }
-    n = uniform(n);
+    const int n = fe_compact<false>(p, i, lane, recA, recB, nullptr);
     if (p.ncount && lane == 0) p.ncount[ii] = n;
     if (n > p.n_cap) {                      // capacity exceeded: report, leave G zero
         if (lane == 0) atomicMax(p.errflag, n);
         if (lane < ANNP_GPAD) p.G[(size_t)ii * ANNP_GPAD + lane] = 0.0;
         return;
+    }
+    wave_lds_sync();
+
+    // ---- stage A, second sweep: geometry, radial sums, and the three neighbour sums that
+    //      give the T_0 and T_1 angular functions in closed form:
+    //        sum_{a<b} fc_a fc_b            = (S1^2 - S2)/2
+    //        sum_{a<b} fc_a fc_b cos(theta) = (|V|^2 - S2)/2,   S1 = sum fc, S2 = sum fc^2, V = sum fc e
+    double gr[NP];
+#pragma unroll
+    for (int m = 0; m < NP; m++) gr[m] = 0.0;
+    double s1 = 0.0, s2 = 0.0, vx = 0.0, vy = 0.0, vz = 0.0;
+    for (int a = lane; a < n; a += 64) {
+        const FeNbr g = fe_geometry(recA[a], recB[a], pi_over_rc);
+        recA[a] = make_double2(g.ex, g.ey);
+        recB[a] = make_double2(g.ez, g.fc);
+        s1 += g.fc; s2 = fma(g.fc, g.fc, s2);
+        vx = fma(g.fc, g.ex, vx); vy = fma(g.fc, g.ey, vy); vz = fma(g.fc, g.ez, vz);
+        const double xr = g.r * two_over_rcp - 1.0;        // fe:643
+        const double y2 = 2.0 * xr;
+        double tm2 = 1.0, tm1 = xr;
+        gr[0] += g.fc;
+        if (NP > 1) gr[1] = fma(xr, g.fc, gr[1]);
+#pragma unroll
+        for (int mm = 2; mm < NP; mm++) {
+            const double t = fma(y2, tm1, -tm2);
+            gr[mm] = fma(t, g.fc, gr[mm]);
+            tm2 = tm1; tm1 = t;
+        }
     }
     if (lane == 0) {                        // null record: zero weight
         recA[p.n_cap] = make_double2(0.0, 0.0);
@@ -133,7 +189,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
     }
     wave_lds_sync();
 
-    // ---- stage B: angular sums over the tournament
+    // ---- stage B: angular sums T_2..T_{NT-1} over the tournament
     double ga[NT];
 #pragma unroll
     for (int m = 0; m < NT; m++) ga[m] = 0.0;
@@ -141,51 +197,61 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
     const int L = (H + FE_Q - 1) / FE_Q;
     const int nitems = n * FE_Q;
     const bool even = (n & 1) == 0;
-    // item it -> (row a = it mod n, chunk q = it div n): the 64 lanes of a step hold
-    // consecutive rows of one chunk, hence consecutive, distinct partners b
-    int a = lane, q = 0;
-    while (a >= n && q < FE_Q) { a -= n; q++; }
+    FeItem it;
+    it.init(lane, n);
     for (int it0 = 0; it0 < nitems; it0 += 64) {
-        const bool act = q < FE_Q;
-        const int t0 = 1 + q * L;
+        const bool act = it.q < FE_Q;
+        const int t0 = 1 + it.q * L;
         int t1 = min(H, t0 + L - 1);
-        if (even && a >= H && t1 == H) t1 = H - 1;
+        if (even && it.a >= H && t1 == H) t1 = H - 1;
         const int smax = act ? (t1 - t0) : -1;
-        const int ar = act ? a : p.n_cap;
+        const int ar = act ? it.a : p.n_cap;          // idle lanes carry the null record: zero weight
         const double2 A0 = recA[ar], A1 = recB[ar];
-        int b = a + t0;
+        const int inc = act ? 1 : 0;
+        int b = it.a + t0;
         if (b >= n) b -= n;
-        int bi = (0 <= smax) ? b : p.n_cap;
-        double2 B0 = recA[bi], B1 = recB[bi];
-        for (int s = 0; s < L; ++s) {
-            // prefetch the next partner while this one is being worked on
-            b++;
-            if (b == n) b = 0;
-            const int bn = (s + 1 <= smax) ? b : p.n_cap;
-            const double2 N0 = recA[bn], N1 = recB[bn];
+        if (!act) b = p.n_cap;
+        const int Lm = fe_round_min_steps(it.q, H, L, even);   // steps every lane may take unchecked
+
+        auto step = [&](const double2 B0, const double2 B1) {
             const double c = fma(A1.x, B1.x, fma(A0.y, B0.y, A0.x * B0.x));
             const double w = A1.y * B1.y;
             const double y = c + 1.0;            // 2x with x = (cos+1)/2  (fe:671)
             const double x1 = 0.5 * y;
-            double tm2 = 1.0, tm1 = x1;
-            ga[0] += w;
-            if (NT > 1) ga[1] = fma(x1, w, ga[1]);
+            double tm2 = x1, tm1 = fma(y, x1, -1.0);      // T_1, T_2
+            ga[2] = fma(tm1, w, ga[2]);
 #pragma unroll
-            for (int mm = 2; mm < NT; mm++) {
+            for (int mm = 3; mm < NT; mm++) {
                 const double t = fma(y, tm1, -tm2);
                 ga[mm] = fma(t, w, ga[mm]);
                 tm2 = tm1; tm1 = t;
             }
-            B0 = N0; B1 = N1;
+        };
+        int s = 0;
+        if (Lm > 0) {
+            double2 B0 = recA[b], B1 = recB[b];
+            for (; s < Lm; ++s) {
+                b += inc;
+                if (b == n) b = 0;
+                const double2 N0 = recA[b], N1 = recB[b];      // prefetch
+                step(B0, B1);
+                B0 = N0; B1 = N1;
+            }
         }
-        a += 64;
-        while (a >= n && q < FE_Q) { a -= n; q++; }
+        for (; s < L; ++s) {                       // ragged tail of the round (at most a few steps)
+            const int bi = (s <= smax) ? b : p.n_cap;
+            step(recA[bi], recB[bi]);
+            b += inc;
+            if (b == n) b = 0;
+        }
+        it.next(n);
     }
     wave_lds_sync();    // records are dead from here; the area becomes reduction scratch
 
-    // ---- reduce 64 lane-partials of NP+NT sums, 8 sums per round through LDS
-    double *Gout = p.G + (size_t)ii * ANNP_GPAD;
-    constexpr int NS = NP + NT;
+    // ---- reduce the lane partials, 8 sums per round through LDS.
+    //      slots: [0,NP) radial, then angular T_2.. (NT-2 of them), then S1 S2 Vx Vy Vz
+    constexpr int NS = NP + (NT - 2) + 5;
+    static_assert(NS <= 64, "too many sums");
 #pragma unroll
     for (int c8 = 0; c8 < (NS + 7) / 8; c8++) {
 #pragma unroll
@@ -193,7 +259,12 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
             const int m = c8 * 8 + k;
             double v = 0.0;
             if (m < NP) v = gr[m < NP ? m : 0];
-            else if (m < NS) v = ga[(m - NP) < NT && (m - NP) >= 0 ? (m - NP) : 0];
+            else if (m < NP + NT - 2) v = ga[(m - NP + 2) < NT && (m - NP + 2) >= 2 ? (m - NP + 2) : 2];
+            else if (m == NP + NT - 2) v = s1;
+            else if (m == NP + NT - 1) v = s2;
+            else if (m == NP + NT) v = vx;
+            else if (m == NP + NT + 1) v = vy;
+            else if (m == NP + NT + 2) v = vz;
             scratch[k * 64 + lane] = v;
         }
         wave_lds_sync();
@@ -207,11 +278,24 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
             s += __shfl_xor(s, 2, 64);
             s += __shfl_xor(s, 4, 64);
             const int m = c8 * 8 + k;
-            if (part == 0 && m < NS) Gout[m] = s;
+            if (part == 0 && m < NS) red[m] = s;
         }
         wave_lds_sync();
     }
-    if (lane >= NS && lane < ANNP_GPAD) Gout[lane] = 0.0;
+    double *Gout = p.G + (size_t)ii * ANNP_GPAD;
+    if (lane < ANNP_GPAD) {
+        double v = 0.0;
+        if (lane < NP) v = red[lane];
+        else if (lane >= NP + 2 && lane < NP + NT) v = red[lane - 2];
+        else if (lane == NP || lane == NP + 1) {
+            const double S1 = red[NP + NT - 2], S2 = red[NP + NT - 1];
+            const double V0 = red[NP + NT], V1 = red[NP + NT + 1], V2 = red[NP + NT + 2];
+            const double g0 = 0.5 * (S1 * S1 - S2);                            // sum w T_0
+            const double wc = 0.5 * (fma(V0, V0, fma(V1, V1, V2 * V2)) - S2);   // sum w cos
+            v = (lane == NP) ? g0 : 0.5 * (wc + g0);                           // T_1 = (cos+1)/2
+        }
+        Gout[lane] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -220,6 +304,13 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
 //             [NP, NP+NT)       p_0..p_{NT-1}       P(z) = sum_n c_{NP+n} T_n((z+1)/2) = sum_k p_k z^k
 //             [NP+NT, NP+2NT-1) d_0..d_{NT-2}       dP/dz = sum_k d_k z^k
 //   with z = cos(theta_jik); written by the network pass (mlp_kernels.hpp epilogue)
+//
+//   per pair (a,b):  alpha = dP/dz fc_a fc_b
+//     d/dx_a :  alpha (-e_b + z e_a)/r_a  - P fc'_a fc_b e_a          (fe:683 with fe:618-628)
+//   so with V_a = sum_b alpha e_b, C_a = sum_b alpha z, S_a = sum_b P fc_b:
+//     Fn_a = (-V_a + C_a e_a)/r_a - (S_a fc'_a + R_a) e_a,   R_a = radial dE/dr   (fe:648)
+//   The lane that evaluates the pair adds the a-side in registers and scatters the b-side
+//   (5 doubles) with LDS atomics.
 // ---------------------------------------------------------------------------------
 template <int NP, int NT, bool VIRIAL>
 __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
@@ -244,37 +335,26 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     int *auxJ = reinterpret_cast<int *>(auxR + n1);
 
     const int i = p.ilist ? p.ilist[ii] : ii;
-    const double xi = p.x[3 * (size_t)i], yi = p.x[3 * (size_t)i + 1], zi = p.x[3 * (size_t)i + 2];
-    const long long base = p.first[i];
-    const int jn = p.numneigh[i];
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
     const double two_over_rcp = 2.0 / p.rc_par;
     const double *cf = p.coef + (size_t)ii * ANNP_CPAD;
 
-    double cr[NP];
+    const int n = fe_compact<true>(p, i, lane, recA, recB, auxJ);
+    if (n > p.n_cap) {
+        if (lane == 0) atomicMax(p.errflag, n);
+        return;
+    }
+    wave_lds_sync();
+    {
+        double cr[NP];
 #pragma unroll
-    for (int m = 0; m < NP; m++) cr[m] = cf[m];
-
-    // ---- stage A
-    int n = 0;
-    for (int c0 = 0; c0 < jn; c0 += 64) {
-        const int jj = c0 + lane;
-        const bool valid = jj < jn;
-        const int j = valid ? (p.neigh[base + jj] & ANNP_NEIGHMASK) : i;
-        const double dx = xi - p.x[3 * (size_t)j], dy = yi - p.x[3 * (size_t)j + 1], dz = zi - p.x[3 * (size_t)j + 2];
-        const double rsq = dx * dx + dy * dy + dz * dz;
-        const bool in = valid && !(rsq > p.cutsq) && !(rsq < 1.0e-12);
-        const unsigned long long m = __ballot(in);
-        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-        if (in && pos < p.n_cap) {
-            const double r = sqrt(rsq);
-            const double rinv = 1.0 / r;
-            double fc, dfc;
-            cutoff_fc(r, pi_over_rc, fc, dfc);
-            recA[pos] = make_double2(dx * rinv, dy * rinv);
-            recB[pos] = make_double2(dz * rinv, fc);
+        for (int m = 0; m < NP; m++) cr[m] = cf[m];
+        for (int a = lane; a < n; a += 64) {
+            const FeNbr g = fe_geometry(recA[a], recB[a], pi_over_rc);
+            recA[a] = make_double2(g.ex, g.ey);
+            recB[a] = make_double2(g.ez, g.fc);
             // radial: R = sum_m c_m (T'_m 2/Rc fc + T_m fc')    (fe:648)
-            const double xr = r * two_over_rcp - 1.0;
+            const double xr = g.r * two_over_rcp - 1.0;
             const double y2 = 2.0 * xr;
             double tm2 = 1.0, tm1 = xr, dm2 = 0.0, dm1 = 1.0;
             double st = cr[0], sd = 0.0;              // sum c T, sum c T'
@@ -287,23 +367,17 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
                 sd = fma(cr[mm], d, sd);
                 tm2 = tm1; tm1 = t; dm2 = dm1; dm1 = d;
             }
-            auxR[pos] = fma(sd * two_over_rcp, fc, st * dfc);
-            auxRinv[pos] = rinv;
-            auxDfc[pos] = dfc;
-            auxJ[pos] = j;
-            accV0[pos] = 0.0; accV1[pos] = 0.0; accV2[pos] = 0.0; accS[pos] = 0.0; accC[pos] = 0.0;
+            auxR[a] = fma(sd * two_over_rcp, g.fc, st * g.dfc);
+            auxRinv[a] = g.rinv;
+            auxDfc[a] = g.dfc;
+            accV0[a] = 0.0; accV1[a] = 0.0; accV2[a] = 0.0; accS[a] = 0.0; accC[a] = 0.0;
         }
-        n += __popcll(m);
     }
-    n = uniform(n);
-    if (n > p.n_cap) {
-        if (lane == 0) atomicMax(p.errflag, n);
-        return;
-    }
-    if (lane == 0) {
-        recA[p.n_cap] = make_double2(0.0, 0.0);
-        recB[p.n_cap] = make_double2(0.0, 0.0);
-        accV0[p.n_cap] = 0.0; accV1[p.n_cap] = 0.0; accV2[p.n_cap] = 0.0; accS[p.n_cap] = 0.0; accC[p.n_cap] = 0.0;
+    if (lane < FE_DUMP) {
+        const int d = p.n_cap + lane;
+        recA[d] = make_double2(0.0, 0.0);
+        recB[d] = make_double2(0.0, 0.0);
+        accV0[d] = 0.0; accV1[d] = 0.0; accV2[d] = 0.0; accS[d] = 0.0; accC[d] = 0.0;
     }
     wave_lds_sync();
 
@@ -320,30 +394,25 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     const int nitems = n * FE_Q;
     const bool even = (n & 1) == 0;
     const int dump = p.n_cap + (lane & (FE_DUMP - 1));
-    int a = lane, q = 0;
-    while (a >= n && q < FE_Q) { a -= n; q++; }
+    FeItem it;
+    it.init(lane, n);
     for (int it0 = 0; it0 < nitems; it0 += 64) {
-        const bool act = q < FE_Q;
-        const int t0 = 1 + q * L;
+        const bool act = it.q < FE_Q;
+        const int t0 = 1 + it.q * L;
         int t1 = min(H, t0 + L - 1);
-        if (even && a >= H && t1 == H) t1 = H - 1;
+        if (even && it.a >= H && t1 == H) t1 = H - 1;
         const int smax = act ? (t1 - t0) : -1;
-        const int ar = act ? a : p.n_cap;
+        const int ar = act ? it.a : p.n_cap;          // idle lanes: null record (fc_a = 0 -> they scatter zeros)
         const double2 A0 = recA[ar], A1 = recB[ar];
         double va0 = 0.0, va1 = 0.0, va2 = 0.0, sa = 0.0, ca = 0.0;
-        int b = a + t0;
+        const int inc = act ? 1 : 0;
+        int b = it.a + t0;
         if (b >= n) b -= n;
-        int bi = (0 <= smax) ? b : p.n_cap;
-        double2 B0 = recA[bi], B1 = recB[bi];
-        // land the first record before the loop: inside it only the prefetch and the
-        // (result-less) atomics are in flight, so the loop needs one counted wait per step
-        asm volatile("" : "+v"(B0.x), "+v"(B0.y), "+v"(B1.x), "+v"(B1.y));
-        for (int s = 0; s < L; ++s) {
-            b++;
-            if (b == n) b = 0;
-            const int bn = (s + 1 <= smax) ? b : p.n_cap;
-            const double2 N0 = recA[bn], N1 = recB[bn];      // prefetch, issued first
-            __builtin_amdgcn_sched_barrier(0);
+        if (!act) b = p.n_cap;
+        const int Lm = fe_round_min_steps(it.q, H, L, even);
+
+        // one pair: evaluate, keep the a-side, scatter the b-side to slot bt
+        auto step = [&](const double2 B0, const double2 B1, const int bt) {
             const double c = fma(A1.x, B1.x, fma(A0.y, B0.y, A0.x * B0.x));
             // P(z) and dP/dz by Horner, z = cos(theta)
             double P = ce[NT - 1];
@@ -354,25 +423,44 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
                 if (mm < NT - 2) Pd = fma(Pd, c, cd[mm]);
             }
             const double w = A1.y * B1.y;          // fc_a fc_b
-            const double al = Pd * w;              // (P'/2) fc_a fc_b
+            const double al = Pd * w;
             const double alc = al * c;
             va0 = fma(al, B0.x, va0); va1 = fma(al, B0.y, va1); va2 = fma(al, B1.x, va2);
             sa = fma(P, B1.y, sa);
             ca += alc;
 #if ANNP_VARIANT != 3
-            {   // unconditional: masked-off steps carry zero weight and land in a dump slot,
-                // so the scatter needs no branch and the prefetch above keeps a counted wait
-                const int bt = (bi == p.n_cap) ? dump : bi;
-                atomicAdd(&accV0[bt], al * A0.x);
-                atomicAdd(&accV1[bt], al * A0.y);
-                atomicAdd(&accV2[bt], al * A1.x);
-                atomicAdd(&accS[bt], P * A1.y);
-                atomicAdd(&accC[bt], alc);
-            }
+            atomicAdd(&accV0[bt], al * A0.x);
+            atomicAdd(&accV1[bt], al * A0.y);
+            atomicAdd(&accV2[bt], al * A1.x);
+            atomicAdd(&accS[bt], P * A1.y);
+            atomicAdd(&accC[bt], alc);
 #else
-            asm volatile("" ::"v"(al * A0.x), "v"(al * A0.y), "v"(al * A1.x), "v"(P * A1.y));
+            asm volatile("" ::"v"(al * A0.x), "v"(al * A0.y), "v"(al * A1.x), "v"(P * A1.y), "v"(bt));
 #endif
-            B0 = N0; B1 = N1; bi = bn;
+        };
+
+        int s = 0;
+        if (Lm > 0) {
+            double2 B0 = recA[b], B1 = recB[b];
+            // land the first record before the loop: inside it only the prefetch and the
+            // (result-less) atomics are in flight, so the loop needs one counted wait per step
+            asm volatile("" : "+v"(B0.x), "+v"(B0.y), "+v"(B1.x), "+v"(B1.y));
+            for (; s < Lm; ++s) {
+                const int bt = act ? b : dump;
+                b += inc;
+                if (b == n) b = 0;
+                const double2 N0 = recA[b], N1 = recB[b];      // prefetch, issued first
+                __builtin_amdgcn_sched_barrier(0);
+                step(B0, B1, bt);
+                B0 = N0; B1 = N1;
+            }
+        }
+        for (; s < L; ++s) {                       // ragged tail of the round
+            const bool ok = s <= smax;
+            const int bi = ok ? b : p.n_cap;
+            step(recA[bi], recB[bi], ok ? b : dump);
+            b += inc;
+            if (b == n) b = 0;
         }
         {
             const int at = act ? ar : dump;
@@ -382,8 +470,7 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
             atomicAdd(&accS[at], sa);
             atomicAdd(&accC[at], ca);
         }
-        a += 64;
-        while (a >= n && q < FE_Q) { a -= n; q++; }
+        it.next(n);
     }
     wave_lds_sync();
 

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *opnd = reinterpret_cast<double *>(lds_raw);                 // [S::total][64]
     double *cbuf_all = opnd + (size_t)S::total * 64;                    // [4 waves][16][32]
+    double *m2m = cbuf_all + (size_t)ANNP_WAVES_PER_BLOCK * 16 * 32;    // [nt][nt] Chebyshev -> monomial (mode 0)
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -134,6 +135,8 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
         }
         opnd[(size_t)slot * 64 + lane] = v;
     }
+    if (p.mode == 0)
+        for (int k = threadIdx.x; k < p.nt * p.nt; k += blockDim.x) m2m[k] = p.cheb2mono[k];
     __syncthreads();
     double *cbuf = cbuf_all + (size_t)wave * 16 * 32;
 
@@ -256,11 +259,11 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
                 v = c[o];
             } else if (o < np + nt) {                 // p_k: P(z) = sum_n c_n T_n((z+1)/2) = sum_k p_k z^k
                 const int k = o - np;
-                const double *row = p.cheb2mono + (size_t)k * nt;
+                const double *row = m2m + k * nt;
                 for (int m = k; m < nt; m++) v = fma(row[m], c[np + m], v);      // T_n has no z^k for n < k
             } else if (o < np + 2 * nt - 1) {         // d_k = (k+1) p_{k+1}:  dP/dz
                 const int k = o - np - nt;
-                const double *row = p.cheb2mono + (size_t)(k + 1) * nt;
+                const double *row = m2m + (k + 1) * nt;
                 for (int m = k + 1; m < nt; m++) v = fma(row[m], c[np + m], v);
                 v *= (double)(k + 1);
             }
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
 template <int KS0, int MT, int NL>
 inline size_t mlp_lds_bytes()
 {
-    return ((size_t)MlpSlots<KS0, MT, NL>::total * 64 + (size_t)ANNP_WAVES_PER_BLOCK * 16 * 32) * sizeof(double);
+    return ((size_t)MlpSlots<KS0, MT, NL>::total * 64 + (size_t)ANNP_WAVES_PER_BLOCK * 16 * 32 + 32 * 32) * sizeof(double);
 }
 
 }  // namespace annp
