@@ -209,10 +209,10 @@ def main():
         xs = dom.x.cpu().numpy()
         s = _sample_system(lib, h, xs, nlocal, nall, m, rc_list)
         pot = read_pot(FE_POT)
-        nthreads = oracle_lib().annp_oracle_max_threads()
-        oracle_compute(pot, s, KIND_FE, FAST, inum=min(m, 256))           # warm
+        nthreads = min(oracle_lib().annp_oracle_max_threads(), _cpu_share())
+        oracle_compute(pot, s, KIND_FE, FAST, inum=min(m, 256), nthreads=nthreads)           # warm
         t1 = time.perf_counter()
-        oracle_compute(pot, s, KIND_FE, FAST, inum=m)
+        oracle_compute(pot, s, KIND_FE, FAST, inum=m, nthreads=nthreads)
         tc = time.perf_counter() - t1
         out["cpu_baseline"] = {
             "value": m / tc, "unit": "atom-steps/s", "cores": int(nthreads), "kind": "port",
@@ -223,6 +223,18 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _cpu_share():
+    """CPUs this process may actually use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
 
 
 class _NoDist:

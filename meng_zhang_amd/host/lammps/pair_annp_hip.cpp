@@ -1,0 +1,109 @@
+/* pair_annp_hip.cpp -- see pair_annp_hip.h.  The only translation unit that needs
+ * LAMMPS headers (stable_2Aug2023 or later; the reference targets that release,
+ * annp-gpu-lammps/README.md:17). */
+#include "pair_annp_hip.h"
+
+#include "annp_pair.h"     // meng_zhang_amd/host
+
+#include "atom.h"
+#include "comm.h"
+#include "error.h"
+#include "force.h"
+#include "memory.h"
+#include "neigh_list.h"
+#include "neighbor.h"
+#include "universe.h"
+
+#include <cstdlib>
+#include <cstring>
+
+using namespace LAMMPS_NS;
+
+PairANNPHIP::PairANNPHIP(LAMMPS *lmp) : Pair(lmp), impl(nullptr), cutmax(0.0), device_id(0)
+{
+  restartinfo = 0;      // fe_v2/src/pair_annp.cpp:45-47
+  one_coeff = 1;
+  manybody_flag = 1;
+}
+
+PairANNPHIP::~PairANNPHIP()
+{
+  if (copymode) return;
+  delete impl;          // releases the device (annp_hip_clear), as pair_annp_gpu.cpp:68-70
+  if (allocated) {
+    memory->destroy(cutsq);
+    memory->destroy(setflag);
+  }
+}
+
+void PairANNPHIP::allocate()
+{
+  allocated = 1;
+  const int n = atom->ntypes;
+  memory->create(cutsq, n + 1, n + 1, "pair:cutsq");
+  memory->create(setflag, n + 1, n + 1, "pair:setflag");
+  for (int i = 1; i <= n; i++)
+    for (int j = i; j <= n; j++) setflag[i][j] = 0;
+}
+
+void PairANNPHIP::settings(int narg, char **arg)
+{
+  if (!impl) impl = new annp_host::PairANNP(atom->ntypes);
+  if (impl->settings(narg, arg) != 0) error->all(FLERR, impl->error());
+}
+
+void PairANNPHIP::coeff(int narg, char **arg)
+{
+  if (!allocated) allocate();
+  if (!impl) impl = new annp_host::PairANNP(atom->ntypes);
+  if (impl->coeff(narg, arg) != 0) error->all(FLERR, impl->error());
+  cutmax = impl->cutmax();
+  for (int i = 1; i <= atom->ntypes; i++)
+    for (int j = i; j <= atom->ntypes; j++) setflag[i][j] = 1;   // every type maps to the single element
+}
+
+void PairANNPHIP::init_style()
+{
+  if (force->newton_pair == 0) error->all(FLERR, "Pair style annp/hip requires newton pair on");
+  // one GPU per rank: ranks on a node take devices round-robin unless told otherwise
+  const char *env = std::getenv("ANNP_HIP_DEVICE");
+  if (env) device_id = std::atoi(env);
+  else {
+    const char *lr = std::getenv("OMPI_COMM_WORLD_LOCAL_RANK");
+    if (!lr) lr = std::getenv("MPI_LOCALRANKID");
+    if (!lr) lr = std::getenv("SLURM_LOCALID");
+    const char *nd = std::getenv("ANNP_HIP_DEVICES_PER_NODE");
+    const int ndev = nd ? std::atoi(nd) : 8;
+    device_id = (lr ? std::atoi(lr) : comm->me) % (ndev > 0 ? ndev : 1);
+  }
+  const int rc = impl->init_style(force->newton_pair, device_id);
+  if (rc != 0) error->all(FLERR, impl->error());     // GPU_EXTRA::check_flag equivalent
+  neighbor->add_request(this, NeighConst::REQ_FULL); // fe_v2/src/pair_annp.cpp:317
+}
+
+double PairANNPHIP::init_one(int i, int j)
+{
+  if (setflag[i][j] == 0) error->all(FLERR, "All pair coeffs are not set");
+  return cutmax;
+}
+
+void PairANNPHIP::compute(int eflag, int vflag)
+{
+  ev_init(eflag, vflag);
+  const int nall = atom->nlocal + atom->nghost;
+  double evdwl = 0.0;
+  double v6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  // atom->x and atom->f are contiguous nall x 3 arrays (memory->create), x[0] is the flat pointer
+  const int rc = impl->compute(eflag_either, vflag_global, eflag_atom, neighbor->ago, list->inum, nall, atom->nghost,
+                               atom->x[0], atom->type, list->ilist, list->numneigh, list->firstneigh,
+                               atom->f[0], &evdwl, eflag_atom ? eatom : nullptr, vflag_global ? v6 : nullptr);
+  if (rc != 0) error->one(FLERR, impl->error());
+  if (eflag_global) eng_vdwl += evdwl;                 // fe_v2/src/pair_annp.cpp:185
+  if (vflag_global) for (int k = 0; k < 6; k++) virial[k] += v6[k];
+  if (vflag_fdotr) virial_fdotr_compute();             // fe_v2/src/pair_annp.cpp:221
+}
+
+double PairANNPHIP::memory_usage()
+{
+  return Pair::memory_usage() + (impl ? impl->memory_usage() : 0.0);
+}
