@@ -62,7 +62,7 @@ __host__ __device__ inline size_t fe_desc_lds_per_wave(int n_cap)
 }
 __host__ __device__ inline size_t fe_force_lds_per_wave(int n_cap)
 {
-    return (size_t)(n_cap + FE_DUMP) * (32 + 40 + 24 + 8);
+    return (size_t)(n_cap + FE_DUMP) * (32 + 40 + 24 + 8);   // records, accumulators, (1/r, fc', R), index (padded)
 }
 
 // ---- stage A, first sweep: candidates -> compacted raw entries (dx,dy | dz,r^2) [+ index]
@@ -324,12 +324,12 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     unsigned char *wbase = lds_raw + (size_t)wave * fe_force_lds_per_wave(p.n_cap);
     double2 *recA = reinterpret_cast<double2 *>(wbase);          // e.x e.y
     double2 *recB = recA + n1;                                    // e.z fc
-    double *accV0 = reinterpret_cast<double *>(recB + n1);        // sum alpha e_b .x
-    double *accV1 = accV0 + n1;
-    double *accV2 = accV1 + n1;
-    double *accS = accV2 + n1;                                    // sum P fc_b
-    double *accC = accS + n1;                                     // sum alpha cos
-    double *auxRinv = accC + n1;
+    // per-neighbour accumulators, 5 doubles each (stride 40 B: the 16 lanes of an LDS pass
+    // land on 16 distinct even banks, so 64-bit atomics of consecutive b stay conflict-free
+    // and the five adds of a step share one address register):
+    //   [0..2] V = sum alpha e_b   [3] S = sum P fc_b   [4] C = sum alpha cos
+    double *acc = reinterpret_cast<double *>(recB + n1);
+    double *auxRinv = acc + 5 * n1;
     double *auxDfc = auxRinv + n1;
     double *auxR = auxDfc + n1;                                   // radial dE/dr
     int *auxJ = reinterpret_cast<int *>(auxR + n1);
@@ -370,14 +370,16 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
             auxR[a] = fma(sd * two_over_rcp, g.fc, st * g.dfc);
             auxRinv[a] = g.rinv;
             auxDfc[a] = g.dfc;
-            accV0[a] = 0.0; accV1[a] = 0.0; accV2[a] = 0.0; accS[a] = 0.0; accC[a] = 0.0;
+            double *q = acc + 5 * a;
+            q[0] = 0.0; q[1] = 0.0; q[2] = 0.0; q[3] = 0.0; q[4] = 0.0;
         }
     }
     if (lane < FE_DUMP) {
         const int d = p.n_cap + lane;
         recA[d] = make_double2(0.0, 0.0);
         recB[d] = make_double2(0.0, 0.0);
-        accV0[d] = 0.0; accV1[d] = 0.0; accV2[d] = 0.0; accS[d] = 0.0; accC[d] = 0.0;
+        double *q = acc + 5 * d;
+        q[0] = 0.0; q[1] = 0.0; q[2] = 0.0; q[3] = 0.0; q[4] = 0.0;
     }
     wave_lds_sync();
 
@@ -388,6 +390,9 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
 #pragma unroll
     for (int m = 0; m < NT - 1; m++) cd[m] = cf[NP + NT + m];
     cd[NT - 1] = 0.0;
+    // the two Horner chains start from a register, not from a second SGPR operand per step
+    double ce_top = ce[NT - 1], cd_top = cd[NT - 2];
+    asm volatile("" : "+v"(ce_top), "+v"(cd_top));
 
     const int H = n >> 1;
     const int L = (H + FE_Q - 1) / FE_Q;
@@ -415,8 +420,8 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
         auto step = [&](const double2 B0, const double2 B1, const int bt) {
             const double c = fma(A1.x, B1.x, fma(A0.y, B0.y, A0.x * B0.x));
             // P(z) and dP/dz by Horner, z = cos(theta)
-            double P = ce[NT - 1];
-            double Pd = cd[NT - 2];
+            double P = ce_top;
+            double Pd = cd_top;
 #pragma unroll
             for (int mm = NT - 2; mm >= 0; mm--) {
                 P = fma(P, c, ce[mm]);
@@ -429,11 +434,12 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
             sa = fma(P, B1.y, sa);
             ca += alc;
 #if ANNP_VARIANT != 3
-            atomicAdd(&accV0[bt], al * A0.x);
-            atomicAdd(&accV1[bt], al * A0.y);
-            atomicAdd(&accV2[bt], al * A1.x);
-            atomicAdd(&accS[bt], P * A1.y);
-            atomicAdd(&accC[bt], alc);
+            double *q = acc + 5 * bt;
+            atomicAdd(q + 0, al * A0.x);
+            atomicAdd(q + 1, al * A0.y);
+            atomicAdd(q + 2, al * A1.x);
+            atomicAdd(q + 3, P * A1.y);
+            atomicAdd(q + 4, alc);
 #else
             asm volatile("" ::"v"(al * A0.x), "v"(al * A0.y), "v"(al * A1.x), "v"(P * A1.y), "v"(bt));
 #endif
@@ -445,14 +451,26 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
             // land the first record before the loop: inside it only the prefetch and the
             // (result-less) atomics are in flight, so the loop needs one counted wait per step
             asm volatile("" : "+v"(B0.x), "+v"(B0.y), "+v"(B1.x), "+v"(B1.y));
-            for (; s < Lm; ++s) {
-                const int bt = act ? b : dump;
+            for (; s + 1 < Lm; s += 2) {                   // two steps per trip: records ping-pong B <-> N
+                const int bt0 = act ? b : dump;
                 b += inc;
                 if (b == n) b = 0;
                 const double2 N0 = recA[b], N1 = recB[b];      // prefetch, issued first
                 __builtin_amdgcn_sched_barrier(0);
+                step(B0, B1, bt0);
+                const int bt1 = act ? b : dump;
+                b += inc;
+                if (b == n) b = 0;
+                B0 = recA[b]; B1 = recB[b];
+                __builtin_amdgcn_sched_barrier(0);
+                step(N0, N1, bt1);
+            }
+            if (s < Lm) {                                  // odd count: one more, record already here
+                const int bt = act ? b : dump;
+                b += inc;
+                if (b == n) b = 0;
                 step(B0, B1, bt);
-                B0 = N0; B1 = N1;
+                ++s;
             }
         }
         for (; s < L; ++s) {                       // ragged tail of the round
@@ -463,12 +481,12 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
             if (b == n) b = 0;
         }
         {
-            const int at = act ? ar : dump;
-            atomicAdd(&accV0[at], va0);
-            atomicAdd(&accV1[at], va1);
-            atomicAdd(&accV2[at], va2);
-            atomicAdd(&accS[at], sa);
-            atomicAdd(&accC[at], ca);
+            double *q = acc + 5 * (act ? ar : dump);
+            atomicAdd(q + 0, va0);
+            atomicAdd(q + 1, va1);
+            atomicAdd(q + 2, va2);
+            atomicAdd(q + 3, sa);
+            atomicAdd(q + 4, ca);
         }
         it.next(n);
     }
@@ -480,10 +498,11 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     for (int a = lane; a < n; a += 64) {
         const double2 E0 = recA[a], E1 = recB[a];
         const double rinv = auxRinv[a];
-        const double t = fma(accC[a], rinv, -fma(accS[a], auxDfc[a], auxR[a]));
-        const double g0 = fma(t, E0.x, -accV0[a] * rinv);
-        const double g1 = fma(t, E0.y, -accV1[a] * rinv);
-        const double g2 = fma(t, E1.x, -accV2[a] * rinv);
+        const double *q = acc + 5 * a;
+        const double t = fma(q[4], rinv, -fma(q[3], auxDfc[a], auxR[a]));
+        const double g0 = fma(t, E0.x, -q[0] * rinv);
+        const double g1 = fma(t, E0.y, -q[1] * rinv);
+        const double g2 = fma(t, E1.x, -q[2] * rinv);
         const int j = auxJ[a];
         atomicAdd(&p.f[3 * (size_t)j], -g0);
         atomicAdd(&p.f[3 * (size_t)j + 1], -g1);
