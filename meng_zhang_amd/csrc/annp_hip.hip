@@ -49,9 +49,9 @@ struct annp_hip_handle {
     double e_scale = 0, e_shift = 0, e_atom = 0, cut = 0, cutsq = 0;
     double *dW[MLP_MAXL] = {nullptr, nullptr, nullptr, nullptr};
     double *dB[MLP_MAXL] = {nullptr, nullptr, nullptr, nullptr};
-    double *d_norm = nullptr;           // nmul | nsub | nden | cmul, ANNP_GPAD each
+    double *d_norm = nullptr;           // nmul | nsub | nden, ANNP_GPAD each
+    double *d_coefmat = nullptr;        // [ANNP_CPAD][nnod]: coef = coefmat . dE/dZ_0 (network pass epilogue)
     double *d_sym = nullptr;            // BEHLER: rad[npsf*3] then ang[ntsf*4]
-    double *d_cheb2mono = nullptr;      // CHEBYSHEV: [ntsf][ntsf] T_n((z+1)/2) -> powers of z
     std::vector<double> sym_rad, sym_ang;
     // work buffers
     DevBuf<double> G, coef, x, f, eatom;
@@ -171,10 +171,9 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     MlpArgs m{};
     m.inum = inum; m.ilist = d_ilist; m.nsf = h->nsf; m.nnod = h->nnod; m.nl = h->nl;
     for (int l = 0; l < h->nl; l++) { m.act[l] = h->flagact[l]; m.W[l] = h->dW[l]; m.B[l] = h->dB[l]; }
-    m.nmul = h->d_norm; m.nsub = h->d_norm + ANNP_GPAD; m.nden = h->d_norm + 2 * ANNP_GPAD; m.cmul = h->d_norm + 3 * ANNP_GPAD;
+    m.nmul = h->d_norm; m.nsub = h->d_norm + ANNP_GPAD; m.nden = h->d_norm + 2 * ANNP_GPAD; m.coefmat = h->d_coefmat;
     m.e_scale = h->e_scale; m.e_shift = h->e_shift; m.e_atom = h->e_atom;
     m.G = h->G.p; m.coef = h->coef.p; m.eatom = d_eatom; m.eng = d_eng;
-    m.np = h->npsf; m.nt = h->ntsf; m.cheb2mono = h->d_cheb2mono;
 
     if (h->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
         if (!(h->npsf == 9 && h->ntsf == 19))
@@ -194,7 +193,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         HIP_TRY(h, hipGetLastError());
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
         // pass 2
-        m.act_plain = 0; m.energy_raw = 0; m.mode = 0;
+        m.act_plain = 0; m.energy_raw = 0;
         if ((rc = run_mlp(h, m, s))) return rc;
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
         // pass 3: size the LDS records by the in-cutoff maximum just measured
@@ -219,7 +218,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         if (rcn) return fail(h, ANNP_HIP_ESHAPE, "Behler kernels support npsf<=%d ntsf<=%d", NI_MAXP, NI_MAXT);
         HIP_TRY(h, hipGetLastError());
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
-        m.act_plain = 1; m.energy_raw = 1; m.mode = 1;
+        m.act_plain = 1; m.energy_raw = 1;
         if ((rc = run_mlp(h, m, s))) return rc;
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
         ni_launch_force(a, blocks, d_virial != nullptr, s);
@@ -249,7 +248,7 @@ void annp_hip_clear(annp_hip_handle *h)
     for (int l = 0; l < MLP_MAXL; l++) { if (h->dW[l]) (void)hipFree(h->dW[l]); if (h->dB[l]) (void)hipFree(h->dB[l]); }
     if (h->d_norm) (void)hipFree(h->d_norm);
     if (h->d_sym) (void)hipFree(h->d_sym);
-    if (h->d_cheb2mono) (void)hipFree(h->d_cheb2mono);
+    if (h->d_coefmat) (void)hipFree(h->d_coefmat);
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom);
     release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount);
     release(h, h->first);
@@ -316,45 +315,63 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         INIT_TRY(hipMemcpy(h->dB[l], p->bias_all[l], sizeof(double) * nr, hipMemcpyHostToDevice));
         h->bytes += sizeof(double) * (nr * nc + nr);
     }
-    {   // normalisation / coefficient tables
-        std::vector<double> t(4 * ANNP_GPAD, 0.0);
-        for (int k = 0; k < ANNP_GPAD; k++) { t[k] = 0.0; t[ANNP_GPAD + k] = 0.0; t[2 * ANNP_GPAD + k] = 1.0; t[3 * ANNP_GPAD + k] = 0.0; }
+    {   // normalisation of the descriptor and the linear map dE/dZ_0 -> coef
+        std::vector<double> t(3 * ANNP_GPAD, 0.0), cmul(ANNP_GPAD, 0.0);
+        for (int k = 0; k < ANNP_GPAD; k++) t[2 * ANNP_GPAD + k] = 1.0;
         for (int k = 0; k < p->nsf; k++) {
             if (p->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
                 // G_k = s_k * sum  (fe:647,678);  Ghat = G - s_k avg_k (fe:178-180);  c_k = e_scale s_k dE/dGhat_k (fe:197)
                 t[k] = p->sfnor_scal[k];
                 t[ANNP_GPAD + k] = p->sfnor_scal[k] * p->sfnor_avg[k];
                 t[2 * ANNP_GPAD + k] = 1.0;
-                t[3 * ANNP_GPAD + k] = p->e_scale * p->sfnor_scal[k];
+                cmul[k] = p->e_scale * p->sfnor_scal[k];
             } else {
                 // Ghat = (G - sf_min)/(sf_max - sf_min) (ni:168-170);  F = -dE/dGhat dG / (sf_max-sf_min) * CFFORCE (ni:186-189)
                 t[k] = 1.0;
                 t[ANNP_GPAD + k] = p->sfnor_avg[k];
                 t[2 * ANNP_GPAD + k] = p->sfnor_scal[k];
-                t[3 * ANNP_GPAD + k] = 1.0 / p->sfnor_scal[k];
+                cmul[k] = 1.0 / p->sfnor_scal[k];
             }
         }
         INIT_TRY(hipMalloc((void **)&h->d_norm, sizeof(double) * t.size()));
         INIT_TRY(hipMemcpy(h->d_norm, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
         h->bytes += sizeof(double) * t.size();
-    }
-    if (p->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
-        // coefficients of z^k in T_n((z+1)/2): T_0 = 1, T_1 = (1+z)/2, T_n = (1+z) T_{n-1} - T_{n-2}.
-        // All entries are dyadic rationals below 2^53, so this fp64 recurrence is exact.
-        const int nt = p->ntsf;
-        std::vector<double> M((size_t)nt * nt, 0.0);       // M[k*nt + n]
-        std::vector<double> a(nt, 0.0), b(nt, 0.0), t(nt, 0.0);
-        a[0] = 1.0;
-        for (int k = 0; k < nt; k++) M[(size_t)k * nt + 0] = a[k];
-        if (nt > 1) { b[0] = 0.5; b[1] = 0.5; for (int k = 0; k < nt; k++) M[(size_t)k * nt + 1] = b[k]; }
-        for (int n = 2; n < nt; n++) {
-            for (int k = 0; k < nt; k++) t[k] = b[k] + (k > 0 ? b[k - 1] : 0.0) - a[k];
-            a = b; b = t;
-            for (int k = 0; k < nt; k++) M[(size_t)k * nt + n] = b[k];
+
+        // T: rows of coef as linear forms of c_k = cmul_k dE/dGhat_k
+        const int nsf = p->nsf, np_ = p->npsf, nt = p->ntsf, nnod = p->nnod;
+        std::vector<long double> T((size_t)ANNP_CPAD * nsf, 0.0L);
+        if (p->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
+            if (np_ + 2 * nt - 1 > ANNP_CPAD) { fail(h, 0, "descriptor too large for the coefficient buffer"); return bail(ANNP_HIP_ESHAPE); }
+            // coefficients of z^k in T_n((z+1)/2): T_0 = 1, T_1 = (1+z)/2, T_n = (1+z) T_{n-1} - T_{n-2}.
+            // All entries are dyadic rationals below 2^53, so this recurrence is exact.
+            std::vector<double> M((size_t)nt * nt, 0.0), a(nt, 0.0), b(nt, 0.0), tt(nt, 0.0);
+            a[0] = 1.0;
+            for (int k = 0; k < nt; k++) M[(size_t)k * nt + 0] = a[k];
+            if (nt > 1) { b[0] = 0.5; b[1] = 0.5; for (int k = 0; k < nt; k++) M[(size_t)k * nt + 1] = b[k]; }
+            for (int n = 2; n < nt; n++) {
+                for (int k = 0; k < nt; k++) tt[k] = b[k] + (k > 0 ? b[k - 1] : 0.0) - a[k];
+                a = b; b = tt;
+                for (int k = 0; k < nt; k++) M[(size_t)k * nt + n] = b[k];
+            }
+            for (int m = 0; m < np_; m++) T[(size_t)m * nsf + m] = 1.0L;                          // radial c_m
+            for (int k = 0; k < nt; k++)                                                          // p_k
+                for (int n = 0; n < nt; n++) T[(size_t)(np_ + k) * nsf + np_ + n] = M[(size_t)k * nt + n];
+            for (int k = 0; k + 1 < nt; k++)                                                      // d_k = (k+1) p_{k+1}
+                for (int n = 0; n < nt; n++) T[(size_t)(np_ + nt + k) * nsf + np_ + n] = (long double)(k + 1) * M[(size_t)(k + 1) * nt + n];
+        } else {
+            for (int k = 0; k < nsf; k++) T[(size_t)k * nsf + k] = 1.0L;
         }
-        INIT_TRY(hipMalloc((void **)&h->d_cheb2mono, sizeof(double) * M.size()));
-        INIT_TRY(hipMemcpy(h->d_cheb2mono, M.data(), sizeof(double) * M.size(), hipMemcpyHostToDevice));
-        h->bytes += sizeof(double) * M.size();
+        // coefmat[o][i] = sum_k T[o][k] cmul_k W_0[i][k]
+        std::vector<double> cm((size_t)ANNP_CPAD * nnod, 0.0);
+        for (int o = 0; o < ANNP_CPAD; o++)
+            for (int i = 0; i < nnod; i++) {
+                long double acc = 0.0L;
+                for (int k = 0; k < nsf; k++) acc += T[(size_t)o * nsf + k] * (long double)cmul[k] * (long double)p->weight_all[0][(size_t)i * nsf + k];
+                cm[(size_t)o * nnod + i] = (double)acc;
+            }
+        INIT_TRY(hipMalloc((void **)&h->d_coefmat, sizeof(double) * cm.size()));
+        INIT_TRY(hipMemcpy(h->d_coefmat, cm.data(), sizeof(double) * cm.size(), hipMemcpyHostToDevice));
+        h->bytes += sizeof(double) * cm.size();
     }
     if (p->descriptor == ANNP_HIP_DESC_BEHLER) {
         h->sym_rad.assign(p->cofsymrad, p->cofsymrad + 3 * p->npsf);

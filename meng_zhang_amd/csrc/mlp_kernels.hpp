@@ -15,12 +15,14 @@
 // of M-tile t is k-step 4t+r.  Activations are applied in place and no data
 // ever moves between lanes or through LDS between layers.
 //
-// The epilogue turns dE/dG into what the force pass consumes
-// (fe_kernels.hpp / ni_kernels.hpp) and writes per-atom energies.  For the Chebyshev
-// descriptor that is the angular polynomial of the atom, P(z) = sum_n c_n T_n((z+1)/2),
-// re-expanded in powers of z = cos(theta) (exact dyadic conversion matrix; the
-// monomial form is well conditioned on [-1,1] here: |p_k| <= ~120 max|c_n|), so the
-// force pass evaluates P and dP/dz by Horner instead of running a recurrence.
+// What the force pass consumes (fe_kernels.hpp / ni_kernels.hpp) is a fixed linear image
+// of dE/dG: c_k = cmul_k dE/dGhat_k for Ni; for the Chebyshev descriptor the radial c_m
+// plus the atom's angular polynomial P(z) = sum_n c_n T_n((z+1)/2) re-expanded in powers
+// of z = cos(theta) (exact dyadic conversion matrix; the monomial form is well conditioned
+// on [-1,1] here: |p_k| <= ~120 max|c_n|) and its derivative, so that the force pass
+// evaluates P and dP/dz by Horner instead of running a recurrence.  That image is folded
+// into the last product of the reverse sweep: coef = (T diag(cmul) W_0^T) . delta_0, one
+// more MFMA chain with a host-precomputed 48 x nnod matrix -- no epilogue arithmetic.
 #pragma once
 #include "annp_common.hpp"
 
@@ -39,12 +41,9 @@ struct MlpArgs {
     const double *W[MLP_MAXL];    // device, row-major [d_{l+1}][d_l]
     const double *B[MLP_MAXL];
     const double *nmul, *nsub, *nden;   // [ANNP_GPAD] normalisation: Ghat = (raw*nmul - nsub)/nden
-    const double *cmul;                 // [ANNP_GPAD] c_k = cmul_k dE/dGhat_k
+    const double *coefmat;              // [ANNP_CPAD][nnod] row-major: coef = coefmat . dE/dZ_0
     double e_scale, e_shift, e_atom;
     int energy_raw;               // ni: E_i = network output (ni:858-860)
-    int mode;                     // 0: Chebyshev epilogue (np radial, nt angular)   1: plain c_k
-    int np, nt;
-    const double *cheb2mono;      // mode 0: [nt][nt], row k = coefficients of z^k in T_n((z+1)/2), n = 0..nt-1
     const double *G;              // [inum][ANNP_GPAD]
     double *coef;                 // [inum][ANNP_CPAD]
     double *eatom;                // nullable, indexed by atom
@@ -71,7 +70,7 @@ __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c)
 template <int KS0, int MT, int NL>
 struct MlpSlots {
     static constexpr int KSH = 4 * MT;                      // k-steps over a hidden layer
-    static constexpr int MT0 = (KS0 * 4 + 15) / 16;         // M-tiles over the input features
+    static constexpr int MT0 = ANNP_CPAD / 16;              // M-tiles over the rows of coef
     static constexpr int fwd0 = 0;                          // MT*KS0
     static constexpr int fwdh = fwd0 + MT * KS0;            // (NL-2) * MT*KSH
     static constexpr int fwdo = fwdh + (NL - 2) * MT * KSH; // KSH
@@ -89,8 +88,8 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
     constexpr int KSH = S::KSH, MT0 = S::MT0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *opnd = reinterpret_cast<double *>(lds_raw);                 // [S::total][64]
-    double *cbuf_all = opnd + (size_t)S::total * 64;                    // [4 waves][16][32]
-    double *m2m = cbuf_all + (size_t)ANNP_WAVES_PER_BLOCK * 16 * 32;    // [nt][nt] Chebyshev -> monomial (mode 0)
+    double *cbuf_all = opnd + (size_t)S::total * 64;                    // [4 waves][16][ANNP_CPAD]
+
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -121,11 +120,11 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
             const int l = (NL - 2) - q / (MT * KSH), mt = (q / KSH) % MT, s = q % KSH;
             const int r = 4 * s + lq, c = 16 * mt + lr;
             if (r < nnod && c < nnod) v = p.W[l][r * nnod + c];
-        } else if (slot < S::bias) {                            // bwd layer 0: W0[4s+lq][16mt+lr]
+        } else if (slot < S::bias) {                            // coef rows: coefmat[16mt+lr][4s+lq]
             const int q = slot - S::bwd0;
             const int mt = q / KSH, s = q % KSH;
-            const int r = 4 * s + lq, c = 16 * mt + lr;
-            if (r < nnod && c < nsf) v = p.W[0][r * nsf + c];
+            const int r = 16 * mt + lr, c = 4 * s + lq;
+            if (r < ANNP_CPAD && c < nnod) v = p.coefmat[r * nnod + c];
         } else {                                                // bias in C layout: row 16mt+lq+4r
             const int q = slot - S::bias;
             const int l = q / (MT * 4), mt = (q / 4) % MT, r = q % 4;
@@ -135,10 +134,8 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
         }
         opnd[(size_t)slot * 64 + lane] = v;
     }
-    if (p.mode == 0)
-        for (int k = threadIdx.x; k < p.nt * p.nt; k += blockDim.x) m2m[k] = p.cheb2mono[k];
     __syncthreads();
-    double *cbuf = cbuf_all + (size_t)wave * 16 * 32;
+    double *cbuf = cbuf_all + (size_t)wave * 16 * ANNP_CPAD;
 
     double e_wave = 0.0;
     const int ntiles = (p.inum + 15) / 16;
@@ -231,7 +228,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) dl[mt] = nx[mt];
         }
-        // dE/dGhat[k = 16mt+lq+4r][atom] -> c_k -> LDS [atom][32]
+        // coef[k = 16mt+lq+4r][atom] = coefmat . delta_0  -> LDS [atom][48] -> coalesced rows
 #pragma unroll
         for (int mt = 0; mt < MT0; mt++) {
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -239,35 +236,13 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
             for (int s = 0; s < KSH; s++)
                 acc = mfma_f64(opnd[(size_t)(S::bwd0 + mt * KSH + s) * 64 + lane], dl[s / 4][s % 4], acc);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int k = 16 * mt + lq + 4 * r;
-                if (k < ANNP_GPAD) cbuf[lr * 32 + k] = (k < nsf) ? acc[r] * p.cmul[k] : 0.0;
-            }
+            for (int r = 0; r < 4; r++) cbuf[lr * ANNP_CPAD + 16 * mt + lq + 4 * r] = acc[r];
         }
         wave_lds_sync();
-        // ---- epilogue: what the force pass reads
-        const int np = p.np, nt = p.nt;
-        for (int idx = lane; idx < 16 * ANNP_CPAD; idx += 64) {
-            const int at = idx / ANNP_CPAD, o = idx % ANNP_CPAD;
-            const int ia2 = tile * 16 + at;
-            if (ia2 >= p.inum) continue;
-            const double *c = cbuf + at * 32;
-            double v = 0.0;
-            if (p.mode == 1) {
-                if (o < nsf) v = c[o];
-            } else if (o < np) {
-                v = c[o];
-            } else if (o < np + nt) {                 // p_k: P(z) = sum_n c_n T_n((z+1)/2) = sum_k p_k z^k
-                const int k = o - np;
-                const double *row = m2m + k * nt;
-                for (int m = k; m < nt; m++) v = fma(row[m], c[np + m], v);      // T_n has no z^k for n < k
-            } else if (o < np + 2 * nt - 1) {         // d_k = (k+1) p_{k+1}:  dP/dz
-                const int k = o - np - nt;
-                const double *row = m2m + (k + 1) * nt;
-                for (int m = k + 1; m < nt; m++) v = fma(row[m], c[np + m], v);
-                v *= (double)(k + 1);
-            }
-            p.coef[(size_t)ia2 * ANNP_CPAD + o] = v;
+        {
+            const int nrow = min(16, p.inum - tile * 16);
+            double *dst = p.coef + (size_t)tile * 16 * ANNP_CPAD;
+            for (int idx = lane; idx < nrow * ANNP_CPAD; idx += 64) dst[idx] = cbuf[idx];
         }
         wave_lds_sync();
     }
@@ -280,7 +255,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
 template <int KS0, int MT, int NL>
 inline size_t mlp_lds_bytes()
 {
-    return ((size_t)MlpSlots<KS0, MT, NL>::total * 64 + (size_t)ANNP_WAVES_PER_BLOCK * 16 * 32 + 32 * 32) * sizeof(double);
+    return ((size_t)MlpSlots<KS0, MT, NL>::total * 64 + (size_t)ANNP_WAVES_PER_BLOCK * 16 * ANNP_CPAD) * sizeof(double);
 }
 
 }  // namespace annp
