@@ -504,9 +504,13 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
         const double g1 = fma(t, E0.y, -q[1] * rinv);
         const double g2 = fma(t, E1.x, -q[2] * rinv);
         const int j = auxJ[a];
+#if ANNP_VARIANT != 4
         atomicAdd(&p.f[3 * (size_t)j], -g0);
         atomicAdd(&p.f[3 * (size_t)j + 1], -g1);
         atomicAdd(&p.f[3 * (size_t)j + 2], -g2);
+#else
+        asm volatile("" ::"v"(j));
+#endif
         fi0 += g0; fi1 += g1; fi2 += g2;
         if (VIRIAL) {   // ev_tally_xyz(i,j,...,fx=-Fj, del = xi-xj = r e)   (fe:201-209)
             const double r = 1.0 / rinv;

@@ -1,0 +1,85 @@
+"""Device-resident entry points (annp_hip_neigh_build_device / annp_hip_compute_device) and the
+single-rank halo machinery that bench.py uses, checked against the oracle on a real MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from annp_testlib import (A_FE, A_NI, FAST, FE_POT, KIND_FE, KIND_NI_FIXED, NI_POT, System, bcc, fcc, oracle_compute,
+                          perturb)
+
+pytestmark = pytest.mark.gpu
+RC_LIST = 8.5
+
+
+class _NoDist:
+    P2POp = None
+
+    @staticmethod
+    def batch_isend_irecv(ops):
+        return []
+
+
+def device_eval(potfile, elem, x0, xg, box, want_virial=False):
+    import torch
+    from meng_zhang_amd import PairANNP
+    from meng_zhang_amd.domain import Domain, HaloPlan
+    from meng_zhang_amd.lib import load_library
+    lib = load_library()
+    dev = torch.device("cuda", 0)
+    plan = HaloPlan(x0, box, (1, 1, 1), RC_LIST, 1, 0)
+    dom = Domain(plan, x0, dev, _NoDist())
+    dom.x[: plan.nlocal] = torch.from_numpy(xg).to(dev)      # owned atoms move ...
+    dom.forward()                                            # ... their periodic images follow
+    pair = PairANNP(1, device=0)
+    pair.settings([])
+    pair.coeff(["*", "*", potfile, elem])
+    pair.init_style()
+    h = pair.handle
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    p_num, p_first, p_neigh, mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    assert lib.annp_hip_neigh_build_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), RC_LIST, C.byref(p_num),
+                                           C.byref(p_first), C.byref(p_neigh), C.byref(mx), stream) == 0
+    eng = torch.zeros(1, dtype=torch.float64, device=dev)
+    eatom = torch.zeros(plan.nall, dtype=torch.float64, device=dev)
+    vir = torch.zeros(6, dtype=torch.float64, device=dev)
+    rc = lib.annp_hip_compute_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), None, None, p_num, p_first, p_neigh,
+                                     mx.value, dom.f.data_ptr(), eatom.data_ptr(), eng.data_ptr(),
+                                     vir.data_ptr() if want_virial else None, stream)
+    assert rc == 0, lib.annp_hip_last_error(h)
+    assert lib.annp_hip_sync(h) == 0
+    dom.reverse()
+    counts = np.zeros(plan.nlocal, dtype=np.int32)
+    assert lib.annp_hip_last_counts(h, counts.ctypes.data_as(C.POINTER(C.c_int)), plan.nlocal) == 0
+    out = dict(f=dom.f[: plan.nlocal].cpu().numpy(), eatom=eatom[: plan.nlocal].cpu().numpy(), energy=float(eng.item()),
+               virial=vir.cpu().numpy(), counts=counts, max_numneigh=mx.value, nghost=plan.nghost)
+    pair.close()
+    return out
+
+
+def test_fe_device_path_16k(fe_pot):
+    x0, box = bcc(20, 20, 20, A_FE)
+    xg = perturb(x0, 2024, 0.05)
+    r = device_eval(FE_POT, "Fe", x0, xg, box, want_virial=True)
+    s = System(xg, box)
+    o = oracle_compute(fe_pot, s, KIND_FE, FAST, want_virial=True)
+    assert r["nghost"] == s.nghost and r["max_numneigh"] == s.numneigh.max()
+    assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6
+    assert np.abs(r["f"] - o["f"]).max() < 1e-5
+    assert np.abs(r["f"] - o["f"]).max() < 1e-9
+    assert abs(r["energy"] - o["energy"]) < 1e-6 * s.nlocal
+    assert np.allclose(r["virial"], o["virial"], rtol=1e-9, atol=1e-6)
+    assert r["counts"].min() >= 100 and r["counts"].max() <= 124        # 112 in a perfect lattice
+
+
+def test_ni_device_path_512k(ni_pot):
+    """BASELINE config 4: fcc Ni, 40 x 40 x 80 cells x 4 = 512 000 atoms, second element / net width."""
+    x0, box = fcc(40, 40, 80, A_NI)
+    xg = perturb(x0, 31337, 0.05)
+    r = device_eval(NI_POT, "Ni", x0, xg, box)
+    s = System(xg, box)
+    assert s.nlocal == 512000
+    o = oracle_compute(ni_pot, s, KIND_NI_FIXED, FAST)
+    assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6
+    assert np.abs(r["f"] - o["f"]).max() < 1e-5
+    assert abs(r["energy"] - o["energy"]) < 1e-6 * s.nlocal

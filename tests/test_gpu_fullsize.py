@@ -1,0 +1,127 @@
+"""BASELINE.json's full size (1 024 000-atom bcc-Fe box) on the GPU: properties that do not
+need an oracle run of the whole box, plus an oracle check on a sample of its atoms."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from annp_testlib import A_FE, FAST, FE_POT, KIND_FE, _dp, _ip, _lp, bcc, oracle_compute, oracle_lib, perturb, System
+
+pytestmark = pytest.mark.gpu
+RC_LIST = 8.5
+
+
+class _NoDist:
+    P2POp = None
+
+    @staticmethod
+    def batch_isend_irecv(ops):
+        return []
+
+
+@pytest.fixture(scope="module")
+def big():
+    import torch
+    from meng_zhang_amd import PairANNP
+    from meng_zhang_amd.domain import Domain, HaloPlan
+    from meng_zhang_amd.lib import load_library
+    lib = load_library()
+    dev = torch.device("cuda", 0)
+    x0, box = bcc(80, 80, 80, A_FE)
+    xg = perturb(x0, 12345, 0.05)
+    plan = HaloPlan(x0, box, (1, 1, 1), RC_LIST, 1, 0)
+    dom = Domain(plan, xg, dev, _NoDist())
+    pair = PairANNP(1, device=0)
+    pair.settings([])
+    pair.coeff(["*", "*", FE_POT, "Fe"])
+    pair.init_style()
+    h = pair.handle
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    p_num, p_first, p_neigh, mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    assert lib.annp_hip_neigh_build_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), RC_LIST, C.byref(p_num),
+                                           C.byref(p_first), C.byref(p_neigh), C.byref(mx), stream) == 0
+
+    def evaluate():
+        dom.f.zero_()
+        eng = torch.zeros(1, dtype=torch.float64, device=dev)
+        eatom = torch.zeros(plan.nall, dtype=torch.float64, device=dev)
+        rc = lib.annp_hip_compute_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), None, None, p_num, p_first, p_neigh,
+                                         mx.value, dom.f.data_ptr(), eatom.data_ptr(), eng.data_ptr(), None, stream)
+        assert rc == 0, lib.annp_hip_last_error(h)
+        assert lib.annp_hip_sync(h) == 0
+        dom.reverse()
+        return float(eng.item()), dom.f[: plan.nlocal].clone(), eatom[: plan.nlocal].clone()
+
+    yield dict(torch=torch, dom=dom, plan=plan, evaluate=evaluate, xg=xg, box=box, x0=x0)
+    pair.close()
+
+
+def test_momentum_and_energy_scale(big):
+    e, f, eatom = big["evaluate"]()
+    n = big["plan"].nlocal
+    assert n == 1024000
+    assert float(f.sum(0).abs().max()) < 1e-6                    # Newton's third law over 1M atoms
+    assert abs(e - float(eatom.sum())) < 1e-4                    # total = sum of per-atom energies
+    assert abs(e / n - (-4479.8696)) < 1e-3                      # same lattice, same displacements as the 2000-atom box
+
+
+def test_rigid_translation_and_repeatability(big):
+    torch, dom = big["torch"], big["dom"]
+    e0, f0, ea0 = big["evaluate"]()
+    e1, f1, ea1 = big["evaluate"]()
+    assert abs(e1 - e0) < 1e-5 and float((f1 - f0).abs().max()) < 1e-10     # atomics reorder sums only at round-off
+    dom.x += torch.tensor([0.37, -1.21, 2.05], dtype=torch.float64, device=dom.x.device)
+    e2, f2, ea2 = big["evaluate"]()
+    dom.x -= torch.tensor([0.37, -1.21, 2.05], dtype=torch.float64, device=dom.x.device)
+    assert float((ea2 - ea0).abs().max()) < 1e-8
+    assert float((f2 - f0).abs().max()) < 1e-9
+
+
+def test_sample_of_atoms_matches_oracle(big, fe_pot):
+    """per-atom energies of 4096 atoms of the 1M box vs the oracle on the same neighbourhoods"""
+    e, f, eatom = big["evaluate"]()
+    plan, dom = big["plan"], big["dom"]
+    x_all = dom.x.cpu().numpy()
+    m = 4096
+    ol = oracle_lib()
+    s = System.__new__(System)
+    s.nlocal, s.nall, s.nghost = plan.nlocal, plan.nall, plan.nghost
+    s.x = np.ascontiguousarray(x_all)
+    s.type = np.ones(s.nall, dtype=np.int32)
+    s.numneigh = np.zeros(s.nall, dtype=np.int32)
+    tot = ol.harness_neigh(m, s.nall, _dp(s.x), RC_LIST, _ip(s.numneigh), None, None)
+    s.first = np.zeros(s.nall + 1, dtype=np.int64)
+    np.cumsum(s.numneigh, out=s.first[1:])
+    s.neigh = np.empty(int(tot), dtype=np.int32)
+    ol.harness_neigh(m, s.nall, _dp(s.x), RC_LIST, _ip(s.numneigh), _lp(s.first), _ip(s.neigh))
+    s.ilist = np.arange(m, dtype=np.int32)
+    s.inum = m
+    s.owner = np.zeros(s.nghost, dtype=np.int32)
+    o = oracle_compute(fe_pot, s, KIND_FE, FAST, inum=m)
+    assert np.abs(eatom[:m].cpu().numpy() - o["eatom"][:m]).max() < 1e-6
+
+
+def test_nve_energy_conservation(big):
+    """velocity-Verlet, dt = 1 fs, 40 steps from rest: forces are the gradient of the energy the
+    path reports, so E_pot + E_kin stays put (list is valid: atoms move < 0.05 A)."""
+    torch, dom, plan = big["torch"], big["dom"], big["plan"]
+    n = plan.nlocal
+    x_save = dom.x.clone()
+    mass, dt = 55.847, 0.001
+    ftm2v, mvv2e = 1.0 / 1.0364269e-4, 1.0364269e-4
+    dtf = 0.5 * dt * ftm2v / mass
+    v = torch.zeros((n, 3), dtype=torch.float64, device=dom.x.device)
+    e0, f, _ = big["evaluate"]()
+    etot = [e0]
+    for _ in range(40):
+        v += dtf * f
+        dom.x[:n] += dt * v
+        dom.forward()
+        e, f, _ = big["evaluate"]()
+        v += dtf * f
+        etot.append(e + 0.5 * mvv2e * mass * float((v * v).sum()))
+    dom.x.copy_(x_save)
+    etot = np.array(etot)
+    ke_final = etot[-1] - e
+    assert ke_final > 1.0                                        # the lattice did start moving (eV)
+    assert np.abs(etot - etot[0]).max() < 2e-4 * ke_final + 1e-3  # drift far below the kinetic energy exchanged
