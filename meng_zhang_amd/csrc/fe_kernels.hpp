@@ -33,7 +33,7 @@
 namespace annp {
 
 constexpr int FE_Q = 4;       // chunks per tournament row
-constexpr int FE_DUMP = 16;   // dump slots behind the records: where masked-off pair steps scatter to
+constexpr int FE_DUMP = 8;    // null / dump slots behind the records: where masked-off pair steps read and scatter
 
 struct FeArgs {
     int inum;
@@ -54,15 +54,25 @@ struct FeArgs {
     int *errflag;              // device int: max n seen when n > n_cap
 };
 
-// bytes of LDS one wave needs
+// LDS layout of one wave.  A record is two 16-byte halves (e_x,e_y) and (e_z,fc), kept in two
+// parallel arrays recA[slot], recB[slot] so that the 64 lanes of a ds_read_b128 touch 64
+// consecutive 16-byte slots (an interleaved 32-byte struct costs a 2-way bank conflict per read,
+// and the LDS pipe is the second-busiest unit of the force pass).  Slots:
+//   [0,n)            the in-cutoff neighbours
+//   [n,n+L)          copies of records 0..L-1, so a run of L consecutive partners never wraps
+//   [NZ,NZ+FE_DUMP)  null records (fc = 0); NZ = n_cap + fe_lcap(n_cap)
+// The force pass keeps 5 accumulators (40 B) per record slot in a parallel array.
+__host__ __device__ inline int fe_lcap(int n_cap) { return n_cap / 8 + 1; }       // >= ceil(floor(n/2)/FE_Q)
+__host__ __device__ inline int fe_slots(int n_cap) { return n_cap + fe_lcap(n_cap) + FE_DUMP; }
 __host__ __device__ inline size_t fe_desc_lds_per_wave(int n_cap)
 {
-    size_t rec = (size_t)(n_cap + 1) * 32;
+    size_t rec = (size_t)fe_slots(n_cap) * 32;      // multiple of 16: every wave's base stays b128-aligned
     return rec < 4096 + 512 ? 4096 + 512 : rec;     // reduction scratch [8][64] + [64] results
 }
 __host__ __device__ inline size_t fe_force_lds_per_wave(int n_cap)
 {
-    return (size_t)(n_cap + FE_DUMP) * (32 + 40 + 24 + 8);   // records, accumulators, (1/r, fc', R), index (padded)
+    const size_t b = (size_t)fe_slots(n_cap) * (32 + 40) + (size_t)n_cap * (24 + 8);   // + (1/r, fc', R), index (padded)
+    return (b + 15) & ~(size_t)15;                  // every wave's base stays b128-aligned
 }
 
 // ---- stage A, first sweep: candidates -> compacted raw entries (dx,dy | dz,r^2) [+ index]
@@ -137,12 +147,12 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
     const int wave = uniform(threadIdx.x >> 6);
     const int ii = uniform(blockIdx.x * ANNP_WAVES_PER_BLOCK + wave);
     if (ii >= p.inum) return;
-    const int n1 = p.n_cap + 1;
     unsigned char *wbase = lds_raw + (size_t)wave * fe_desc_lds_per_wave(p.n_cap);
-    double2 *recA = reinterpret_cast<double2 *>(wbase);          // e.x e.y
-    double2 *recB = recA + n1;                                    // e.z fc
+    double2 *recA = reinterpret_cast<double2 *>(wbase);
+    double2 *recB = recA + fe_slots(p.n_cap);
     double *scratch = reinterpret_cast<double *>(wbase);          // reused after the pair loop: [8][64]
     double *red = scratch + 8 * 64;                               // [64] reduced sums
+    const int NZ = p.n_cap + fe_lcap(p.n_cap);                    // first null record
 
     const int i = p.ilist ? p.ilist[ii] : ii;
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
@@ -156,6 +166,8 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
         return;
     }
     wave_lds_sync();
+    const int H = n >> 1;
+    const int L = (H + FE_Q - 1) / FE_Q;
 
     // ---- stage A, second sweep: geometry, radial sums, and the three neighbour sums that
     //      give the T_0 and T_1 angular functions in closed form:
@@ -167,8 +179,9 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
     double s1 = 0.0, s2 = 0.0, vx = 0.0, vy = 0.0, vz = 0.0;
     for (int a = lane; a < n; a += 64) {
         const FeNbr g = fe_geometry(recA[a], recB[a], pi_over_rc);
-        recA[a] = make_double2(g.ex, g.ey);
-        recB[a] = make_double2(g.ez, g.fc);
+        const double2 RA = make_double2(g.ex, g.ey), RB = make_double2(g.ez, g.fc);
+        recA[a] = RA; recB[a] = RB;
+        if (a < L) { recA[n + a] = RA; recB[n + a] = RB; }         // wrap-free copy
         s1 += g.fc; s2 = fma(g.fc, g.fc, s2);
         vx = fma(g.fc, g.ex, vx); vy = fma(g.fc, g.ey, vy); vz = fma(g.fc, g.ez, vz);
         const double xr = g.r * two_over_rcp - 1.0;        // fe:643
@@ -183,9 +196,9 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
             tm2 = tm1; tm1 = t;
         }
     }
-    if (lane == 0) {                        // null record: zero weight
-        recA[p.n_cap] = make_double2(0.0, 0.0);
-        recB[p.n_cap] = make_double2(0.0, 0.0);
+    if (lane < FE_DUMP) {                   // null records: zero weight
+        recA[NZ + lane] = make_double2(0.0, 0.0);
+        recB[NZ + lane] = make_double2(0.0, 0.0);
     }
     wave_lds_sync();
 
@@ -193,8 +206,6 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
     double ga[NT];
 #pragma unroll
     for (int m = 0; m < NT; m++) ga[m] = 0.0;
-    const int H = n >> 1;
-    const int L = (H + FE_Q - 1) / FE_Q;
     const int nitems = n * FE_Q;
     const bool even = (n & 1) == 0;
     FeItem it;
@@ -205,12 +216,13 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
         int t1 = min(H, t0 + L - 1);
         if (even && it.a >= H && t1 == H) t1 = H - 1;
         const int smax = act ? (t1 - t0) : -1;
-        const int ar = act ? it.a : p.n_cap;          // idle lanes carry the null record: zero weight
+        const int ar = act ? it.a : NZ;               // idle lanes carry a null record: zero weight
         const double2 A0 = recA[ar], A1 = recB[ar];
-        const int inc = act ? 1 : 0;
         int b = it.a + t0;
         if (b >= n) b -= n;
-        if (!act) b = p.n_cap;
+        if (!act) b = NZ + (lane & (FE_DUMP - 1));
+        const double2 *pA = recA + b, *pB = recB + b;   // partner run b, b+1, .. never wraps (copies behind n)
+        const int inc = act ? 1 : 0;
         const int Lm = fe_round_min_steps(it.q, H, L, even);   // steps every lane may take unchecked
 
         auto step = [&](const double2 B0, const double2 B1) {
@@ -229,20 +241,21 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
         };
         int s = 0;
         if (Lm > 0) {
-            double2 B0 = recA[b], B1 = recB[b];
-            for (; s < Lm; ++s) {
-                b += inc;
-                if (b == n) b = 0;
-                const double2 N0 = recA[b], N1 = recB[b];      // prefetch
+            double2 B0 = *pA, B1 = *pB;
+            for (; s + 1 < Lm; s += 2) {               // two steps per trip, records ping-pong B <-> N
+                pA += inc; pB += inc;
+                const double2 N0 = *pA, N1 = *pB;
                 step(B0, B1);
-                B0 = N0; B1 = N1;
+                pA += inc; pB += inc;
+                B0 = *pA; B1 = *pB;
+                step(N0, N1);
             }
+            if (s < Lm) { step(B0, B1); pA += inc; pB += inc; ++s; }
         }
         for (; s < L; ++s) {                       // ragged tail of the round (at most a few steps)
-            const int bi = (s <= smax) ? b : p.n_cap;
-            step(recA[bi], recB[bi]);
-            b += inc;
-            if (b == n) b = 0;
+            const bool ok = s <= smax;
+            step(ok ? *pA : recA[NZ], ok ? *pB : recB[NZ]);
+            pA += inc; pB += inc;
         }
         it.next(n);
     }
@@ -271,14 +284,14 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
         {
             const int k = lane >> 3, part = lane & 7;
             const double *src = scratch + k * 64 + part * 8;
-            double s = 0.0;
+            double sm = 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; u++) s += src[u];
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
+            for (int u = 0; u < 8; u++) sm += src[u];
+            sm += __shfl_xor(sm, 1, 64);
+            sm += __shfl_xor(sm, 2, 64);
+            sm += __shfl_xor(sm, 4, 64);
             const int m = c8 * 8 + k;
-            if (part == 0 && m < NS) red[m] = s;
+            if (part == 0 && m < NS) red[m] = sm;
         }
         wave_lds_sync();
     }
@@ -303,14 +316,15 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
 //   coef[ii]: [0,NP)            c_m                 radial weights
 //             [NP, NP+NT)       p_0..p_{NT-1}       P(z) = sum_n c_{NP+n} T_n((z+1)/2) = sum_k p_k z^k
 //             [NP+NT, NP+2NT-1) d_0..d_{NT-2}       dP/dz = sum_k d_k z^k
-//   with z = cos(theta_jik); written by the network pass (mlp_kernels.hpp epilogue)
+//   with z = cos(theta_jik); written by the network pass (mlp_kernels.hpp)
 //
 //   per pair (a,b):  alpha = dP/dz fc_a fc_b
 //     d/dx_a :  alpha (-e_b + z e_a)/r_a  - P fc'_a fc_b e_a          (fe:683 with fe:618-628)
 //   so with V_a = sum_b alpha e_b, C_a = sum_b alpha z, S_a = sum_b P fc_b:
 //     Fn_a = (-V_a + C_a e_a)/r_a - (S_a fc'_a + R_a) e_a,   R_a = radial dE/dr   (fe:648)
 //   The lane that evaluates the pair adds the a-side in registers and scatters the b-side
-//   (5 doubles) with LDS atomics.
+//   (5 doubles) with LDS atomics into the accumulator slot that parallels the record slot
+//   (copies behind n have their own accumulators, folded back at the end).
 // ---------------------------------------------------------------------------------
 template <int NP, int NT, bool VIRIAL>
 __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
@@ -320,19 +334,19 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     const int wave = uniform(threadIdx.x >> 6);
     const int ii = uniform(blockIdx.x * ANNP_WAVES_PER_BLOCK + wave);
     if (ii >= p.inum) return;
-    const int n1 = p.n_cap + FE_DUMP;
+    const int nslot = fe_slots(p.n_cap);
+    const int NZ = p.n_cap + fe_lcap(p.n_cap);
     unsigned char *wbase = lds_raw + (size_t)wave * fe_force_lds_per_wave(p.n_cap);
-    double2 *recA = reinterpret_cast<double2 *>(wbase);          // e.x e.y
-    double2 *recB = recA + n1;                                    // e.z fc
-    // per-neighbour accumulators, 5 doubles each (stride 40 B: the 16 lanes of an LDS pass
-    // land on 16 distinct even banks, so 64-bit atomics of consecutive b stay conflict-free
-    // and the five adds of a step share one address register):
+    double2 *recA = reinterpret_cast<double2 *>(wbase);
+    double2 *recB = recA + nslot;
+    // 5 accumulators per slot (stride 40 B: the 16 lanes of an LDS pass land on 16 distinct even
+    // banks, so 64-bit atomics of consecutive b stay conflict-free and share one address register):
     //   [0..2] V = sum alpha e_b   [3] S = sum P fc_b   [4] C = sum alpha cos
-    double *acc = reinterpret_cast<double *>(recB + n1);
-    double *auxRinv = acc + 5 * n1;
-    double *auxDfc = auxRinv + n1;
-    double *auxR = auxDfc + n1;                                   // radial dE/dr
-    int *auxJ = reinterpret_cast<int *>(auxR + n1);
+    double *acc = reinterpret_cast<double *>(recB + nslot);
+    double *auxRinv = acc + 5 * (size_t)nslot;
+    double *auxDfc = auxRinv + p.n_cap;
+    double *auxR = auxDfc + p.n_cap;                              // radial dE/dr
+    int *auxJ = reinterpret_cast<int *>(auxR + p.n_cap);
 
     const int i = p.ilist ? p.ilist[ii] : ii;
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
@@ -345,14 +359,17 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
         return;
     }
     wave_lds_sync();
+    const int H = n >> 1;
+    const int L = (H + FE_Q - 1) / FE_Q;
     {
         double cr[NP];
 #pragma unroll
         for (int m = 0; m < NP; m++) cr[m] = cf[m];
         for (int a = lane; a < n; a += 64) {
             const FeNbr g = fe_geometry(recA[a], recB[a], pi_over_rc);
-            recA[a] = make_double2(g.ex, g.ey);
-            recB[a] = make_double2(g.ez, g.fc);
+            const double2 RA = make_double2(g.ex, g.ey), RB = make_double2(g.ez, g.fc);
+            recA[a] = RA; recB[a] = RB;
+            if (a < L) { recA[n + a] = RA; recB[n + a] = RB; }
             // radial: R = sum_m c_m (T'_m 2/Rc fc + T_m fc')    (fe:648)
             const double xr = g.r * two_over_rcp - 1.0;
             const double y2 = 2.0 * xr;
@@ -370,16 +387,14 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
             auxR[a] = fma(sd * two_over_rcp, g.fc, st * g.dfc);
             auxRinv[a] = g.rinv;
             auxDfc[a] = g.dfc;
-            double *q = acc + 5 * a;
-            q[0] = 0.0; q[1] = 0.0; q[2] = 0.0; q[3] = 0.0; q[4] = 0.0;
         }
     }
+    for (int k = lane; k < 5 * (n + L); k += 64) acc[k] = 0.0;
     if (lane < FE_DUMP) {
-        const int d = p.n_cap + lane;
-        recA[d] = make_double2(0.0, 0.0);
-        recB[d] = make_double2(0.0, 0.0);
-        double *q = acc + 5 * d;
-        q[0] = 0.0; q[1] = 0.0; q[2] = 0.0; q[3] = 0.0; q[4] = 0.0;
+        recA[NZ + lane] = make_double2(0.0, 0.0);
+        recB[NZ + lane] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[5 * (NZ + lane) + k] = 0.0;
     }
     wave_lds_sync();
 
@@ -394,11 +409,9 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     double ce_top = ce[NT - 1], cd_top = cd[NT - 2];
     asm volatile("" : "+v"(ce_top), "+v"(cd_top));
 
-    const int H = n >> 1;
-    const int L = (H + FE_Q - 1) / FE_Q;
     const int nitems = n * FE_Q;
     const bool even = (n & 1) == 0;
-    const int dump = p.n_cap + (lane & (FE_DUMP - 1));
+    const int dump = NZ + (lane & (FE_DUMP - 1));
     FeItem it;
     it.init(lane, n);
     for (int it0 = 0; it0 < nitems; it0 += 64) {
@@ -407,17 +420,20 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
         int t1 = min(H, t0 + L - 1);
         if (even && it.a >= H && t1 == H) t1 = H - 1;
         const int smax = act ? (t1 - t0) : -1;
-        const int ar = act ? it.a : p.n_cap;          // idle lanes: null record (fc_a = 0 -> they scatter zeros)
+        const int ar = act ? it.a : dump;             // idle lanes: null record (fc_a = 0 -> they scatter zeros)
         const double2 A0 = recA[ar], A1 = recB[ar];
         double va0 = 0.0, va1 = 0.0, va2 = 0.0, sa = 0.0, ca = 0.0;
-        const int inc = act ? 1 : 0;
         int b = it.a + t0;
         if (b >= n) b -= n;
-        if (!act) b = p.n_cap;
+        if (!act) b = dump;
+        // the run b, b+1, .. never wraps: records and accumulators have copies behind n
+        const double2 *pA = recA + b, *pB = recB + b;
+        double *qb = acc + 5 * b;
+        const int incr = act ? 1 : 0, inca = act ? 5 : 0;
         const int Lm = fe_round_min_steps(it.q, H, L, even);
 
-        // one pair: evaluate, keep the a-side, scatter the b-side to slot bt
-        auto step = [&](const double2 B0, const double2 B1, const int bt) {
+        // one pair: evaluate, keep the a-side, scatter the b-side to accumulator slot q
+        auto step = [&](const double2 B0, const double2 B1, double *q) {
             const double c = fma(A1.x, B1.x, fma(A0.y, B0.y, A0.x * B0.x));
             // P(z) and dP/dz by Horner, z = cos(theta)
             double P = ce_top;
@@ -434,54 +450,47 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
             sa = fma(P, B1.y, sa);
             ca += alc;
 #if ANNP_VARIANT != 3
-            double *q = acc + 5 * bt;
             atomicAdd(q + 0, al * A0.x);
             atomicAdd(q + 1, al * A0.y);
             atomicAdd(q + 2, al * A1.x);
             atomicAdd(q + 3, P * A1.y);
             atomicAdd(q + 4, alc);
 #else
-            asm volatile("" ::"v"(al * A0.x), "v"(al * A0.y), "v"(al * A1.x), "v"(P * A1.y), "v"(bt));
+            asm volatile("" ::"v"(al * A0.x), "v"(al * A0.y), "v"(al * A1.x), "v"(P * A1.y), "v"(q));
 #endif
         };
 
         int s = 0;
         if (Lm > 0) {
-            double2 B0 = recA[b], B1 = recB[b];
+            double2 B0 = *pA, B1 = *pB;
             // land the first record before the loop: inside it only the prefetch and the
             // (result-less) atomics are in flight, so the loop needs one counted wait per step
             asm volatile("" : "+v"(B0.x), "+v"(B0.y), "+v"(B1.x), "+v"(B1.y));
             for (; s + 1 < Lm; s += 2) {                   // two steps per trip: records ping-pong B <-> N
-                const int bt0 = act ? b : dump;
-                b += inc;
-                if (b == n) b = 0;
-                const double2 N0 = recA[b], N1 = recB[b];      // prefetch, issued first
+                pA += incr; pB += incr;
+                const double2 N0 = *pA, N1 = *pB;              // prefetch, issued first
                 __builtin_amdgcn_sched_barrier(0);
-                step(B0, B1, bt0);
-                const int bt1 = act ? b : dump;
-                b += inc;
-                if (b == n) b = 0;
-                B0 = recA[b]; B1 = recB[b];
+                step(B0, B1, qb);
+                qb += inca;
+                pA += incr; pB += incr;
+                B0 = *pA; B1 = *pB;
                 __builtin_amdgcn_sched_barrier(0);
-                step(N0, N1, bt1);
+                step(N0, N1, qb);
+                qb += inca;
             }
             if (s < Lm) {                                  // odd count: one more, record already here
-                const int bt = act ? b : dump;
-                b += inc;
-                if (b == n) b = 0;
-                step(B0, B1, bt);
+                step(B0, B1, qb);
+                qb += inca; pA += incr; pB += incr;
                 ++s;
             }
         }
         for (; s < L; ++s) {                       // ragged tail of the round
             const bool ok = s <= smax;
-            const int bi = ok ? b : p.n_cap;
-            step(recA[bi], recB[bi], ok ? b : dump);
-            b += inc;
-            if (b == n) b = 0;
+            step(ok ? *pA : recA[NZ], ok ? *pB : recB[NZ], ok ? qb : acc + 5 * dump);
+            pA += incr; pB += incr; qb += inca;
         }
         {
-            double *q = acc + 5 * (act ? ar : dump);
+            double *q = acc + 5 * ar;
             atomicAdd(q + 0, va0);
             atomicAdd(q + 1, va1);
             atomicAdd(q + 2, va2);
@@ -490,6 +499,9 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
         }
         it.next(n);
     }
+    wave_lds_sync();
+    // fold the accumulators of the copies back onto their originals
+    for (int k = lane; k < 5 * L; k += 64) acc[k] += acc[5 * n + k];
     wave_lds_sync();
 
     // ---- finalize: Fn_a = sum_n c_n dG_n/dx_a ; F_a = -Fn_a to neighbour, +Fn_a to centre (fe:190-213)
