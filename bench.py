@@ -196,7 +196,7 @@ def main():
             "peak": PEAK_FP64_VECTOR,
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP64_VECTOR,
-            "traffic": None,
+            "traffic": _pmc_traffic("annp_fe_force", natoms if world == 1 else None),
             "algorithmic_flop_per_launch": flop_force,
             "descriptor_pass": {"achieved": flop_desc / (desc_ms * 1e-3) / 1e12, "frac": flop_desc / (desc_ms * 1e-3) / 1e12 / PEAK_FP64_VECTOR},
             "hbm": {"achieved_GBps": nlocal * BYTES_ATOM_STEP / (float(ms4[3]) * 1e-3) / 1e9, "peak_GBps": PEAK_HBM,
@@ -223,6 +223,26 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _pmc_traffic(kernel, natoms):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r*_pmc_counters.json: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, i.e. the upper bound).  None when no matching profile exists:
+    the counters cannot be read from inside an un-profiled run."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json"))):
+        try:
+            d = json.load(open(f))
+            if natoms is None or str(natoms) not in d.get("workload", ""):
+                continue
+            for k, v in d["per_launch_mean"].items():
+                if kernel in k:
+                    best = v["hbm_bytes_upper"]
+        except Exception:
+            pass
+    return best
 
 
 def _cpu_share():

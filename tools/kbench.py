@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Developer tool: kernel timings (HIP events) of one force evaluation for a synthetic box.
+   python tools/kbench.py fe 80      # bcc Fe, 80^3 cells
+   python tools/kbench.py ni 40 40 80  # fcc Ni 40x40x80 cells (512 000 atoms)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class _NoDist:
+    P2POp = None
+
+    @staticmethod
+    def batch_isend_irecv(ops):
+        return []
+
+
+def main():
+    import torch
+    from annp_testlib import A_FE, A_NI, FE_POT, NI_POT, bcc, fcc, perturb
+    from meng_zhang_amd import PairANNP
+    from meng_zhang_amd.domain import Domain, HaloPlan
+    from meng_zhang_amd.lib import load_library
+    kind = sys.argv[1]
+    dims = [int(v) for v in sys.argv[2:5]]
+    while len(dims) < 3:
+        dims.append(dims[-1])
+    reps = 5
+    if kind == "fe":
+        x0, box = bcc(*dims, A_FE)
+        pot, el = FE_POT, "Fe"
+    else:
+        x0, box = fcc(*dims, A_NI)
+        pot, el = NI_POT, "Ni"
+    xg = perturb(x0, 12345, 0.05)
+    lib = load_library()
+    dev = torch.device("cuda", 0)
+    plan = HaloPlan(x0, box, (1, 1, 1), 8.5, 1, 0)
+    dom = Domain(plan, xg, dev, _NoDist())
+    pair = PairANNP(1, device=0)
+    pair.settings([])
+    pair.coeff(["*", "*", pot, el])
+    pair.init_style()
+    h = pair.handle
+    st = torch.cuda.current_stream(dev).cuda_stream
+    pn, pf, pg, mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    assert lib.annp_hip_neigh_build_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), 8.5, C.byref(pn), C.byref(pf), C.byref(pg), C.byref(mx), st) == 0
+    eng = torch.zeros(1, dtype=torch.float64, device=dev)
+    lib.annp_hip_set_timing(h, 1)
+    for _ in range(reps + 1):
+        dom.f.zero_()
+        eng.zero_()
+        rc = lib.annp_hip_compute_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value, dom.f.data_ptr(), None, eng.data_ptr(), None, st)
+        assert rc == 0, lib.annp_hip_last_error(h)
+    ms = np.zeros(4)
+    ns = C.c_int(0)
+    lib.annp_hip_timing_stats(h, ms.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ns))
+    print("%s atoms=%d ghosts=%d maxnbr=%d  desc %.3f  net %.3f  force %.3f  total %.3f ms  -> %.2f M atom-evals/s  E/atom %.6f" % (
+        kind, plan.nlocal, plan.nghost, mx.value, ms[0], ms[1], ms[2], ms[3], plan.nlocal / ms[3] / 1e3, float(eng.item()) / plan.nlocal))
+
+
+if __name__ == "__main__":
+    main()
