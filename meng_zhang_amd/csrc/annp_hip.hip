@@ -51,7 +51,9 @@ struct annp_hip_handle {
     double *dB[MLP_MAXL] = {nullptr, nullptr, nullptr, nullptr};
     double *d_norm = nullptr;           // nmul | nsub | nden, ANNP_GPAD each
     double *d_coefmat = nullptr;        // [ANNP_CPAD][nnod]: coef = coefmat . dE/dZ_0 (network pass epilogue)
-    double *d_sym = nullptr;            // BEHLER: rad[npsf*3] then ang[ntsf*4]
+    double *d_sym = nullptr;            // BEHLER: function tables (ni_kernels.hpp, "per-function tables")
+    int *d_isym = nullptr;
+    NiShape ni_shape = {0, 0, 0};       // {lambda} x {eta} x {zeta} product shape of the angular set (0 = none)
     std::vector<double> sym_rad, sym_ang;
     // work buffers
     DevBuf<double> G, coef, x, f, eatom;
@@ -210,18 +212,18 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     } else {
         NiArgs a{};
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
-        a.npsf = h->npsf; a.ntsf = h->ntsf; a.sym = h->d_sym; a.compat = h->ni_compat;
+        a.npsf = h->npsf; a.ntsf = h->ntsf; a.sym = h->d_sym; a.isym = h->d_isym; a.compat = h->ni_compat;
         a.rc_rad = h->sym_rad[2]; a.rc_ang = h->sym_ang[3];
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.ncount = h->ncount.p; a.errflag = h->d_flags;
         a.n_cap = NI_NCAP;
-        int rcn = ni_launch_desc(a, blocks, s);
+        int rcn = ni_launch_desc(a, h->ni_shape, blocks, s);
         if (rcn) return fail(h, ANNP_HIP_ESHAPE, "Behler kernels support npsf<=%d ntsf<=%d", NI_MAXP, NI_MAXT);
         HIP_TRY(h, hipGetLastError());
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
         m.act_plain = 1; m.energy_raw = 1;
         if ((rc = run_mlp(h, m, s))) return rc;
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
-        ni_launch_force(a, blocks, d_virial != nullptr, s);
+        ni_launch_force(a, h->ni_shape, blocks, d_virial != nullptr, s);
         HIP_TRY(h, hipGetLastError());
     }
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[3], s)); h->ev_count++; }
@@ -248,6 +250,7 @@ void annp_hip_clear(annp_hip_handle *h)
     for (int l = 0; l < MLP_MAXL; l++) { if (h->dW[l]) (void)hipFree(h->dW[l]); if (h->dB[l]) (void)hipFree(h->dB[l]); }
     if (h->d_norm) (void)hipFree(h->d_norm);
     if (h->d_sym) (void)hipFree(h->d_sym);
+    if (h->d_isym) (void)hipFree(h->d_isym);
     if (h->d_coefmat) (void)hipFree(h->d_coefmat);
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom);
     release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount);
@@ -376,11 +379,70 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (p->descriptor == ANNP_HIP_DESC_BEHLER) {
         h->sym_rad.assign(p->cofsymrad, p->cofsymrad + 3 * p->npsf);
         h->sym_ang.assign(p->cofsymang, p->cofsymang + 4 * p->ntsf);
+        // visit order (lambda, eta, zeta): one squaring ladder per lambda, one exp per pair
+        const int nt = p->ntsf;
+        std::vector<int> perm(nt);
+        for (int m = 0; m < nt; m++) perm[m] = m;
+        const double *ang = p->cofsymang;
+        std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) {
+            if (ang[4 * x + 1] != ang[4 * y + 1]) return ang[4 * x + 1] < ang[4 * y + 1];
+            if (ang[4 * x] != ang[4 * y]) return ang[4 * x] < ang[4 * y];
+            return ang[4 * x + 2] < ang[4 * y + 2];
+        });
+        std::vector<double> etas;
+        std::vector<int> eidx(nt), zint(nt);
+        for (int pos = 0; pos < nt; pos++) {
+            const int m = perm[pos];
+            size_t e = 0;
+            for (; e < etas.size(); e++) if (etas[e] == ang[4 * m]) break;
+            if (e == etas.size()) etas.push_back(ang[4 * m]);
+            eidx[pos] = (int)e;
+            const double z = ang[4 * m + 2];
+            zint[pos] = (z >= 0.0 && z < 32.0 && z == std::floor(z)) ? (int)z : -1;
+            if (zint[pos] < 0) { fail(h, 0, "angular function %d: zeta = %g is not an integer in [0,32)", m, z); return bail(ANNP_HIP_ESHAPE); }
+        }
+        if ((int)etas.size() > NI_MAXE) { fail(h, 0, "more than %d distinct eta values in the angular functions", NI_MAXE); return bail(ANNP_HIP_ESHAPE); }
+        {   // is the set a full product {lambda} x {eta} x {zeta}?  (visit order is then (l*ne + e)*nz + z)
+            std::vector<double> lams, zets;
+            for (int pos = 0; pos < nt; pos++) {
+                const int m = perm[pos];
+                if (std::find(lams.begin(), lams.end(), ang[4 * m + 1]) == lams.end()) lams.push_back(ang[4 * m + 1]);
+                if (std::find(zets.begin(), zets.end(), ang[4 * m + 2]) == zets.end()) zets.push_back(ang[4 * m + 2]);
+            }
+            const int nl_ = (int)lams.size(), ne_ = (int)etas.size(), nz_ = (int)zets.size();
+            bool prod = nl_ * ne_ * nz_ == nt;
+            std::sort(zets.begin(), zets.end());
+            for (int pos = 0; pos < nt && prod; pos++) {
+                const int m = perm[pos];
+                const int l = pos / (ne_ * nz_), e = (pos / nz_) % ne_, z = pos % nz_;
+                prod = ang[4 * m + 1] == lams[l] && ang[4 * m] == etas[e] && ang[4 * m + 2] == zets[z];
+            }
+            h->ni_shape = prod ? NiShape{nl_, ne_, nz_} : NiShape{0, 0, 0};
+        }
+        std::vector<int> emult(NI_MAXE, 0);
+        for (size_t e = 1; e < etas.size(); e++) {
+            const double k = etas[e] / etas[0];
+            const double kr = std::floor(k + 0.5);
+            if (kr >= 1.0 && kr <= 64.0 && std::fabs(kr * etas[0] - etas[e]) <= 4e-16 * std::fabs(etas[e])) emult[e] = (int)kr;
+        }
         std::vector<double> t(h->sym_rad);
         t.insert(t.end(), h->sym_ang.begin(), h->sym_ang.end());
+        for (int pos = 0; pos < nt; pos++) {
+            const int m = perm[pos];
+            t.push_back(ang[4 * m]); t.push_back(ang[4 * m + 1]); t.push_back(ang[4 * m + 2]);
+            t.push_back(std::pow(2.0, 1.0 - ang[4 * m + 2]));                 // term_coe, ni:748
+        }
+        for (int e = 0; e < NI_MAXE; e++) t.push_back(e < (int)etas.size() ? etas[e] : 0.0);
+        std::vector<int> it(perm);
+        it.insert(it.end(), eidx.begin(), eidx.end());
+        it.insert(it.end(), zint.begin(), zint.end());
+        it.push_back((int)etas.size());
+        it.insert(it.end(), emult.begin(), emult.end());
         INIT_TRY(hipMalloc((void **)&h->d_sym, sizeof(double) * t.size()));
         INIT_TRY(hipMemcpy(h->d_sym, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
-        h->bytes += sizeof(double) * t.size();
+        INIT_TRY(hipMalloc((void **)&h->d_isym, sizeof(int) * it.size()));
+        INIT_TRY(hipMemcpy(h->d_isym, it.data(), sizeof(int) * it.size(), hipMemcpyHostToDevice));
+        h->bytes += sizeof(double) * t.size() + sizeof(int) * it.size();
     }
     INIT_TRY(hipMalloc((void **)&h->d_scalars, 8 * sizeof(double)));
     INIT_TRY(hipMalloc((void **)&h->d_flags, 4 * sizeof(int)));
