@@ -108,7 +108,7 @@ def main():
         dom.f.zero_()
         eng.zero_()
         check(lib.annp_hip_compute_device(h, nlocal, nall, dom.x.data_ptr(), None, None, p_num, p_first, p_neigh, mx.value,
-                                          dom.f.data_ptr(), None, eng.data_ptr(), None, stream), "compute_device")
+                                          dom.f.data_ptr(), None, eng.data_ptr(), None, None, stream), "compute_device")
 
     def step():
         xo, fo = dom.x[:nlocal], dom.f[:nlocal]

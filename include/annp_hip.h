@@ -101,7 +101,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *params, int d
  *   eng_vdwl   accumulated when eflag;  eatom [nall] accumulated when eatom_flag (nullable)
  *   virial     6 doubles xx yy zz xy xz yz accumulated when vflag: the ev_tally_xyz
  *              contraction of fe_v2/src/pair_annp.cpp:201-209 (nullable)
- *   vatom      reserved (per-atom virial), must be NULL */
+ *   vatom      atom->vatom[0]: nall*6 doubles accumulated when vatom_flag (nullable): the per-atom
+ *              share of the same tally, half of each pair term to i, half to j (ev_tally_xyz) */
 int annp_hip_compute(annp_hip_handle *handle, int ago, int inum, int nall, int nghost,
                      const double *host_x, const int *host_type,
                      const int *ilist, const int *numj, const int *const *firstneigh,
@@ -123,12 +124,13 @@ int annp_hip_compute_n(annp_hip_handle *handle, int ago, int inum, int nall, int
  *   neighbours of atom i: d_neigh[d_first[i] .. d_first[i]+d_numneigh[i])
  *   d_f [nall*3] accumulated;  d_eatom [nall] accumulated (nullable)
  *   d_eng: 1 double accumulated (nullable);  d_virial: 6 doubles accumulated (nullable)
+ *   d_vatom: [nall*6] accumulated (nullable)
  *   stream: hipStream_t (NULL = default stream).  Asynchronous: returns after enqueue. */
 int annp_hip_compute_device(annp_hip_handle *handle, int inum, int nall,
                             const double *d_x, const int *d_type, const int *d_ilist,
                             const int *d_numneigh, const long long *d_first, const int *d_neigh,
                             int max_numneigh,
-                            double *d_f, double *d_eatom, double *d_eng, double *d_virial,
+                            double *d_f, double *d_eatom, double *d_eng, double *d_virial, double *d_vatom,
                             void *stream);
 
 /* Device neighbour-list build (binned, full list, r^2 <= cutneigh^2) for the

@@ -56,7 +56,7 @@ struct annp_hip_handle {
     NiShape ni_shape = {0, 0, 0};       // {lambda} x {eta} x {zeta} product shape of the angular set (0 = none)
     std::vector<double> sym_rad, sym_ang;
     // work buffers
-    DevBuf<double> G, coef, x, f, eatom;
+    DevBuf<double> G, coef, x, f, eatom, vatom;
     DevBuf<int> type, ilist, numneigh, neigh, ncount;
     DevBuf<long long> first;
     double *d_scalars = nullptr;        // [0] energy, [1..6] virial
@@ -154,7 +154,7 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // ---- one evaluation on device-resident data ----------------------------------------
 int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_x, const int *d_ilist,
                         const int *d_numneigh, const long long *d_first, const int *d_neigh, int max_numneigh,
-                        double *d_f, double *d_eatom, double *d_eng, double *d_virial, hipStream_t s)
+                        double *d_f, double *d_eatom, double *d_eng, double *d_virial, double *d_vatom, hipStream_t s)
 {
     if (inum <= 0) return 0;
     int rc;
@@ -183,7 +183,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         FeArgs a{};
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
         a.cutsq = h->cutsq; a.rc_list = std::sqrt(h->cutsq); a.rc_par = h->cut;
-        a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.ncount = h->ncount.p;
+        a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.vatom = d_vatom; a.ncount = h->ncount.p;
         a.errflag = h->d_flags;
         // pass 1: capacity = list length (upper bound of the in-cutoff count)
         a.n_cap = cap_list;
@@ -206,7 +206,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.n_cap = std::max(16, round_up(h->h_flags[1], 16));
         size_t lds3 = fe_force_lds_per_wave(a.n_cap) * ANNP_WAVES_PER_BLOCK;
         if (lds3 > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "too many in-cutoff neighbours for LDS (%d)", h->h_flags[1]);
-        if (d_virial) hipLaunchKernelGGL((annp_fe_force<9, 19, true>), dim3(blocks), dim3(256), lds3, s, a);
+        if (d_virial || d_vatom) hipLaunchKernelGGL((annp_fe_force<9, 19, true>), dim3(blocks), dim3(256), lds3, s, a);
         else hipLaunchKernelGGL((annp_fe_force<9, 19, false>), dim3(blocks), dim3(256), lds3, s, a);
         HIP_TRY(h, hipGetLastError());
     } else {
@@ -214,7 +214,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
         a.npsf = h->npsf; a.ntsf = h->ntsf; a.sym = h->d_sym; a.isym = h->d_isym; a.compat = h->ni_compat;
         a.rc_rad = h->sym_rad[2]; a.rc_ang = h->sym_ang[3];
-        a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.ncount = h->ncount.p; a.errflag = h->d_flags;
+        a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.vatom = d_vatom; a.ncount = h->ncount.p; a.errflag = h->d_flags;
         a.n_cap = NI_NCAP;
         int rcn = ni_launch_desc(a, h->ni_shape, blocks, s);
         if (rcn) return fail(h, ANNP_HIP_ESHAPE, "Behler kernels support npsf<=%d ntsf<=%d", NI_MAXP, NI_MAXT);
@@ -223,7 +223,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         m.act_plain = 1; m.energy_raw = 1;
         if ((rc = run_mlp(h, m, s))) return rc;
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
-        ni_launch_force(a, h->ni_shape, blocks, d_virial != nullptr, s);
+        ni_launch_force(a, h->ni_shape, blocks, d_virial != nullptr || d_vatom != nullptr, s);
         HIP_TRY(h, hipGetLastError());
     }
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[3], s)); h->ev_count++; }
@@ -252,7 +252,7 @@ void annp_hip_clear(annp_hip_handle *h)
     if (h->d_sym) (void)hipFree(h->d_sym);
     if (h->d_isym) (void)hipFree(h->d_isym);
     if (h->d_coefmat) (void)hipFree(h->d_coefmat);
-    release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom);
+    release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom); release(h, h->vatom);
     release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount);
     release(h, h->first);
     neigh_release(h->nb);
@@ -543,7 +543,7 @@ int annp_hip_compute_device(annp_hip_handle *h, int inum, int nall,
                             const double *d_x, const int *d_type, const int *d_ilist,
                             const int *d_numneigh, const long long *d_first, const int *d_neigh,
                             int max_numneigh,
-                            double *d_f, double *d_eatom, double *d_eng, double *d_virial, void *stream)
+                            double *d_f, double *d_eatom, double *d_eng, double *d_virial, double *d_vatom, void *stream)
 {
     if (!h) return ANNP_HIP_EARG;
     if (inum < 0 || nall < inum || !d_x || !d_f || (inum > 0 && (!d_numneigh || !d_first || !d_neigh)))
@@ -551,7 +551,7 @@ int annp_hip_compute_device(annp_hip_handle *h, int inum, int nall,
     (void)d_type;   // single-element potentials: the type never enters the arithmetic
     HIP_TRY(h, hipSetDevice(h->device));
     return compute_device_impl(h, inum, nall, d_x, d_ilist, d_numneigh, d_first, d_neigh, max_numneigh,
-                               d_f, d_eatom, d_eng, d_virial, (hipStream_t)stream);
+                               d_f, d_eatom, d_eng, d_virial, d_vatom, (hipStream_t)stream);
 }
 
 int annp_hip_neigh_build_device(annp_hip_handle *h, int nlocal, int nall, const double *d_x, double cutneigh,
@@ -574,7 +574,7 @@ int annp_hip_neigh_build_device(annp_hip_handle *h, int nlocal, int nall, const 
 
 // ---- host-pointer entry points --------------------------------------------------------
 static int host_finish(annp_hip_handle *h, int inum, int nall, int eflag, int vflag, int eatom_flag,
-                       double *f, double *eng_vdwl, double *eatom, double *virial,
+                       double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom,
                        std::vector<double> &hf, std::vector<double> &he)
 {
     hipStream_t s = h->stream;
@@ -584,8 +584,14 @@ static int host_finish(annp_hip_handle *h, int inum, int nall, int eflag, int vf
         he.resize((size_t)nall);
         HIP_TRY(h, hipMemcpyAsync(he.data(), h->eatom.p, sizeof(double) * nall, hipMemcpyDeviceToHost, s));
     }
+    std::vector<double> hv;
+    if (vatom) {
+        hv.resize((size_t)nall * 6);
+        HIP_TRY(h, hipMemcpyAsync(hv.data(), h->vatom.p, sizeof(double) * nall * 6, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(h, hipMemcpyAsync(h->h_scalars, h->d_scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    if (vatom) for (size_t k = 0; k < (size_t)nall * 6; k++) vatom[k] += hv[k];
     for (size_t k = 0; k < (size_t)nall * 3; k++) f[k] += hf[k];                  // fe:199,211: += / -=
     if (eflag && eng_vdwl) *eng_vdwl += h->h_scalars[0];                          // fe:185
     if (eflag && eatom_flag && eatom) for (int k = 0; k < nall; k++) eatom[k] += he[k];   // fe:186
@@ -603,7 +609,7 @@ int annp_hip_compute(annp_hip_handle *h, int ago, int inum, int nall, int nghost
     if (!h) return ANNP_HIP_EARG;
     if (inum < 0 || nall < inum || nghost < 0 || !host_x || !f || (inum > 0 && (!ilist || !numj || !firstneigh)))
         return fail(h, ANNP_HIP_EARG, "annp_hip_compute: bad argument");
-    if (vatom_flag || vatom) return fail(h, ANNP_HIP_ESHAPE, "per-atom virial is not implemented");
+    const bool want_vatom = vatom_flag && vatom;
     (void)host_type;
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -645,11 +651,16 @@ int annp_hip_compute(annp_hip_handle *h, int ago, int inum, int nall, int nghost
     HIP_TRY(h, hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), s));
     const bool want_eatom = eflag && eatom_flag && eatom;
     if (want_eatom) HIP_TRY(h, hipMemsetAsync(h->eatom.p, 0, sizeof(double) * (size_t)nall, s));
+    if (want_vatom) {
+        if ((rc = ensure(h, h->vatom, (size_t)nall * 6))) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->vatom.p, 0, sizeof(double) * (size_t)nall * 6, s));
+    }
     rc = compute_device_impl(h, inum, nall, h->x.p, h->ilist.p, h->numneigh.p, h->first.p, h->neigh.p, h->list_max,
-                             h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr, s);
+                             h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr,
+                             want_vatom ? h->vatom.p : nullptr, s);
     if (rc) return rc;
     std::vector<double> hf, he;
-    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, hf, he);
+    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, want_vatom ? vatom : nullptr, hf, he);
 }
 
 int annp_hip_compute_n(annp_hip_handle *h, int ago, int inum, int nall, int nghost,
@@ -661,7 +672,7 @@ int annp_hip_compute_n(annp_hip_handle *h, int ago, int inum, int nall, int ngho
     if (!h) return ANNP_HIP_EARG;
     if (inum < 0 || nall < inum || nghost < 0 || !host_x || !f || cutneigh <= 0)
         return fail(h, ANNP_HIP_EARG, "annp_hip_compute_n: bad argument");
-    if (vatom_flag || vatom) return fail(h, ANNP_HIP_ESHAPE, "per-atom virial is not implemented");
+    const bool want_vatom = vatom_flag && vatom;
     (void)host_type; (void)sublo; (void)subhi;
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -680,11 +691,16 @@ int annp_hip_compute_n(annp_hip_handle *h, int ago, int inum, int nall, int ngho
     HIP_TRY(h, hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), s));
     const bool want_eatom = eflag && eatom_flag && eatom;
     if (want_eatom) HIP_TRY(h, hipMemsetAsync(h->eatom.p, 0, sizeof(double) * (size_t)nall, s));
+    if (want_vatom) {
+        if ((rc = ensure(h, h->vatom, (size_t)nall * 6))) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->vatom.p, 0, sizeof(double) * (size_t)nall * 6, s));
+    }
     rc = compute_device_impl(h, inum, nall, h->x.p, nullptr, h->nb.numneigh, h->nb.first, h->nb.neigh, h->nb.max_numneigh,
-                             h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr, s);
+                             h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr,
+                             want_vatom ? h->vatom.p : nullptr, s);
     if (rc) return rc;
     std::vector<double> hf, he;
-    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, hf, he);
+    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, want_vatom ? vatom : nullptr, hf, he);
 }
 
 }  // extern "C"

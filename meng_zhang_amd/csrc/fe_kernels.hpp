@@ -50,6 +50,7 @@ struct FeArgs {
     const double *coef;        // [inum][ANNP_CPAD] (pass 2 in)
     double *f;                 // [nall][3] accumulated
     double *virial;            // nullable, 6 doubles accumulated
+    double *vatom;             // nullable, [nall][6] accumulated (needs the VIRIAL kernel variant)
     int *ncount;               // nullable [inum]: in-cutoff neighbour count
     int *errflag;              // device int: max n seen when n > n_cap
 };
@@ -527,8 +528,13 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
         if (VIRIAL) {   // ev_tally_xyz(i,j,...,fx=-Fj, del = xi-xj = r e)   (fe:201-209)
             const double r = 1.0 / rinv;
             const double d0 = r * E0.x, d1 = r * E0.y, d2 = r * E1.x;
-            v0 = fma(d0, g0, v0); v1 = fma(d1, g1, v1); v2 = fma(d2, g2, v2);
-            v3 = fma(d0, g1, v3); v4 = fma(d0, g2, v4); v5 = fma(d1, g2, v5);
+            const double w0 = d0 * g0, w1 = d1 * g1, w2 = d2 * g2, w3 = d0 * g1, w4 = d0 * g2, w5 = d1 * g2;
+            v0 += w0; v1 += w1; v2 += w2; v3 += w3; v4 += w4; v5 += w5;
+            if (p.vatom) {      // ev_tally_xyz, vflag_atom: half of the pair term to j (the other half to i below)
+                double *vj = p.vatom + 6 * (size_t)j;
+                atomicAdd(vj + 0, 0.5 * w0); atomicAdd(vj + 1, 0.5 * w1); atomicAdd(vj + 2, 0.5 * w2);
+                atomicAdd(vj + 3, 0.5 * w3); atomicAdd(vj + 4, 0.5 * w4); atomicAdd(vj + 5, 0.5 * w5);
+            }
         }
     }
     fi0 = wave_sum(fi0); fi1 = wave_sum(fi1); fi2 = wave_sum(fi2);
@@ -541,8 +547,15 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
         v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
         v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
         if (lane == 0) {
-            atomicAdd(&p.virial[0], v0); atomicAdd(&p.virial[1], v1); atomicAdd(&p.virial[2], v2);
-            atomicAdd(&p.virial[3], v3); atomicAdd(&p.virial[4], v4); atomicAdd(&p.virial[5], v5);
+            if (p.virial) {
+                atomicAdd(&p.virial[0], v0); atomicAdd(&p.virial[1], v1); atomicAdd(&p.virial[2], v2);
+                atomicAdd(&p.virial[3], v3); atomicAdd(&p.virial[4], v4); atomicAdd(&p.virial[5], v5);
+            }
+            if (p.vatom) {
+                double *vi = p.vatom + 6 * (size_t)i;
+                atomicAdd(vi + 0, 0.5 * v0); atomicAdd(vi + 1, 0.5 * v1); atomicAdd(vi + 2, 0.5 * v2);
+                atomicAdd(vi + 3, 0.5 * v3); atomicAdd(vi + 4, 0.5 * v4); atomicAdd(vi + 5, 0.5 * v5);
+            }
         }
     }
 }

@@ -38,6 +38,7 @@ struct NiArgs {
     const double *coef;         // [inum][ANNP_CPAD]: c_k = dE/dGhat_k / (sf_max-sf_min)_k
     double *f;
     double *virial;
+    double *vatom;              // nullable, [nall][6] accumulated (VIRIAL variant)
     int *ncount;
     int *errflag;
 };
@@ -493,8 +494,13 @@ __global__ __launch_bounds__(256) void annp_ni_force(NiArgs p)
         atomicAdd(&p.f[3 * (size_t)j + 2], -g2 * ANNP_CFFORCE);
         fi0 += g0; fi1 += g1; fi2 += g2;
         if (VIRIAL) {       // the reference tallies the un-converted force (ni:190-198)
-            v0 = fma(d0, g0, v0); v1 = fma(d1, g1, v1); v2 = fma(d2, g2, v2);
-            v3 = fma(d0, g1, v3); v4 = fma(d0, g2, v4); v5 = fma(d1, g2, v5);
+            const double w0 = d0 * g0, w1 = d1 * g1, w2 = d2 * g2, w3 = d0 * g1, w4 = d0 * g2, w5 = d1 * g2;
+            v0 += w0; v1 += w1; v2 += w2; v3 += w3; v4 += w4; v5 += w5;
+            if (p.vatom) {
+                double *vj = p.vatom + 6 * (size_t)j;
+                atomicAdd(vj + 0, 0.5 * w0); atomicAdd(vj + 1, 0.5 * w1); atomicAdd(vj + 2, 0.5 * w2);
+                atomicAdd(vj + 3, 0.5 * w3); atomicAdd(vj + 4, 0.5 * w4); atomicAdd(vj + 5, 0.5 * w5);
+            }
         }
     }
     fi0 = wave_sum(fi0); fi1 = wave_sum(fi1); fi2 = wave_sum(fi2);
@@ -507,8 +513,15 @@ __global__ __launch_bounds__(256) void annp_ni_force(NiArgs p)
         v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
         v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
         if (lane == 0) {
-            atomicAdd(&p.virial[0], v0); atomicAdd(&p.virial[1], v1); atomicAdd(&p.virial[2], v2);
-            atomicAdd(&p.virial[3], v3); atomicAdd(&p.virial[4], v4); atomicAdd(&p.virial[5], v5);
+            if (p.virial) {
+                atomicAdd(&p.virial[0], v0); atomicAdd(&p.virial[1], v1); atomicAdd(&p.virial[2], v2);
+                atomicAdd(&p.virial[3], v3); atomicAdd(&p.virial[4], v4); atomicAdd(&p.virial[5], v5);
+            }
+            if (p.vatom) {
+                double *vi = p.vatom + 6 * (size_t)i;
+                atomicAdd(vi + 0, 0.5 * v0); atomicAdd(vi + 1, 0.5 * v1); atomicAdd(vi + 2, 0.5 * v2);
+                atomicAdd(vi + 3, 0.5 * v3); atomicAdd(vi + 4, 0.5 * v4); atomicAdd(vi + 5, 0.5 * v5);
+            }
         }
     }
 }

@@ -121,11 +121,12 @@ int PairANNP::init_style(int newton_pair, int device)
 
 int PairANNP::compute(int eflag, int vflag, int eflag_atom, int ago, int inum, int nall, int nghost,
                       const double *x, const int *type, const int *ilist, const int *numneigh,
-                      const int *const *firstneigh, double *f, double *eng_vdwl, double *eatom, double *virial)
+                      const int *const *firstneigh, double *f, double *eng_vdwl, double *eatom, double *virial,
+                      double *vatom)
 {
     if (!handle_) return fail(ANNP_HIP_EARG, "pair style annp/hip used before init_style");
     const int rc = annp_hip_compute(handle_, ago, inum, nall, nghost, x, type, ilist, numneigh, firstneigh,
-                                    eflag, vflag, eflag_atom, 0, f, eng_vdwl, eatom, virial, nullptr);
+                                    eflag, vflag, eflag_atom, vatom ? 1 : 0, f, eng_vdwl, eatom, virial, vatom);
     if (rc == ANNP_HIP_ENOMEM) return fail(rc, "Insufficient memory on accelerator");   // pair_annp_gpu.cpp:122-123
     if (rc != 0) return fail(rc, annp_hip_last_error(handle_));
     return 0;
@@ -133,11 +134,11 @@ int PairANNP::compute(int eflag, int vflag, int eflag_atom, int ago, int inum, i
 
 int PairANNP::compute_n(int eflag, int vflag, int eflag_atom, int ago, int inum, int nall, int nghost,
                         const double *x, const int *type, const double *sublo, const double *subhi, double cutneigh,
-                        double *f, double *eng_vdwl, double *eatom, double *virial)
+                        double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom)
 {
     if (!handle_) return fail(ANNP_HIP_EARG, "pair style annp/hip used before init_style");
     const int rc = annp_hip_compute_n(handle_, ago, inum, nall, nghost, x, type, sublo, subhi, cutneigh,
-                                      eflag, vflag, eflag_atom, 0, f, eng_vdwl, eatom, virial, nullptr);
+                                      eflag, vflag, eflag_atom, vatom ? 1 : 0, f, eng_vdwl, eatom, virial, vatom);
     if (rc == ANNP_HIP_ENOMEM) return fail(rc, "Insufficient memory on accelerator");
     if (rc != 0) return fail(rc, annp_hip_last_error(handle_));
     return 0;
@@ -168,16 +169,17 @@ int annp_pair_init_style(annp_pair *p, int newton_pair, int device) { return p ?
 double annp_pair_init_one(annp_pair *p, int i, int j) { return p ? p->impl.init_one(i, j) : -1.0; }
 int annp_pair_compute(annp_pair *p, int eflag, int vflag, int eflag_atom, int ago, int inum, int nall, int nghost,
                       const double *x, const int *type, const int *ilist, const int *numneigh,
-                      const int *const *firstneigh, double *f, double *eng_vdwl, double *eatom, double *virial)
+                      const int *const *firstneigh, double *f, double *eng_vdwl, double *eatom, double *virial,
+                      double *vatom)
 {
-    return p ? p->impl.compute(eflag, vflag, eflag_atom, ago, inum, nall, nghost, x, type, ilist, numneigh, firstneigh, f, eng_vdwl, eatom, virial)
+    return p ? p->impl.compute(eflag, vflag, eflag_atom, ago, inum, nall, nghost, x, type, ilist, numneigh, firstneigh, f, eng_vdwl, eatom, virial, vatom)
              : ANNP_HIP_EARG;
 }
 int annp_pair_compute_n(annp_pair *p, int eflag, int vflag, int eflag_atom, int ago, int inum, int nall, int nghost,
                         const double *x, const int *type, const double *sublo, const double *subhi, double cutneigh,
-                        double *f, double *eng_vdwl, double *eatom, double *virial)
+                        double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom)
 {
-    return p ? p->impl.compute_n(eflag, vflag, eflag_atom, ago, inum, nall, nghost, x, type, sublo, subhi, cutneigh, f, eng_vdwl, eatom, virial)
+    return p ? p->impl.compute_n(eflag, vflag, eflag_atom, ago, inum, nall, nghost, x, type, sublo, subhi, cutneigh, f, eng_vdwl, eatom, virial, vatom)
              : ANNP_HIP_EARG;
 }
 double annp_pair_memory_usage(const annp_pair *p) { return p ? p->impl.memory_usage() : 0.0; }

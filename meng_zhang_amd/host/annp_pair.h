@@ -36,11 +36,12 @@ class PairANNP {
     // PairANNPGPU::compute, host neighbour list (pair_annp_gpu.cpp:81-127, gpu_mode == GPU_FORCE)
     int compute(int eflag, int vflag, int eflag_atom, int ago, int inum, int nall, int nghost,
                 const double *x, const int *type, const int *ilist, const int *numneigh,
-                const int *const *firstneigh, double *f, double *eng_vdwl, double *eatom, double *virial);
+                const int *const *firstneigh, double *f, double *eng_vdwl, double *eatom, double *virial,
+                double *vatom);
     // same with the device-built list (gpu_mode != GPU_FORCE)
     int compute_n(int eflag, int vflag, int eflag_atom, int ago, int inum, int nall, int nghost,
                   const double *x, const int *type, const double *sublo, const double *subhi, double cutneigh,
-                  double *f, double *eng_vdwl, double *eatom, double *virial);
+                  double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom);
 
     double memory_usage() const;
     double cutmax() const { return cutmax_; }
@@ -78,10 +79,11 @@ int annp_pair_init_style(annp_pair *p, int newton_pair, int device);
 double annp_pair_init_one(annp_pair *p, int i, int j);
 int annp_pair_compute(annp_pair *p, int eflag, int vflag, int eflag_atom, int ago, int inum, int nall, int nghost,
                       const double *x, const int *type, const int *ilist, const int *numneigh,
-                      const int *const *firstneigh, double *f, double *eng_vdwl, double *eatom, double *virial);
+                      const int *const *firstneigh, double *f, double *eng_vdwl, double *eatom, double *virial,
+                double *vatom);
 int annp_pair_compute_n(annp_pair *p, int eflag, int vflag, int eflag_atom, int ago, int inum, int nall, int nghost,
                         const double *x, const int *type, const double *sublo, const double *subhi, double cutneigh,
-                        double *f, double *eng_vdwl, double *eatom, double *virial);
+                        double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom);
 double annp_pair_memory_usage(const annp_pair *p);
 const char *annp_pair_error(const annp_pair *p);
 annp_hip_handle *annp_pair_handle(const annp_pair *p);

@@ -96,7 +96,8 @@ void PairANNPHIP::compute(int eflag, int vflag)
   // atom->x and atom->f are contiguous nall x 3 arrays (memory->create), x[0] is the flat pointer
   const int rc = impl->compute(eflag_either, vflag_global, eflag_atom, neighbor->ago, list->inum, nall, atom->nghost,
                                atom->x[0], atom->type, list->ilist, list->numneigh, list->firstneigh,
-                               atom->f[0], &evdwl, eflag_atom ? eatom : nullptr, vflag_global ? v6 : nullptr);
+                               atom->f[0], &evdwl, eflag_atom ? eatom : nullptr, vflag_global ? v6 : nullptr,
+                               vflag_atom ? vatom[0] : nullptr);
   if (rc != 0) error->one(FLERR, impl->error());
   if (eflag_global) eng_vdwl += evdwl;                 // fe_v2/src/pair_annp.cpp:185
   if (vflag_global) for (int k = 0; k < 6; k++) virial[k] += v6[k];

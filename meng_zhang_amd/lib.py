@@ -51,7 +51,7 @@ def load_library():
     lib.annp_hip_last_timing.argtypes = [vp, dp]
     lib.annp_hip_timing_stats.argtypes = [vp, dp, ip]
     lib.annp_hip_last_counts.argtypes = [vp, ip, C.c_int]
-    lib.annp_hip_compute_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.annp_hip_compute_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.annp_hip_neigh_build_device.argtypes = [vp, C.c_int, C.c_int, vp, C.c_double,
                                                 C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), ip, vp]
     lib.annp_pair_create.argtypes = [C.c_int]
@@ -64,8 +64,8 @@ def load_library():
     lib.annp_pair_init_style.argtypes = [vp, C.c_int, C.c_int]
     lib.annp_pair_init_one.argtypes = [vp, C.c_int, C.c_int]
     lib.annp_pair_init_one.restype = C.c_double
-    lib.annp_pair_compute.argtypes = [vp] + [C.c_int] * 7 + [dp, ip, ip, ip, ipp, dp, dp, dp, dp]
-    lib.annp_pair_compute_n.argtypes = [vp] + [C.c_int] * 7 + [dp, ip, dp, dp, C.c_double, dp, dp, dp, dp]
+    lib.annp_pair_compute.argtypes = [vp] + [C.c_int] * 7 + [dp, ip, ip, ip, ipp, dp, dp, dp, dp, dp]
+    lib.annp_pair_compute_n.argtypes = [vp] + [C.c_int] * 7 + [dp, ip, dp, dp, C.c_double, dp, dp, dp, dp, dp]
     lib.annp_pair_memory_usage.argtypes = [vp]
     lib.annp_pair_memory_usage.restype = C.c_double
     lib.annp_pair_error.argtypes = [vp]

@@ -64,6 +64,7 @@ class PairANNP:
         self.eng_vdwl = 0.0
         self.eatom = None
         self.virial = np.zeros(6)
+        self.vatom = None
         self.atom = None
         self.list = None
         self.ago = 0
@@ -109,16 +110,19 @@ class PairANNP:
             self._check(-1)
         return c
 
-    def compute(self, eflag=1, vflag=0, eflag_atom=True):
+    def compute(self, eflag=1, vflag=0, eflag_atom=True, vflag_atom=False):
         """PairANNP::compute(eflag, vflag) on self.atom / self.list; accumulates into atom.f."""
         a, l = self.atom, self.list
         if eflag_atom and (self.eatom is None or self.eatom.shape[0] != a.nall):
             self.eatom = np.zeros(a.nall)
+        if vflag_atom and (self.vatom is None or self.vatom.shape[0] != a.nall):
+            self.vatom = np.zeros((a.nall, 6))
         eng = C.c_double(0.0)
         vir = np.zeros(6)
         rc = self._lib.annp_pair_compute(self._p, int(eflag), int(vflag), int(bool(eflag_atom)), self.ago, l.inum, a.nall,
                                          a.nghost, _dp(a.x), _ip(a.type), _ip(l.ilist), _ip(l.numneigh), l._ptrs,
-                                         _dp(a.f), C.byref(eng), _dp(self.eatom) if eflag_atom else None, _dp(vir))
+                                         _dp(a.f), C.byref(eng), _dp(self.eatom) if eflag_atom else None, _dp(vir),
+                                         _dp(self.vatom) if vflag_atom else None)
         self._check(rc)
         self.ago += 1
         if eflag:
@@ -137,7 +141,7 @@ class PairANNP:
         hi = np.ascontiguousarray(a.x[: a.nlocal].max(0)) if a.nlocal else np.zeros(3)
         rc = self._lib.annp_pair_compute_n(self._p, int(eflag), int(vflag), int(bool(eflag_atom)), self.ago, a.nlocal,
                                            a.nall, a.nghost, _dp(a.x), _ip(a.type), _dp(lo), _dp(hi), float(cutneigh),
-                                           _dp(a.f), C.byref(eng), _dp(self.eatom) if eflag_atom else None, _dp(vir))
+                                           _dp(a.f), C.byref(eng), _dp(self.eatom) if eflag_atom else None, _dp(vir), None)
         self._check(rc)
         self.ago += 1
         if eflag:

@@ -798,3 +798,37 @@ int annp_oracle_compute(const annp_oracle_pot *pot, int kind, int strategy,
     if (virial) for (int m = 0; m < 6; m++) virial[m] += vtot[m];
     return 0;
 }
+
+/* Per-atom virial, LITERAL strategy re-run with a force probe: the pair term of (i, j) is
+ * v = (x_i - x_j) (x) (-F_j^(i)) where F_j^(i) is what atom i's energy puts on neighbour j
+ * (fe:201-209, ni:190-198).  F_j^(i) is obtained by evaluating atom i alone into a scratch
+ * force array, so this routine shares every formula with annp_oracle_compute. */
+int annp_oracle_compute_vatom(const annp_oracle_pot *pot, int kind,
+                              int nall, const double *x,
+                              int inum, const int *ilist, const int *numneigh,
+                              const long long *first, const int *neigh,
+                              double cutsq, int ni_calls, double *vatom)
+{
+    double *ftmp = (double *)calloc((size_t)nall * 3, sizeof(double));
+    if (!ftmp) return -3;
+    for (int ii = 0; ii < inum; ii++) {
+        const int i = ilist[ii];
+        int one = i;
+        int rc = annp_oracle_compute(pot, kind, ANNP_ORACLE_LITERAL, nall, x, 1, &one, numneigh, first, neigh,
+                                     cutsq, ni_calls, ftmp, NULL, NULL, NULL, NULL, NULL, 1);
+        if (rc) { free(ftmp); return rc; }
+        const int *jl = neigh + first[i];
+        const double fscale = (kind == ANNP_ORACLE_FE) ? 1.0 : 1.0 / CFFORCE;   /* ni tallies the un-converted force */
+        for (int jj = 0; jj < numneigh[i]; jj++) {
+            const int j = jl[jj] & NEIGHMASK;
+            const double fx = -ftmp[3 * j] * fscale, fy = -ftmp[3 * j + 1] * fscale, fz = -ftmp[3 * j + 2] * fscale;
+            const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+            const double v[6] = {dx * fx, dy * fy, dz * fz, dx * fy, dx * fz, dy * fz};
+            for (int k = 0; k < 6; k++) { vatom[6 * i + k] += 0.5 * v[k]; vatom[6 * j + k] += 0.5 * v[k]; }
+            ftmp[3 * j] = ftmp[3 * j + 1] = ftmp[3 * j + 2] = 0.0;
+        }
+        ftmp[3 * i] = ftmp[3 * i + 1] = ftmp[3 * i + 2] = 0.0;
+    }
+    free(ftmp);
+    return 0;
+}

@@ -76,6 +76,14 @@ int annp_oracle_compute(const annp_oracle_pot *pot, int kind, int strategy,
                         double *f, double *eatom, double *eng, double *virial,
                         double *Gout, double *dEdGout, int nthreads);
 
+/* Same evaluation, also tallying the per-atom virial vatom[nall*6] (+=) the way
+ * ev_tally_xyz does with newton_pair on: half of each pair term to i, half to j. */
+int annp_oracle_compute_vatom(const annp_oracle_pot *pot, int kind,
+                              int nall, const double *x,
+                              int inum, const int *ilist, const int *numneigh,
+                              const long long *first, const int *neigh,
+                              double cutsq, int ni_calls, double *vatom);
+
 /* number of threads the FAST strategy will use when nthreads<=0 */
 int annp_oracle_max_threads(void);
 

@@ -71,6 +71,9 @@ def oracle_lib():
             C.c_double, C.c_int, dp, dp, dp, dp, dp, dp, C.c_int]
         lib.annp_oracle_compute.restype = C.c_int
         lib.annp_oracle_max_threads.restype = C.c_int
+        lib.annp_oracle_compute_vatom.argtypes = [C.POINTER(OraclePot), C.c_int, C.c_int, dp, C.c_int, ip, ip, lp, ip,
+                                                  C.c_double, C.c_int, dp]
+        lib.annp_oracle_compute_vatom.restype = C.c_int
         lib.harness_ghosts.argtypes = [C.c_int, dp, dp, ip, C.c_double, C.c_longlong, dp, ip]
         lib.harness_ghosts.restype = C.c_longlong
         lib.harness_neigh.argtypes = [C.c_int, C.c_int, dp, C.c_double, ip, lp, ip]
@@ -201,6 +204,19 @@ def oracle_compute(pot, sysm, kind=KIND_FE, strategy=FAST, cutsq=None, ni_calls=
         raise RuntimeError("annp_oracle_compute -> %d" % rc)
     return dict(f_all=f, f=sysm.fold(f), eatom=eatom[: sysm.nlocal], energy=float(eng[0]),
                 virial=vir, G=G, dEdG=dEdG)
+
+
+def oracle_vatom(pot, sysm, kind=KIND_FE, cutsq=None, ni_calls=1):
+    """per-atom virial [nall][6] as ev_tally_xyz would leave it (ghost shares not folded)"""
+    lib = oracle_lib()
+    if cutsq is None:
+        cutsq = pot.cut * pot.cut
+    v = np.zeros((sysm.nall, 6))
+    rc = lib.annp_oracle_compute_vatom(C.byref(pot), kind, sysm.nall, _dp(sysm.x), sysm.inum, _ip(sysm.ilist),
+                                       _ip(sysm.numneigh), _lp(sysm.first), _ip(sysm.neigh), cutsq, ni_calls, _dp(v))
+    if rc != 0:
+        raise RuntimeError("annp_oracle_compute_vatom -> %d" % rc)
+    return v
 
 
 def load_fe_st():

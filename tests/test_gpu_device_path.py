@@ -45,7 +45,7 @@ def device_eval(potfile, elem, x0, xg, box, want_virial=False):
     vir = torch.zeros(6, dtype=torch.float64, device=dev)
     rc = lib.annp_hip_compute_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), None, None, p_num, p_first, p_neigh,
                                      mx.value, dom.f.data_ptr(), eatom.data_ptr(), eng.data_ptr(),
-                                     vir.data_ptr() if want_virial else None, stream)
+                                     vir.data_ptr() if want_virial else None, None, stream)
     assert rc == 0, lib.annp_hip_last_error(h)
     assert lib.annp_hip_sync(h) == 0
     dom.reverse()

@@ -46,7 +46,7 @@ def big():
         eng = torch.zeros(1, dtype=torch.float64, device=dev)
         eatom = torch.zeros(plan.nall, dtype=torch.float64, device=dev)
         rc = lib.annp_hip_compute_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), None, None, p_num, p_first, p_neigh,
-                                         mx.value, dom.f.data_ptr(), eatom.data_ptr(), eng.data_ptr(), None, stream)
+                                         mx.value, dom.f.data_ptr(), eatom.data_ptr(), eng.data_ptr(), None, None, stream)
         assert rc == 0, lib.annp_hip_last_error(h)
         assert lib.annp_hip_sync(h) == 0
         dom.reverse()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from annp_testlib import (A_FE, A_NI, FAST, FE_POT, KIND_FE, KIND_NI_COMPAT, KIND_NI_FIXED, NI_POT, System, bcc, fcc,
-                          load_fe_st, oracle_compute, perturb)
+                          load_fe_st, oracle_compute, oracle_vatom, perturb)
 
 pytestmark = pytest.mark.gpu
 
@@ -169,3 +169,25 @@ def test_fe_published_log_kat(fe_pair):
     assert abs(np.abs(r["f"]).max() - 0.93490135) < 5e-5
     p = r["virial"][:3].sum() / (3 * 1773495.9) * 1.6021765e6
     assert abs(p - (-40423.638)) / 40423.638 < 2e-4
+
+
+@pytest.mark.parametrize("which", ["fe", "ni"])
+def test_per_atom_virial(fe_pot, ni_pot, which):
+    """vflag_atom: vatom[i] += v/2, vatom[j] += v/2 per pair term (ev_tally_xyz, fe_v2/src/pair_annp.cpp:201-209)."""
+    if which == "fe":
+        x, box = bcc(4, 4, 4, A_FE)
+        potfile, elem, pot, kind = FE_POT, "Fe", fe_pot, KIND_FE
+    else:
+        x, box = fcc(4, 4, 4, A_NI)
+        potfile, elem, pot, kind = NI_POT, "Ni", ni_pot, KIND_NI_FIXED
+    s = System(perturb(x, 99, 0.05), box)
+    p = make_pair(potfile, elem)
+    try:
+        attach(p, s)
+        p.compute(eflag=1, vflag=1, eflag_atom=True, vflag_atom=True)
+        v_gpu, v_glob = p.vatom.copy(), p.virial.copy()
+    finally:
+        p.close()
+    v_ref = oracle_vatom(pot, s, kind)
+    assert np.abs(v_gpu - v_ref).max() < 1e-9
+    assert np.allclose(v_gpu.sum(0), v_glob, rtol=1e-10, atol=1e-9)

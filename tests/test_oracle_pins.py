@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from annp_testlib import (A_FE, A_NI, FAST, KIND_FE, KIND_NI_COMPAT, KIND_NI_FIXED, LITERAL,
-                          System, bcc, fcc, load_fe_st, oracle_compute, perturb)
+                          System, bcc, fcc, load_fe_st, oracle_compute, oracle_vatom, perturb)
 
 # SURVEY.md Appendix B
 FE_KAT = [(2.80, -4479.873964205), (2.8553, -4479.881765560), (2.90, -4479.854951283)]
@@ -130,3 +130,18 @@ def test_ni_repeated_calls_drift(ni_pot):
     e = [oracle_compute(ni_pot, s, KIND_NI_COMPAT, FAST, ni_calls=c)["energy"] for c in (1, 2, 3)]
     assert abs(e[0] / s.nlocal - 0.757588583) < 1e-9
     assert abs(e[1] - e[0]) > 1e-3 and abs(e[2] - e[1]) > 1e-3
+
+
+@pytest.mark.parametrize("which", ["fe", "ni"])
+def test_per_atom_virial_sums_to_global(fe_pot, ni_pot, which):
+    """vatom (ev_tally_xyz, half to i, half to j) must add up to the global tally."""
+    if which == "fe":
+        x, box = bcc(3, 3, 3, A_FE)
+        pot, kind = fe_pot, KIND_FE
+    else:
+        x, box = fcc(3, 3, 3, A_NI)
+        pot, kind = ni_pot, KIND_NI_FIXED
+    s = System(perturb(x, 99, 0.05), box)
+    v = oracle_vatom(pot, s, kind)
+    g = oracle_compute(pot, s, kind, LITERAL, want_virial=True)["virial"]
+    assert np.allclose(v.sum(0), g, rtol=1e-10, atol=1e-10)

@@ -56,7 +56,7 @@ def main():
     for _ in range(reps + 1):
         dom.f.zero_()
         eng.zero_()
-        rc = lib.annp_hip_compute_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value, dom.f.data_ptr(), None, eng.data_ptr(), None, st)
+        rc = lib.annp_hip_compute_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value, dom.f.data_ptr(), None, eng.data_ptr(), None, None, st)
         assert rc == 0, lib.annp_hip_last_error(h)
     ms = np.zeros(4)
     ns = C.c_int(0)
