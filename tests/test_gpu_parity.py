@@ -191,3 +191,27 @@ def test_per_atom_virial(fe_pot, ni_pot, which):
     v_ref = oracle_vatom(pot, s, kind)
     assert np.abs(v_gpu - v_ref).max() < 1e-9
     assert np.allclose(v_gpu.sum(0), v_glob, rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed,density", [(1, 0.01), (2, 0.03), (3, 0.06), (4, 0.085), (5, 0.11)])
+def test_fe_random_clusters(fe_pair, fe_pot, seed, density):
+    """Disordered, non-periodic point sets: every in-cutoff count from 0 up to ~140 occurs (odd and even,
+    shorter than a wave, longer than two), which exercises every branch of the pair tournament."""
+    rng = np.random.default_rng(seed)
+    side = 26.0
+    n = int(density * side ** 3)
+    x = rng.uniform(0.0, side, size=(n, 3))
+    # keep atoms at least 1.6 A apart (thin out), the potential is not meant for overlapping atoms
+    from scipy.spatial import cKDTree
+    while True:
+        pairs = cKDTree(x).query_pairs(1.6, output_type="ndarray")
+        if pairs.shape[0] == 0:
+            break
+        x = np.delete(x, np.unique(pairs[:, 1]), axis=0)
+    s = System(x, np.array([0, 0, 0, side, side, side]), periodic=(0, 0, 0))
+    r = run(fe_pair, s, vflag=1)
+    o = oracle_compute(fe_pot, s, KIND_FE, FAST, want_virial=True)
+    scale = max(1.0, np.abs(o["f"]).max())
+    assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6 * max(1.0, np.abs(o["eatom"] + 4479.0).max())
+    assert np.abs(r["f"] - o["f"]).max() < 1e-9 * scale
+    assert np.allclose(r["virial"], o["virial"], rtol=1e-9, atol=1e-6 * scale)
