@@ -173,7 +173,7 @@ def main():
     value = natoms * args.steps / dt_wall
     achieved = flop_force / (force_ms * 1e-3) / 1e12
     out = {
-        "metric": "atom-steps/sec (whole node), bcc-Fe ANNP",
+        "metric": "atom-steps/sec (whole node), bcc-Fe ANNP, 1/2/4/8 MI355X",
         "value": value,
         "unit": "atom-steps/s",
         "n_gpus": world,
@@ -233,6 +233,8 @@ def main():
             "sample": "1 force evaluation of the first %d of %d atoms of the same box (same neighbour list), "
                       "oracle FAST strategy, OpenMP" % (m, natoms),
             "seconds": tc,
+            "note": "the literal reference CPU pair_annp measured during the survey: 129 atom-steps/s on one core at "
+                    "2 000 atoms (BASELINE.md 2); it cannot run at this size (O(N nall) allocations)",
         }
     print(json.dumps(out))
     if world > 1:

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Developer tool: rate of the host-pointer entry point (annp_hip_compute: what LAMMPS calls), PCIe included."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    from annp_testlib import A_FE, FE_POT, System, bcc, perturb
+    from meng_zhang_amd import AtomData, NeighList, PairANNP
+    cells = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+    x0, box = bcc(cells, cells, cells, A_FE)
+    t = time.time()
+    s = System(perturb(x0, 12345, 0.05), box)
+    print("harness: nlocal %d nall %d list %.1f M entries, %.1f s" % (s.nlocal, s.nall, s.neigh.size / 1e6, time.time() - t))
+    p = PairANNP(1, device=0)
+    p.settings([])
+    p.coeff(["*", "*", FE_POT, "Fe"])
+    p.init_style()
+    p.atom = AtomData(s.x, s.nlocal, s.type)
+    t = time.time()
+    p.list = NeighList(s.ilist, s.numneigh, s.first, s.neigh)
+    print("firstneigh pointers: %.1f s" % (time.time() - t))
+    for label, k in (("ago=0 (list upload)", 1), ("ago>0", 5)):
+        t = time.time()
+        for _ in range(k):
+            p.atom.f[:] = 0.0
+            e = p.compute(eflag=1, vflag=0, eflag_atom=False)
+        dt = (time.time() - t) / k
+        print("%-20s %.1f ms per call -> %.2f M atom-steps/s   E/atom %.6f" % (label, dt * 1e3, s.nlocal / dt / 1e6, e / s.nlocal))
+    p.close()
+
+
+if __name__ == "__main__":
+    main()
