@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(blockIdx.x * ANNP_WAVES_PER_BLOCK + wave);
+    const int ii = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
     if (ii >= p.inum) return;
     unsigned char *wbase = lds_raw + (size_t)wave * fe_desc_lds_per_wave(p.n_cap);
     double2 *recA = reinterpret_cast<double2 *>(wbase);
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(blockIdx.x * ANNP_WAVES_PER_BLOCK + wave);
+    const int ii = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
     if (ii >= p.inum) return;
     const int nslot = fe_slots(p.n_cap);
     const int NZ = p.n_cap + fe_lcap(p.n_cap);

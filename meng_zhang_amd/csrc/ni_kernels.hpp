@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void annp_ni_desc(NiArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(blockIdx.x * ANNP_WAVES_PER_BLOCK + wave);
+    const int ii = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
     if (ii >= p.inum) return;
     unsigned char *wbase = lds_raw + (size_t)wave * ni_lds_per_wave();
     const NiLds L = ni_carve(wbase);
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void annp_ni_force(NiArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(blockIdx.x * ANNP_WAVES_PER_BLOCK + wave);
+    const int ii = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
     if (ii >= p.inum) return;
     unsigned char *wbase = lds_raw + (size_t)wave * ni_lds_per_wave();
     const NiLds L = ni_carve(wbase);
