@@ -260,7 +260,7 @@ static void feed_forward_literal(const annp_oracle_pot *p, int ni_variant, const
     double *J = (double *)calloc((size_t)nmax * nsf, sizeof(double));
     double *J1 = (double *)calloc((size_t)nmax * nsf, sizeof(double));
     double *hdw = (double *)calloc((size_t)nnod * nmax, sizeof(double));
-    double hprev[ANNP_ORACLE_MAXSF], h[ANNP_ORACLE_MAXNOD], hd[ANNP_ORACLE_MAXNOD];
+    double hprev[ANNP_ORACLE_MAXSF], h[ANNP_ORACLE_MAXNOD] = {0}, hd[ANNP_ORACLE_MAXNOD];
     for (int i = 0; i < nsf; i++) J[i * nsf + i] = 1.0;
     for (int i = 0; i < nsf; i++) hprev[i] = G[i];
     for (int l = 0; l < nl; l++) {
