@@ -84,21 +84,34 @@ __device__ __forceinline__ int fe_compact(const FeArgs &p, int i, int lane, doub
     const long long base = p.first[i];
     const int jn = p.numneigh[i];
     int n = 0;
-    for (int c0 = 0; c0 < jn; c0 += 64) {
-        const int jj = c0 + lane;
-        const bool valid = jj < jn;
-        const int j = valid ? (p.neigh[base + jj] & ANNP_NEIGHMASK) : i;
-        const double dx = xi - p.x[3 * (size_t)j], dy = yi - p.x[3 * (size_t)j + 1], dz = zi - p.x[3 * (size_t)j + 2];
-        const double rsq = dx * dx + dy * dy + dz * dz;
-        const bool in = valid && !(rsq > p.cutsq) && !(rsq < 1.0e-12);        // fe:144
-        const unsigned long long m = __ballot(in);
-        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-        if (in && pos < p.n_cap) {
-            recA[pos] = make_double2(dx, dy);
-            recB[pos] = make_double2(dz, rsq);
-            if (WITH_J) auxJ[pos] = j;
+    // four 64-candidate groups per trip: index loads, then 12 coordinate gathers, all in flight together
+    for (int c0 = 0; c0 < jn; c0 += 256) {
+        int j[4];
+        bool valid[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int jj = c0 + 64 * u + lane;
+            valid[u] = jj < jn;
+            j[u] = valid[u] ? (p.neigh[base + jj] & ANNP_NEIGHMASK) : i;
         }
-        n += __popcll(m);
+        double dx[4], dy[4], dz[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            dx[u] = xi - p.x[3 * (size_t)j[u]]; dy[u] = yi - p.x[3 * (size_t)j[u] + 1]; dz[u] = zi - p.x[3 * (size_t)j[u] + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double rsq = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
+            const bool in = valid[u] && !(rsq > p.cutsq) && !(rsq < 1.0e-12);        // fe:144
+            const unsigned long long m = __ballot(in);
+            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            if (in && pos < p.n_cap) {
+                recA[pos] = make_double2(dx[u], dy[u]);
+                recB[pos] = make_double2(dz[u], rsq);
+                if (WITH_J) auxJ[pos] = j[u];
+            }
+            n += __popcll(m);
+        }
     }
     return uniform(n);
 }

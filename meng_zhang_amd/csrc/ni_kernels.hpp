@@ -225,19 +225,33 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int i, const NiLds &L, 
     const double rcmax = fmax(p.rc_rad, p.rc_ang);
     const double rc2 = (rcmax / ANNP_CFLENGTH) * (rcmax / ANNP_CFLENGTH) * (1.0 + 1e-12);   // coarse filter in A^2
     const double pi_over_rc = ANNP_MY_PI / p.rc_ang;
-    // first sweep: cheap distance filter, candidates compacted raw
+    // first sweep: cheap distance filter, candidates compacted raw.  Four 64-candidate groups per
+    // trip so that the index loads, then the 12 coordinate gathers, are all in flight together
+    // (only ~18 of ~224 candidates survive: this sweep is pure memory latency otherwise).
     int n = 0;
-    for (int c0 = 0; c0 < jn; c0 += 64) {
-        const int jj = c0 + lane;
-        const bool valid = jj < jn;
-        const int j = valid ? (p.neigh[base + jj] & ANNP_NEIGHMASK) : i;
-        const double dx = xi - p.x[3 * (size_t)j], dy = yi - p.x[3 * (size_t)j + 1], dz = zi - p.x[3 * (size_t)j + 2];
-        const double rsq = dx * dx + dy * dy + dz * dz;
-        const bool in = valid && rsq < rc2 && rsq > 0.0;
-        const unsigned long long m = __ballot(in);
-        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-        if (in && pos < NI_NCAP) { L.dx[pos] = dx; L.dy[pos] = dy; L.dz[pos] = dz; L.r[pos] = rsq; L.j[pos] = j; }
-        n += __popcll(m);
+    for (int c0 = 0; c0 < jn; c0 += 256) {
+        int j[4];
+        bool valid[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int jj = c0 + 64 * u + lane;
+            valid[u] = jj < jn;
+            j[u] = valid[u] ? (p.neigh[base + jj] & ANNP_NEIGHMASK) : i;
+        }
+        double dx[4], dy[4], dz[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            dx[u] = xi - p.x[3 * (size_t)j[u]]; dy[u] = yi - p.x[3 * (size_t)j[u] + 1]; dz[u] = zi - p.x[3 * (size_t)j[u] + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double rsq = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
+            const bool in = valid[u] && rsq < rc2 && rsq > 0.0;
+            const unsigned long long m = __ballot(in);
+            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            if (in && pos < NI_NCAP) { L.dx[pos] = dx[u]; L.dy[pos] = dy[u]; L.dz[pos] = dz[u]; L.r[pos] = rsq; L.j[pos] = j[u]; }
+            n += __popcll(m);
+        }
     }
     n = uniform(n);
     if (n > NI_NCAP) return n;
