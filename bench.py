@@ -73,8 +73,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("ANNP_FORCE_DIST") == "1"      # the latter: rehearse RCCL with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- workload -------------------------------------------------------------------
@@ -121,13 +123,13 @@ def main():
         dom.forward()                       # Comm::forward_comm
         force_eval()                        # Pair::compute
         dom.reverse()                       # Comm::reverse_comm
-        if world > 1:
+        if use_dist:
             dist.all_reduce(eng)            # thermo: total E_pair
         vel.add_(fo, alpha=dtf)             # second half
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -147,7 +149,7 @@ def main():
     ns = C.c_int(0)
     check(lib.annp_hip_timing_stats(h, ms4.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ns)), "timing_stats")
     lib.annp_hip_set_timing(h, 0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt_wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_wall = float(t.item())
@@ -166,8 +168,7 @@ def main():
     force_ms, desc_ms, mlp_ms = float(ms4[2]), float(ms4[0]), float(ms4[1])
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     value = natoms * args.steps / dt_wall
@@ -236,8 +237,8 @@ def main():
             "note": "the literal reference CPU pair_annp measured during the survey: 129 atom-steps/s on one core at "
                     "2 000 atoms (BASELINE.md 2); it cannot run at this size (O(N nall) allocations)",
         }
-    print(json.dumps(out))
-    if world > 1:
+    _RESULT_LINE.append(json.dumps(out))
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -305,5 +306,23 @@ def _sample_system(lib, h, x_all, nlocal, nall, m, rc_list):
     return s
 
 
+def _main_one_json_line():
+    """stdout carries exactly one line, the JSON: whatever libraries print while the run is set up
+    (e.g. RCCL's version banner under NCCL_DEBUG=VERSION) is sent to stderr instead."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        main()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    if _RESULT_LINE:
+        print(_RESULT_LINE[0], flush=True)
+
+
+_RESULT_LINE = []
+
 if __name__ == "__main__":
-    main()
+    _main_one_json_line()
