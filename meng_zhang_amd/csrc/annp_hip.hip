@@ -78,6 +78,7 @@ struct annp_hip_handle {
     hipEvent_t *ev = nullptr;             // the four events of the evaluation being enqueued
     long long ev_count = 0;               // evaluations recorded since timing was enabled
     int deferred_error = 0;
+    bool mlp_attr_done = false;
 };
 
 namespace {
@@ -124,12 +125,11 @@ void release(annp_hip_handle *h, DevBuf<T> &b)
 template <int KS0, int MT, int NL>
 int launch_mlp(annp_hip_handle *h, const MlpArgs &a, hipStream_t s)
 {
-    static bool attr_done = false;
     const size_t lds = mlp_lds_bytes<KS0, MT, NL>();
-    if (!attr_done) {
+    if (!h->mlp_attr_done) {      // per handle: the attribute is per device, and handles may sit on different GPUs
         HIP_TRY(h, hipFuncSetAttribute((const void *)annp_mlp_mfma<KS0, MT, NL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        h->mlp_attr_done = true;
     }
     const int ntiles = (a.inum + 15) / 16;
     int blocks = (ntiles + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK;
