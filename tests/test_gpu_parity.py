@@ -215,3 +215,22 @@ def test_fe_random_clusters(fe_pair, fe_pot, seed, density):
     assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6 * max(1.0, np.abs(o["eatom"] + 4479.0).max())
     assert np.abs(r["f"] - o["f"]).max() < 1e-9 * scale
     assert np.allclose(r["virial"], o["virial"], rtol=1e-9, atol=1e-6 * scale)
+
+
+def test_special_bits_in_neighbour_indices_are_masked(fe_pair, fe_pot):
+    """LAMMPS stores special-bond flags in the top bits of a neighbour index; the pair style masks
+    them with NEIGHMASK (fe_v2/src/pair_annp.cpp:136)."""
+    x, box = bcc(4, 4, 4, A_FE)
+    s = System(perturb(x, 31, 0.05), box)
+    ref = run(fe_pair, s)
+    rng = np.random.default_rng(5)
+    flagged = s.neigh.copy()
+    sel = rng.random(flagged.size) < 0.3
+    flagged[sel] |= np.int32(1 << 30)
+    flagged[rng.random(flagged.size) < 0.1] |= np.int32(1 << 29)
+    s.neigh = flagged
+    got = run(fe_pair, s)
+    assert np.abs(got["f_all"] - ref["f_all"]).max() < 1e-10
+    assert abs(got["energy"] - ref["energy"]) < 1e-8
+    o = oracle_compute(fe_pot, s, KIND_FE, FAST)
+    assert np.abs(got["f"] - o["f"]).max() < 1e-9
