@@ -26,7 +26,9 @@ struct NeighBuild {
     long long *blocksum = nullptr;
     double *bbox = nullptr;         // device: lo[3], hi[3]
     int *dmax = nullptr;
-    size_t cap_atoms = 0, cap_bins = 0, cap_neigh = 0, cap_local = 0;
+    // element capacity of every array above (each grows on its own)
+    size_t cap_numneigh = 0, cap_first = 0, cap_neigh = 0, cap_binof = 0, cap_binitems = 0;
+    size_t cap_bincount = 0, cap_binstart = 0, cap_binfill = 0, cap_blocksum = 0;
     size_t bytes = 0;
 };
 
@@ -212,10 +214,8 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     nb.valid = false;
     if (nall <= 0 || nlocal <= 0) { nb.nlocal = nlocal; nb.nall = nall; nb.max_numneigh = 0; return 0; }
     if (!nb.bbox) { NB_TRY(hipMalloc((void **)&nb.bbox, 6 * sizeof(double))); NB_TRY(hipMalloc((void **)&nb.dmax, 4 * sizeof(long long))); nb.bytes += 6 * sizeof(double) + 4 * sizeof(long long); }
-    size_t cap;
-    cap = nb.cap_atoms; if (nb_alloc(nb.binof, cap, (size_t)nall, nb.bytes, msg)) return -3;
-    cap = nb.cap_atoms; if (nb_alloc(nb.binitems, cap, (size_t)nall, nb.bytes, msg)) return -3;
-    nb.cap_atoms = cap;
+    if (nb_alloc(nb.binof, nb.cap_binof, (size_t)nall, nb.bytes, msg)) return -3;
+    if (nb_alloc(nb.binitems, nb.cap_binitems, (size_t)nall, nb.bytes, msg)) return -3;
     hipLaunchKernelGGL(annp_bbox, dim3(1), dim3(1024), 0, s, d_x, nall, nb.bbox);
     double hb[6];
     NB_TRY(hipMemcpyAsync(hb, nb.bbox, sizeof(hb), hipMemcpyDeviceToHost, s));
@@ -230,10 +230,9 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     }
     g.inv = 1.0 / cutneigh;
     if (nbins > (1ll << 27)) { msg = "neighbour build: too many bins"; return -1; }
-    cap = nb.cap_bins; if (nb_alloc(nb.bincount, cap, (size_t)nbins + 1, nb.bytes, msg)) return -3;
-    cap = nb.cap_bins; if (nb_alloc(nb.binstart, cap, (size_t)nbins + 1, nb.bytes, msg)) return -3;
-    cap = nb.cap_bins; if (nb_alloc(nb.binfill, cap, (size_t)nbins + 1, nb.bytes, msg)) return -3;
-    nb.cap_bins = cap;
+    if (nb_alloc(nb.bincount, nb.cap_bincount, (size_t)nbins + 1, nb.bytes, msg)) return -3;
+    if (nb_alloc(nb.binstart, nb.cap_binstart, (size_t)nbins + 1, nb.bytes, msg)) return -3;
+    if (nb_alloc(nb.binfill, nb.cap_binfill, (size_t)nbins + 1, nb.bytes, msg)) return -3;
     NB_TRY(hipMemsetAsync(nb.bincount, 0, sizeof(int) * (nbins + 1), s));
     NB_TRY(hipMemsetAsync(nb.binfill, 0, sizeof(int) * (nbins + 1), s));
     const int tb = 256, gb = (nall + tb - 1) / tb;
@@ -242,13 +241,9 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     hipLaunchKernelGGL(annp_bin_fill, dim3(gb), dim3(tb), 0, s, nall, nb.binof, nb.binstart, nb.binfill, nb.binitems);
     hipLaunchKernelGGL(annp_bin_sort, dim3((int)((nbins + tb - 1) / tb)), dim3(tb), 0, s, (int)nbins, nb.binstart, nb.binitems);
     // count
-    cap = nb.cap_local; if (nb_alloc(nb.numneigh, cap, (size_t)nall, nb.bytes, msg)) return -3;
-    cap = nb.cap_local; if (nb_alloc(nb.first, cap, (size_t)nall + 1, nb.bytes, msg)) return -3;
-    {
-        size_t c2 = nb.blocksum ? nb.cap_local : 0;
-        if (nb_alloc(nb.blocksum, c2, (size_t)(nall / 1024 + 2), nb.bytes, msg)) return -3;
-    }
-    nb.cap_local = cap;
+    if (nb_alloc(nb.numneigh, nb.cap_numneigh, (size_t)nall, nb.bytes, msg)) return -3;
+    if (nb_alloc(nb.first, nb.cap_first, (size_t)nall + 1, nb.bytes, msg)) return -3;
+    if (nb_alloc(nb.blocksum, nb.cap_blocksum, (size_t)(nall / 1024 + 2), nb.bytes, msg)) return -3;
     NB_TRY(hipMemsetAsync(nb.numneigh, 0, sizeof(int) * (size_t)nall, s));
     const int wb = (nlocal + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK;
     const double rc2 = cutneigh * cutneigh;
@@ -266,8 +261,7 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     NB_TRY(hipStreamSynchronize(s));
     nb.max_numneigh = (int)(hres[0] & 0xffffffffll);
     const long long total = hres[1];
-    cap = nb.cap_neigh; if (nb_alloc(nb.neigh, cap, (size_t)std::max<long long>(total, 1), nb.bytes, msg)) return -3;
-    nb.cap_neigh = cap;
+    if (nb_alloc(nb.neigh, nb.cap_neigh, (size_t)std::max<long long>(total, 1), nb.bytes, msg)) return -3;
     hipLaunchKernelGGL((annp_neigh_pass<true>), dim3(wb), dim3(256), 0, s, d_x, nlocal, g, rc2, nb.binof, nb.binstart, nb.binitems,
                        nb.numneigh, (const long long *)nb.first, nb.neigh);
     NB_TRY(hipGetLastError());
