@@ -77,7 +77,7 @@ struct annp_hip_handle {
     std::vector<hipEvent_t> evring;       // kRing x 4 events, created on first enable
     hipEvent_t *ev = nullptr;             // the four events of the evaluation being enqueued
     long long ev_count = 0;               // evaluations recorded since timing was enabled
-    int deferred_error = 0;
+    bool flags_pending = false;         // h_flags holds an un-inspected copy of d_flags (Behler path: no mid-step sync)
     bool mlp_attr_done = false;
 };
 
@@ -225,9 +225,23 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
         ni_launch_force(a, h->ni_shape, blocks, d_virial != nullptr || d_vatom != nullptr, s);
         HIP_TRY(h, hipGetLastError());
+        // capacity overflow is reported by the kernels through d_flags[0]; inspected at the next sync point
+        HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        h->flags_pending = true;
     }
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[3], s)); h->ev_count++; }
     (void)nall;
+    return 0;
+}
+
+// after the stream has been synchronised: turn a pending capacity report into an error
+int check_pending_flags(annp_hip_handle *h)
+{
+    if (!h->flags_pending) return 0;
+    h->flags_pending = false;
+    if (h->h_flags[0] > 0)
+        return fail(h, ANNP_HIP_ENEIGHCAP, "%d neighbours inside the descriptor cutoff exceed the kernel capacity %d; "
+                    "the affected atoms were skipped", h->h_flags[0], NI_NCAP);
     return 0;
 }
 
@@ -534,9 +548,7 @@ int annp_hip_sync(annp_hip_handle *h)
     if (!h) return ANNP_HIP_EARG;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
-    int e = h->deferred_error;
-    h->deferred_error = 0;
-    return e;
+    return check_pending_flags(h);
 }
 
 int annp_hip_compute_device(annp_hip_handle *h, int inum, int nall,
@@ -591,6 +603,7 @@ static int host_finish(annp_hip_handle *h, int inum, int nall, int eflag, int vf
     }
     HIP_TRY(h, hipMemcpyAsync(h->h_scalars, h->d_scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    if (int rcf = check_pending_flags(h)) return rcf;
     if (vatom) for (size_t k = 0; k < (size_t)nall * 6; k++) vatom[k] += hv[k];
     for (size_t k = 0; k < (size_t)nall * 3; k++) f[k] += hf[k];                  // fe:199,211: += / -=
     if (eflag && eng_vdwl) *eng_vdwl += h->h_scalars[0];                          // fe:185

@@ -234,3 +234,17 @@ def test_special_bits_in_neighbour_indices_are_masked(fe_pair, fe_pot):
     assert abs(got["energy"] - ref["energy"]) < 1e-8
     o = oracle_compute(fe_pot, s, KIND_FE, FAST)
     assert np.abs(got["f"] - o["f"]).max() < 1e-9
+
+
+def test_ni_capacity_overflow_is_reported():
+    """More in-range neighbours than the Behler kernels hold per wave (128) must surface as error -7
+    (ANNP_HIP_ENEIGHCAP), not as silently skipped atoms."""
+    x, box = fcc(6, 6, 6, 2.0)                       # absurdly dense: ~250 atoms inside 3.9 A
+    s = System(x, box, rc_list=4.5)
+    p = make_pair(NI_POT, "Ni")
+    try:
+        attach(p, s)
+        with pytest.raises(RuntimeError, match="code -7"):
+            p.compute(eflag=1, vflag=0)
+    finally:
+        p.close()
