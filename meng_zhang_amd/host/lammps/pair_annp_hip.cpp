@@ -7,6 +7,7 @@
 
 #include "atom.h"
 #include "comm.h"
+#include "domain.h"
 #include "error.h"
 #include "force.h"
 #include "memory.h"
@@ -19,7 +20,7 @@
 
 using namespace LAMMPS_NS;
 
-PairANNPHIP::PairANNPHIP(LAMMPS *lmp) : Pair(lmp), impl(nullptr), cutmax(0.0), device_id(0)
+PairANNPHIP::PairANNPHIP(LAMMPS *lmp) : Pair(lmp), impl(nullptr), cutmax(0.0), device_id(0), device_neigh(0)
 {
   restartinfo = 0;      // fe_v2/src/pair_annp.cpp:45-47
   one_coeff = 1;
@@ -78,7 +79,10 @@ void PairANNPHIP::init_style()
   }
   const int rc = impl->init_style(force->newton_pair, device_id);
   if (rc != 0) error->all(FLERR, impl->error());     // GPU_EXTRA::check_flag equivalent
-  neighbor->add_request(this, NeighConst::REQ_FULL); // fe_v2/src/pair_annp.cpp:317
+  const char *nm = std::getenv("ANNP_HIP_NEIGH");
+  device_neigh = (nm && std::strcmp(nm, "device") == 0) ? 1 : 0;
+  // host list (gpu_mode == GPU_FORCE, pair_annp_gpu.cpp:228-236) unless the device builds its own
+  if (!device_neigh) neighbor->add_request(this, NeighConst::REQ_FULL); // fe_v2/src/pair_annp.cpp:317
 }
 
 double PairANNPHIP::init_one(int i, int j)
@@ -94,10 +98,17 @@ void PairANNPHIP::compute(int eflag, int vflag)
   double evdwl = 0.0;
   double v6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   // atom->x and atom->f are contiguous nall x 3 arrays (memory->create), x[0] is the flat pointer
-  const int rc = impl->compute(eflag_either, vflag_global, eflag_atom, neighbor->ago, list->inum, nall, atom->nghost,
-                               atom->x[0], atom->type, list->ilist, list->numneigh, list->firstneigh,
-                               atom->f[0], &evdwl, eflag_atom ? eatom : nullptr, vflag_global ? v6 : nullptr,
-                               vflag_atom ? vatom[0] : nullptr);
+  int rc;
+  if (device_neigh)     // pair_annp_gpu.cpp:96-111: only positions cross PCIe, the list never does
+    rc = impl->compute_n(eflag_either, vflag_global, eflag_atom, neighbor->ago, atom->nlocal, nall, atom->nghost,
+                         atom->x[0], atom->type, domain->sublo, domain->subhi, cutmax + neighbor->skin,
+                         atom->f[0], &evdwl, eflag_atom ? eatom : nullptr, vflag_global ? v6 : nullptr,
+                         vflag_atom ? vatom[0] : nullptr);
+  else
+    rc = impl->compute(eflag_either, vflag_global, eflag_atom, neighbor->ago, list->inum, nall, atom->nghost,
+                       atom->x[0], atom->type, list->ilist, list->numneigh, list->firstneigh,
+                       atom->f[0], &evdwl, eflag_atom ? eatom : nullptr, vflag_global ? v6 : nullptr,
+                       vflag_atom ? vatom[0] : nullptr);
   if (rc != 0) error->one(FLERR, impl->error());
   if (eflag_global) eng_vdwl += evdwl;                 // fe_v2/src/pair_annp.cpp:185
   if (vflag_global) for (int k = 0; k < 6; k++) virial[k] += v6[k];

@@ -44,6 +44,7 @@ class PairANNPHIP : public Pair {
   annp_host::PairANNP *impl;
   double cutmax;
   int device_id;      // GPU of this rank: ANNP_HIP_DEVICE or (local rank mod visible devices)
+  int device_neigh;   // ANNP_HIP_NEIGH=device: list built on the GPU (annp_gpu_compute_n analogue, `package gpu neigh yes`)
   void allocate();
 };
 
