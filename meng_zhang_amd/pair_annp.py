@@ -130,15 +130,17 @@ class PairANNP:
         self.virial = vir
         return self.eng_vdwl
 
-    def compute_n(self, cutneigh, eflag=1, vflag=0, eflag_atom=True):
-        """Same, neighbour list built on the device (annp_gpu_compute_n analogue)."""
+    def compute_n(self, cutneigh, eflag=1, vflag=0, eflag_atom=True, sublo=None, subhi=None):
+        """Same, neighbour list built on the device (annp_gpu_compute_n analogue).  sublo/subhi are the
+        sub-domain bounds LAMMPS would pass (domain->sublo/subhi); the library bins by the bounding box of the
+        positions it is given, so they are optional here."""
         a = self.atom
         if eflag_atom and (self.eatom is None or self.eatom.shape[0] != a.nall):
             self.eatom = np.zeros(a.nall)
         eng = C.c_double(0.0)
         vir = np.zeros(6)
-        lo = np.ascontiguousarray(a.x[: a.nlocal].min(0)) if a.nlocal else np.zeros(3)
-        hi = np.ascontiguousarray(a.x[: a.nlocal].max(0)) if a.nlocal else np.zeros(3)
+        lo = np.zeros(3) if sublo is None else np.ascontiguousarray(sublo, dtype=np.float64)
+        hi = np.zeros(3) if subhi is None else np.ascontiguousarray(subhi, dtype=np.float64)
         rc = self._lib.annp_pair_compute_n(self._p, int(eflag), int(vflag), int(bool(eflag_atom)), self.ago, a.nlocal,
                                            a.nall, a.nghost, _dp(a.x), _ip(a.type), _dp(lo), _dp(hi), float(cutneigh),
                                            _dp(a.f), C.byref(eng), _dp(self.eatom) if eflag_atom else None, _dp(vir), None)
