@@ -206,8 +206,14 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.n_cap = std::max(16, round_up(h->h_flags[1], 16));
         size_t lds3 = fe_force_lds_per_wave(a.n_cap) * ANNP_WAVES_PER_BLOCK;
         if (lds3 > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "too many in-cutoff neighbours for LDS (%d)", h->h_flags[1]);
-        if (d_virial || d_vatom) hipLaunchKernelGGL((annp_fe_force<9, 19, true>), dim3(blocks), dim3(256), lds3, s, a);
-        else hipLaunchKernelGGL((annp_fe_force<9, 19, false>), dim3(blocks), dim3(256), lds3, s, a);
+        const bool vir = d_virial || d_vatom;
+        if (fe_force_auxreg(a.n_cap)) {
+            if (vir) hipLaunchKernelGGL((annp_fe_force<9, 19, true, true>), dim3(blocks), dim3(256), lds3, s, a);
+            else hipLaunchKernelGGL((annp_fe_force<9, 19, false, true>), dim3(blocks), dim3(256), lds3, s, a);
+        } else {
+            if (vir) hipLaunchKernelGGL((annp_fe_force<9, 19, true, false>), dim3(blocks), dim3(256), lds3, s, a);
+            else hipLaunchKernelGGL((annp_fe_force<9, 19, false, false>), dim3(blocks), dim3(256), lds3, s, a);
+        }
         HIP_TRY(h, hipGetLastError());
     } else {
         NiArgs a{};
@@ -467,8 +473,10 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     {
         const int full = 160 * 1024;
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc<9, 19>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
-        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
-        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
     }
     // sizing hints, as annp_gpu_init takes them (buffers still grow on demand)
     if (nlocal_hint > 0) {

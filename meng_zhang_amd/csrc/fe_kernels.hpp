@@ -70,9 +70,12 @@ __host__ __device__ inline size_t fe_desc_lds_per_wave(int n_cap)
     size_t rec = (size_t)fe_slots(n_cap) * 32;      // multiple of 16: every wave's base stays b128-aligned
     return rec < 4096 + 512 ? 4096 + 512 : rec;     // reduction scratch [8][64] + [64] results
 }
+// AUXREG (n_cap <= 128): a lane owns neighbours lane and lane+64 and keeps their 1/r and fc' in registers;
+// otherwise they live in LDS.  The neighbour index always does (it is written by the compacting lane).
+__host__ __device__ inline bool fe_force_auxreg(int n_cap) { return n_cap <= 128; }
 __host__ __device__ inline size_t fe_force_lds_per_wave(int n_cap)
 {
-    const size_t b = (size_t)fe_slots(n_cap) * (32 + 40) + (size_t)n_cap * (24 + 8);   // + (1/r, fc', R), index (padded)
+    const size_t b = (size_t)fe_slots(n_cap) * (32 + 40) + (size_t)n_cap * (fe_force_auxreg(n_cap) ? 4 : 16 + 4);
     return (b + 15) & ~(size_t)15;                  // every wave's base stays b128-aligned
 }
 
@@ -336,11 +339,12 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
 //     d/dx_a :  alpha (-e_b + z e_a)/r_a  - P fc'_a fc_b e_a          (fe:683 with fe:618-628)
 //   so with V_a = sum_b alpha e_b, C_a = sum_b alpha z, S_a = sum_b P fc_b:
 //     Fn_a = (-V_a + C_a e_a)/r_a - (S_a fc'_a + R_a) e_a,   R_a = radial dE/dr   (fe:648)
+//   (R_a is folded into the start value of C_a: C_a <- -R_a r_a)
 //   The lane that evaluates the pair adds the a-side in registers and scatters the b-side
 //   (5 doubles) with LDS atomics into the accumulator slot that parallels the record slot
 //   (copies behind n have their own accumulators, folded back at the end).
 // ---------------------------------------------------------------------------------
-template <int NP, int NT, bool VIRIAL>
+template <int NP, int NT, bool VIRIAL, bool AUXREG>
 __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -357,10 +361,10 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     // banks, so 64-bit atomics of consecutive b stay conflict-free and share one address register):
     //   [0..2] V = sum alpha e_b   [3] S = sum P fc_b   [4] C = sum alpha cos
     double *acc = reinterpret_cast<double *>(recB + nslot);
-    double *auxRinv = acc + 5 * (size_t)nslot;
+    int *auxJ = reinterpret_cast<int *>(acc + 5 * (size_t)nslot);
+    double *auxRinv = reinterpret_cast<double *>(auxJ + p.n_cap + (p.n_cap & 1));   // LDS copies, !AUXREG only
     double *auxDfc = auxRinv + p.n_cap;
-    double *auxR = auxDfc + p.n_cap;                              // radial dE/dr
-    int *auxJ = reinterpret_cast<int *>(auxR + p.n_cap);
+    double reg_rinv[2] = {0.0, 0.0}, reg_dfc[2] = {0.0, 0.0};                       // AUXREG: rows lane, lane+64
 
     const int i = p.ilist ? p.ilist[ii] : ii;
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
@@ -375,11 +379,21 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     wave_lds_sync();
     const int H = n >> 1;
     const int L = (H + FE_Q - 1) / FE_Q;
+    // accumulators start at zero, except C which starts at -R r so that the radial term rides along:
+    //   Fn_a = (-V_a + C_a e_a)/r_a - S_a fc'_a e_a   with   C_a = sum_b alpha cos - R_a r_a
+    for (int k = lane; k < 5 * (n + L); k += 64) acc[k] = 0.0;
+    if (lane < FE_DUMP) {
+        recA[NZ + lane] = make_double2(0.0, 0.0);
+        recB[NZ + lane] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[5 * (NZ + lane) + k] = 0.0;
+    }
+    wave_lds_sync();
     {
         double cr[NP];
 #pragma unroll
         for (int m = 0; m < NP; m++) cr[m] = cf[m];
-        for (int a = lane; a < n; a += 64) {
+        auto sweep = [&](int a, double &rinv_out, double &dfc_out) {
             const FeNbr g = fe_geometry(recA[a], recB[a], pi_over_rc);
             const double2 RA = make_double2(g.ex, g.ey), RB = make_double2(g.ez, g.fc);
             recA[a] = RA; recB[a] = RB;
@@ -398,17 +412,23 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
                 sd = fma(cr[mm], d, sd);
                 tm2 = tm1; tm1 = t; dm2 = dm1; dm1 = d;
             }
-            auxR[a] = fma(sd * two_over_rcp, g.fc, st * g.dfc);
-            auxRinv[a] = g.rinv;
-            auxDfc[a] = g.dfc;
-        }
-    }
-    for (int k = lane; k < 5 * (n + L); k += 64) acc[k] = 0.0;
-    if (lane < FE_DUMP) {
-        recA[NZ + lane] = make_double2(0.0, 0.0);
-        recB[NZ + lane] = make_double2(0.0, 0.0);
+            const double R = fma(sd * two_over_rcp, g.fc, st * g.dfc);
+            acc[5 * a + 4] = -R * g.r;
+            rinv_out = g.rinv; dfc_out = g.dfc;
+        };
+        if constexpr (AUXREG) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) acc[5 * (NZ + lane) + k] = 0.0;
+            for (int k = 0; k < 2; k++) {
+                const int a = lane + 64 * k;
+                if (a < n) sweep(a, reg_rinv[k], reg_dfc[k]);
+            }
+        } else {
+            for (int a = lane; a < n; a += 64) {
+                double ri, df;
+                sweep(a, ri, df);
+                auxRinv[a] = ri; auxDfc[a] = df;
+            }
+        }
     }
     wave_lds_sync();
 
@@ -521,11 +541,10 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     // ---- finalize: Fn_a = sum_n c_n dG_n/dx_a ; F_a = -Fn_a to neighbour, +Fn_a to centre (fe:190-213)
     double fi0 = 0.0, fi1 = 0.0, fi2 = 0.0;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
-    for (int a = lane; a < n; a += 64) {
+    auto finish = [&](int a, double rinv, double dfc) {
         const double2 E0 = recA[a], E1 = recB[a];
-        const double rinv = auxRinv[a];
         const double *q = acc + 5 * a;
-        const double t = fma(q[4], rinv, -fma(q[3], auxDfc[a], auxR[a]));
+        const double t = fma(q[4], rinv, -q[3] * dfc);
         const double g0 = fma(t, E0.x, -q[0] * rinv);
         const double g1 = fma(t, E0.y, -q[1] * rinv);
         const double g2 = fma(t, E1.x, -q[2] * rinv);
@@ -549,6 +568,15 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
                 atomicAdd(vj + 3, 0.5 * w3); atomicAdd(vj + 4, 0.5 * w4); atomicAdd(vj + 5, 0.5 * w5);
             }
         }
+    };
+    if constexpr (AUXREG) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int a = lane + 64 * k;
+            if (a < n) finish(a, reg_rinv[k], reg_dfc[k]);
+        }
+    } else {
+        for (int a = lane; a < n; a += 64) finish(a, auxRinv[a], auxDfc[a]);
     }
     fi0 = wave_sum(fi0); fi1 = wave_sum(fi1); fi2 = wave_sum(fi2);
     if (lane == 0) {
