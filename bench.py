@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--cells", type=int, default=80, help="bcc cells per edge (80 -> 1 024 000 atoms)")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="atoms in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dt", type=float, default=0.001, help="ps")
+    ap.add_argument("--rebuild-every", type=int, default=10,
+                    help="secondary figure: the same steps with the neighbour list rebuilt on the device every N steps (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -155,6 +157,24 @@ def main():
         dt_wall = float(t.item())
     e_total = float(eng.item())
 
+    # ---- secondary figure (SURVEY.md 8d ii): the same MD steps with periodic device-side list rebuilds ----------
+    md_rate = None
+    if args.rebuild_every > 0:
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            if k % args.rebuild_every == 0:
+                check(lib.annp_hip_neigh_build_device(h, nlocal, nall, dom.x.data_ptr(), rc_list, C.byref(p_num), C.byref(p_first),
+                                                      C.byref(p_neigh), C.byref(mx), stream), "neigh_build")
+            step()
+        barrier()
+        t_md = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([t_md], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_md = float(t.item())
+        md_rate = natoms * args.steps / t_md
+
     # ---- algorithmic work of this rank's launches (actual in-cutoff counts) ------------
     counts = np.zeros(nlocal, dtype=np.int32)
     check(lib.annp_hip_last_counts(h, counts.ctypes.data_as(C.POINTER(C.c_int)), nlocal), "last_counts")
@@ -195,6 +215,9 @@ def main():
             "step": "verlet + forward halo + force evaluation + reverse halo",
         },
         "energy_per_atom_eV": e_total / natoms,
+        "mini_md": None if md_rate is None else {
+            "value": md_rate, "unit": "atom-steps/s",
+            "note": "same %d steps with the full neighbour list (cutoff 8.5 A) rebuilt on the device every %d steps" % (args.steps, args.rebuild_every)},
         "kernel_ms": {"descriptor": desc_ms, "network": mlp_ms, "force": force_ms, "evaluation": float(ms4[3]), "samples": int(ns.value)},
         "roofline": {
             "kernel": "annp_fe_force<9,19>",
