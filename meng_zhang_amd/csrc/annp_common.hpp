@@ -100,6 +100,71 @@ __device__ __forceinline__ double fast_rsqrt(double x)
     return y;
 }
 
+// ---- table-driven sincos / exp ------------------------------------------------------------
+// A double-precision polynomial constant is not an inline operand on gfx950: the compiler builds each in
+// a register pair and hoists it out of the loop, and a pair loop that evaluates sincos and exp then
+// carries ~70 VGPRs of constants (or spills them).  The Behler kernels keep the constants in LDS instead
+// and read each where it is used (a broadcast ds_read, off the VALU).
+//   [0,10)  sin series -1/21! .. 1/3!    [10,21) cos series 1/22! .. 1/2!    [21] pi/2
+//   [22] log2(e)   [23] ln2 high part   [24] ln2 low part   [25,36) 1/13! .. 1/3!
+#define ANNP_MTAB 36
+__constant__ double annp_mtab[ANNP_MTAB] = {
+    -1.0 / 51090942171709440000.0, 1.0 / 121645100408832000.0, -1.0 / 355687428096000.0, 1.0 / 1307674368000.0,
+    -1.0 / 6227020800.0, 1.0 / 39916800.0, -1.0 / 362880.0, 1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0,
+    1.0 / 1124000727777607680000.0, -1.0 / 2432902008176640000.0, 1.0 / 6402373705728000.0, -1.0 / 20922789888000.0,
+    1.0 / 87178291200.0, -1.0 / 479001600.0, 1.0 / 3628800.0, -1.0 / 40320.0, 1.0 / 720.0, -1.0 / 24.0, 0.5,
+    1.57079632679489661923,
+    1.4426950408889634074, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+    1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+    1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0};
+
+// every wave of the block writes the same values: no ordering between waves is needed
+__device__ __forceinline__ void mtab_fill(double *T, int lane)
+{
+    if (lane < ANNP_MTAB) T[lane] = annp_mtab[lane];
+}
+
+// sincos_0_pi with the coefficients read from T
+__device__ __forceinline__ void sincos_0_pi_tab(double t, const double *T, double &sn, double &cs)
+{
+    const double h = t - T[21];
+    const double h2 = h * h;
+    double ps = T[0];
+#pragma unroll
+    for (int k = 1; k < 10; k++) ps = fma(ps, h2, T[k]);
+    double pc = T[10];
+#pragma unroll
+    for (int k = 11; k < 21; k++) pc = fma(pc, h2, T[k]);
+    sn = fma(-h2, pc, 1.0);                 // cos h
+    cs = -fma(-(h * h2), ps, h);            // -sin h
+}
+
+// exp(x) for x <= 0 (as far down as the subnormals): x = k ln2 + r, |r| <= ln2/2, degree-13 Taylor
+// (truncation 4e-18), scaled by 2^k
+__device__ __forceinline__ double exp_neg_tab(double x, const double *T)
+{
+    const double kf = rint(x * T[22]);
+    double r = fma(-kf, T[23], x);
+    r = fma(-kf, T[24], r);
+    double p = T[25];
+#pragma unroll
+    for (int k = 26; k < ANNP_MTAB; k++) p = fma(p, r, T[k]);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)kf);
+}
+
+// fast_rsqrt written so that its only constant (0.5) is an inline operand
+__device__ __forceinline__ double fast_rsqrt_ic(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return y;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll

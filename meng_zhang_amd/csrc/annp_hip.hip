@@ -45,6 +45,8 @@ struct annp_hip_handle {
     // parameters (copied at init)
     int descriptor = 0, ntypes = 1, ntl = 0, nhl = 0, nnod = 0, nsf = 0, npsf = 0, ntsf = 0, nl = 0;
     int ni_compat = 0;
+    int ni_cap = 24;                    // Behler kernels: record capacity per atom for the next descriptor pass
+    int ni_cap_last = 0;                // ... and what the last force pass ran with
     int flagact[MLP_MAXL] = {0, 0, 0, 0};
     double e_scale = 0, e_shift = 0, e_atom = 0, cut = 0, cutsq = 0;
     double *dW[MLP_MAXL] = {nullptr, nullptr, nullptr, nullptr};
@@ -221,17 +223,36 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.npsf = h->npsf; a.ntsf = h->ntsf; a.sym = h->d_sym; a.isym = h->d_isym; a.compat = h->ni_compat;
         a.rc_rad = h->sym_rad[2]; a.rc_ang = h->sym_ang[3];
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.vatom = d_vatom; a.ncount = h->ncount.p; a.errflag = h->d_flags;
-        a.n_cap = NI_NCAP;
-        int rcn = ni_launch_desc(a, h->ni_shape, blocks, s);
-        if (rcn) return fail(h, ANNP_HIP_ESHAPE, "Behler kernels support npsf<=%d ntsf<=%d", NI_MAXP, NI_MAXT);
-        HIP_TRY(h, hipGetLastError());
+        if (a.npsf > NI_MAXP || a.ntsf > NI_MAXT)
+            return fail(h, ANNP_HIP_ESHAPE, "Behler kernels support npsf<=%d ntsf<=%d", NI_MAXP, NI_MAXT);
+        // pass 1 with the capacity that sufficed last time; the in-range maximum comes back with the overflow flag
+        const int cap_max = ni_max_cap(true, h->nsf);
+        for (int attempt = 0;; attempt++) {
+            a.n_cap = std::min(h->ni_cap, cap_max);
+            ni_launch_desc(a, h->ni_shape, s);
+            HIP_TRY(h, hipGetLastError());
+            hipLaunchKernelGGL(annp_max_int, dim3(std::min(1024, (inum + 255) / 256)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+            if (h->h_flags[0] <= 0) break;
+            if (h->h_flags[0] > cap_max || attempt > 0)
+                return fail(h, ANNP_HIP_ENEIGHCAP, "%d neighbours inside the descriptor cutoff exceed the kernel capacity %d",
+                            h->h_flags[0], cap_max);
+            h->ni_cap = round_up(h->h_flags[0], 8);           // some atom overflowed: redo the pass with room for it
+            HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, 2 * sizeof(int), s));
+        }
+        h->ni_cap = std::max(16, round_up(h->h_flags[1] + 2, 8));   // a little slack for the next call
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
         m.act_plain = 1; m.energy_raw = 1;
         if ((rc = run_mlp(h, m, s))) return rc;
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
-        ni_launch_force(a, h->ni_shape, blocks, d_virial != nullptr || d_vatom != nullptr, s);
+        a.n_cap = std::max(8, round_up(h->h_flags[1], 8));
+        h->ni_cap_last = a.n_cap;
+        ni_launch_force(a, h->ni_shape, d_virial != nullptr || d_vatom != nullptr, s);
         HIP_TRY(h, hipGetLastError());
-        // capacity overflow is reported by the kernels through d_flags[0]; inspected at the next sync point
+        // positions cannot change between the passes, so the force pass cannot overflow; the flag is still read
+        // back at the next sync point as a guard
         HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         h->flags_pending = true;
     }
@@ -247,7 +268,7 @@ int check_pending_flags(annp_hip_handle *h)
     h->flags_pending = false;
     if (h->h_flags[0] > 0)
         return fail(h, ANNP_HIP_ENEIGHCAP, "%d neighbours inside the descriptor cutoff exceed the kernel capacity %d; "
-                    "the affected atoms were skipped", h->h_flags[0], NI_NCAP);
+                    "the affected atoms were skipped", h->h_flags[0], h->ni_cap_last);
     return 0;
 }
 
@@ -437,7 +458,9 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
                 const int l = pos / (ne_ * nz_), e = (pos / nz_) % ne_, z = pos % nz_;
                 prod = ang[4 * m + 1] == lams[l] && ang[4 * m] == etas[e] && ang[4 * m + 2] == zets[z];
             }
-            h->ni_shape = prod ? NiShape{nl_, ne_, nz_} : NiShape{0, 0, 0};
+            h->ni_shape = prod ? NiShape{nl_, ne_, nz_, 0u, 0u} : NiShape{0, 0, 0, 0u, 0u};
+            if (prod && nz_ <= 4)
+                for (int z = 0; z < nz_; z++) h->ni_shape.zp |= (unsigned)zint[z] << (8 * z);    // visit positions 0..nz-1: l = e = 0
         }
         std::vector<int> emult(NI_MAXE, 0);
         for (size_t e = 1; e < etas.size(); e++) {
@@ -445,6 +468,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
             const double kr = std::floor(k + 0.5);
             if (kr >= 1.0 && kr <= 64.0 && std::fabs(kr * etas[0] - etas[e]) <= 4e-16 * std::fabs(etas[e])) emult[e] = (int)kr;
         }
+        h->ni_shape.em = 1u;
+        for (size_t e = 1; e < etas.size() && e < 4; e++) h->ni_shape.em |= (unsigned)emult[e] << (8 * e);
         std::vector<double> t(h->sym_rad);
         t.insert(t.end(), h->sym_ang.begin(), h->sym_ang.end());
         for (int pos = 0; pos < nt; pos++) {
@@ -477,6 +502,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(ni_set_lds_attributes());
     }
     // sizing hints, as annp_gpu_init takes them (buffers still grow on demand)
     if (nlocal_hint > 0) {

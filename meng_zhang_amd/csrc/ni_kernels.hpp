@@ -8,8 +8,14 @@
 // used by the reference's own GPU kernel (ni/lib/lal_annp.cu:409-414).
 //
 // The reference loops over every list entry (≈224 for an 8.5 A list) although only
-// r*CFLENGTH < Rc ones (≈18 in fcc Ni) contribute; here neighbours are filtered into
-// LDS first and the n(n-1)/2 in-range pairs are dealt flat over the 64 lanes.
+// r*CFLENGTH < Rc ones (≈18 in fcc Ni) contribute.  With so few survivors a whole
+// wave per atom idles most of its lanes and, worse, leaves every dependent memory
+// round trip (header -> list row -> coordinates) exposed.  So one wave works on FOUR
+// atoms: the four list rows are filtered as one flat candidate stream (all 64 lanes,
+// four 64-candidate groups in flight), and from then on each atom owns a 16-lane
+// group: its n(n-1)/2 in-range pairs are dealt over those 16 lanes (153 pairs ->
+// 10 trips, 96 % of the lane slots used), per-lane partial sums are private to the
+// atom, and the closing reductions are over 16 lanes.
 // Roles follow list order (j before k) because compat mode is not symmetric in j,k.
 #pragma once
 #include "annp_common.hpp"
@@ -19,12 +25,21 @@ namespace annp {
 #define ANNP_CFLENGTH 1.889726    // ni/src/pair_annp.h:69
 #define ANNP_CFFORCE 51.422515    // ni/src/pair_annp.h:70
 
-constexpr int NI_NCAP = 128;      // in-range neighbours held per wave
+constexpr int NI_GA = 4;          // atoms per wave
+constexpr int NI_GL = 16;         // lanes per atom
 constexpr int NI_MAXP = 8;        // radial functions supported
 constexpr int NI_MAXT = 32;       // angular functions supported
+constexpr int NI_RED = 9;         // sums per LDS reduction round (desc)
+constexpr int NI_REDROW = 17;     // padded row of 16 lane partials
+#ifndef NI_WAVES_PER_SIMD
+#define NI_WAVES_PER_SIMD 4     // descriptor pass: 512 / 4 = 128 VGPRs
+#endif
+#ifndef NI_FORCE_WAVES_PER_SIMD
+#define NI_FORCE_WAVES_PER_SIMD 3
+#endif
 
 struct NiArgs {
-    int inum, n_cap;
+    int inum, n_cap;            // n_cap: in-range neighbours held per atom (LDS records), host-sized
     const int *ilist;
     const double *x;
     const int *numneigh;
@@ -43,17 +58,28 @@ struct NiArgs {
     int *errflag;
 };
 
-__host__ __device__ inline size_t ni_lds_per_wave() { return (size_t)NI_NCAP * (7 * 8 + 3 * 8 + 8); }
+// per-wave LDS: records of NI_GA atoms (7 doubles + index; the force pass adds 3 accumulators and the
+// atoms' coefficient rows), 4 centres, or the reduction scratch of the descriptor pass, whichever is larger
+__host__ __device__ inline int ni_coef_stride(int nsf) { return nsf | 1; }
+__host__ __device__ inline size_t ni_lds_per_wave(int cap, bool force, int nsf)
+{
+    const size_t R = (size_t)NI_GA * cap + 2;          // + two dummy records for idle lanes
+    size_t b = R * 7 * 8 + (force ? R * 3 * 8 + (size_t)NI_GA * ni_coef_stride(nsf) * 8 : 0) + NI_GA * 3 * 8 + R * 4 + NI_GA * 4;
+    const size_t scratch = (size_t)NI_GA * NI_RED * NI_REDROW * 8;
+    if (!force && b < scratch) b = scratch;
+    return (b + 15) / 16 * 16;
+}
 
-// flat pair index -> (a,b), a < b < n, rows a=0: (0,1)..(0,n-1), a=1: ...
+// flat pair index -> (a,b), a < b < n, rows a=0: (0,1)..(0,n-1), a=1: ...   start(r) = r(2n-r-1)/2.
+// The float estimate is within one row of the answer (all operands are integers below 2^24), so one
+// step down and one step up settle it without a loop.
 __device__ __forceinline__ void ni_decode_pair(int p, int n, int &a, int &b)
 {
     const float fn = (float)(2 * n - 1);
     int r = (int)((fn - sqrtf(fn * fn - 8.0f * (float)p)) * 0.5f);
     r = max(0, min(r, n - 2));
-    // start(r) = r(2n-r-1)/2
-    while (r > 0 && r * (2 * n - r - 1) / 2 > p) r--;
-    while ((r + 1) * (2 * n - r - 2) / 2 <= p) r++;
+    if (r * (2 * n - r - 1) / 2 > p) r--;
+    if ((r + 1) * (2 * n - r - 2) / 2 <= p) r++;
     a = r;
     b = p - r * (2 * n - r - 1) / 2 + r + 1;
 }
@@ -71,13 +97,15 @@ __device__ __forceinline__ void ni_decode_pair(int p, int n, int &a, int &b)
 constexpr int NI_MAXE = 4;
 
 struct NiTab {
+    const double *T;            // LDS math table (annp_common.hpp)
     const double *rad, *sorted, *etas;
     const int *perm, *eidx, *zint, *emult;
     int ne;
 };
-__device__ __forceinline__ NiTab ni_tab(const double *sym, const int *isym, int npsf, int ntsf)
+__device__ __forceinline__ NiTab ni_tab(const double *sym, const int *isym, int npsf, int ntsf, const double *T)
 {
     NiTab t;
+    t.T = T;
     t.rad = sym;
     t.sorted = sym + 3 * npsf + 4 * ntsf;
     t.etas = t.sorted + 4 * ntsf;
@@ -117,11 +145,11 @@ __device__ __forceinline__ void ni_visit_functions(const NiTab &t, int ntsf, dou
 {
     // exp(-eta r2sum) for the distinct etas: one exp, powers of it where eta_e is a multiple of eta_0
     double E[NI_MAXE];
-    E[0] = exp(-t.etas[0] * r2sum);
+    E[0] = exp_neg_tab(-t.etas[0] * r2sum, t.T);
 #pragma unroll
     for (int e = 1; e < NI_MAXE; e++) {
         E[e] = 0.0;
-        if (e < t.ne) E[e] = (t.emult[e] > 0) ? ni_powi(E[0], t.emult[e]) : exp(-t.etas[e] * r2sum);
+        if (e < t.ne) E[e] = (t.emult[e] > 0) ? ni_powi(E[0], t.emult[e]) : exp_neg_tab(-t.etas[e] * r2sum, t.T);
     }
     double lam_prev = 0.0, U0 = 0.0;
     double U[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -151,38 +179,105 @@ __device__ __forceinline__ void ni_visit_functions(const NiTab &t, int ntsf, dou
     }
 }
 
-// Same visit when the function set is a full product {lambda} x {eta} x {zeta} (as in the shipped
-// Ni potential: 2 x 3 x 4): the per-function tables collapse to NL + NE + 2 NZ scalars that live
-// in registers, so the inner loop is free of table loads: per function 2 multiplies + the caller's FMA.
-// Visit position = (l * NE + e) * NZ + z, identical to the sorted order above.
-struct NiCart {
-    double lam[4], pref[8], zeta[8];
-    int zint[8];
+// ---- constants of the pair loops, kept in LDS next to the math table ---------------------------
+// Same reason as the math table: a wave-uniform double that is live across the pair loop costs a register
+// pair (or two SGPRs, of which there are not enough either).  Every wave of a block writes the same values.
+//   K[KL + l]        lambda_l                          (product shape)
+//   K[KP + z]        2^(1-zeta_z)
+//   K[KD + 8 l + z]  2^(1-zeta_z) zeta_z lambda_l
+//   K[KE + e]        distinct eta values
+//   K[KM ..]         pi/Rc_ang, Rc_ang, CFLENGTH, 1/CFLENGTH
+//   S[...]           copy of the sorted per-function table + etas (generic shape)
+constexpr int NI_KL = 0, NI_KP = 4, NI_KD = 12, NI_KE = 44, NI_KM = 48, NI_KTAB = 52;
+constexpr int NI_TABLE_DOUBLES = ANNP_MTAB + NI_KTAB + 4 * NI_MAXT + NI_MAXE;
+
+struct NiConst {
+    const double *T, *K;
 };
+
+// compile-time exponents of the product-shape kernels: byte z of ZP = zeta_z, byte e of EM = eta_e / eta_0
+#define NI_BYTE(packed, k) ((int)(((packed) >> (8 * (k))) & 255u))
+
 template <int NL, int NE, int NZ>
-__device__ __forceinline__ NiCart ni_cart_load(const NiTab &t)
+__device__ __forceinline__ NiConst ni_tables_fill(double *lds, const NiArgs &p, NiTab &t, int lane)
 {
-    NiCart c;
-#pragma unroll
-    for (int l = 0; l < NL; l++) c.lam[l] = t.sorted[4 * (l * NE * NZ) + 1];
-#pragma unroll
-    for (int z = 0; z < NZ; z++) {
-        c.zeta[z] = t.sorted[4 * z + 2];
-        c.pref[z] = t.sorted[4 * z + 3];
-        c.zint[z] = t.zint[z];
+    double *T = lds, *K = T + ANNP_MTAB, *S = K + NI_KTAB;
+    mtab_fill(T, lane);
+    if (lane < NI_KTAB) {
+        double v = 0.0;
+        if constexpr (NL > 0) {
+            if (lane < NI_KP) { if (lane < NL) v = t.sorted[4 * (lane * NE * NZ) + 1]; }
+            else if (lane < NI_KD) { const int z = lane - NI_KP; if (z < NZ) v = t.sorted[4 * z + 3]; }
+            else if (lane < NI_KE) {
+                const int l = (lane - NI_KD) >> 3, z = (lane - NI_KD) & 7;
+                if (l < NL && z < NZ) v = t.sorted[4 * z + 3] * t.sorted[4 * z + 2] * t.sorted[4 * (l * NE * NZ) + 1];
+            }
+        }
+        if (lane >= NI_KE && lane < NI_KM) { if (lane - NI_KE < t.ne) v = t.etas[lane - NI_KE]; }
+        if (lane == NI_KM) v = ANNP_MY_PI / p.rc_ang;
+        if (lane == NI_KM + 1) v = p.rc_ang;
+        if (lane == NI_KM + 2) v = ANNP_CFLENGTH;
+        if (lane == NI_KM + 3) v = 1.0 / ANNP_CFLENGTH;
+        K[lane] = v;
     }
+    for (int idx = lane; idx < 4 * p.ntsf + NI_MAXE; idx += 64) S[idx] = t.sorted[idx];
+    NiConst c;
+    c.T = T; c.K = K;
+    t.T = T; t.sorted = S; t.etas = S + 4 * p.ntsf;      // the generic visit reads the LDS copy
     return c;
 }
-template <int NL, int NE, int NZ, bool DERIV, typename Body>
-__device__ __forceinline__ void ni_visit_cart(const NiTab &t, const NiCart &c, double ct, double r2sum, Body &&body)
+
+// exp(-eta_e r2sum) for the distinct etas: one exp, integer powers of it where eta_e is a multiple of eta_0
+template <int NE, unsigned EM>
+__device__ __forceinline__ void ni_exps(const NiConst &c, double r2sum, double (&E)[NE])
+{
+    E[0] = exp_neg_tab(-c.K[NI_KE] * r2sum, c.T);
+#pragma unroll
+    for (int e = 1; e < NE; e++) E[e] = ni_powi(E[0], NI_BYTE(EM, e));
+}
+
+// Descriptor-pass visit for the product shape {lambda} x {eta} x {zeta} (the shipped Ni potential: 2 x 3 x 4),
+// visit position = (l * NE + e) * NZ + z as in the sorted order: per function one FMA, per (l,z) the power.
+//   ga[pos] += 2^(1-zeta) (1+lambda cos)^zeta exp(-eta r2sum) * tfc
+template <int NL, int NE, int NZ, unsigned ZP, unsigned EM, int NT>
+__device__ __forceinline__ void ni_desc_cart(const NiConst &c, double ct, double r2sum, double tfc, double (&ga)[NT])
 {
     double E[NE];
-    E[0] = exp(-t.etas[0] * r2sum);
-#pragma unroll
-    for (int e = 1; e < NE; e++) E[e] = (t.emult[e] > 0) ? ni_powi(E[0], t.emult[e]) : exp(-t.etas[e] * r2sum);
+    ni_exps<NE, EM>(c, r2sum, E);
 #pragma unroll
     for (int l = 0; l < NL; l++) {
-        const double u = fma(c.lam[l], ct, 1.0);
+        const double u = fma(c.K[NI_KL + l], ct, 1.0);
+        const bool ok = u > 0.0;                          // ni:744-747
+        const double U0 = ok ? tfc : 0.0;
+        double U[5];
+        U[0] = ok ? u : 0.0;
+        U[1] = U[0] * U[0]; U[2] = U[1] * U[1]; U[3] = U[2] * U[2]; U[4] = U[3] * U[3];
+#pragma unroll
+        for (int z = 0; z < NZ; z++) {
+            const double pwt = c.K[NI_KP + z] * ni_ladder_pow(U, U0, NI_BYTE(ZP, z));
+#pragma unroll
+            for (int e = 0; e < NE; e++) ga[(l * NE + e) * NZ + z] = fma(pwt, E[e], ga[(l * NE + e) * NZ + z]);
+        }
+    }
+}
+
+// Force-pass visit for the product shape.  The three sums the force needs factor over eta:
+//   A3 = sum c val      = sum_e E_e B_e,      B_e = sum_lz c_lez pw_lz     (pw = 2^(1-zeta) (1+lambda cos)^zeta)
+//   A2 = sum c eta val  = sum_e eta_e E_e B_e
+//   A1 = sum c dval     = sum_e E_e D_e,      D_e = sum_lz c_lez dw_lz     (dw = d pw / d cos)
+// so the visit itself is a polynomial in (1 + lambda cos) with the atom's weights -- 6 FMAs per (l,z) --
+// and the exponentials are only needed afterwards.
+// cw: this atom's weights in visit order (LDS, read as a 16-lane broadcast).
+template <int NL, int NE, int NZ, unsigned ZP, unsigned EM>
+__device__ __forceinline__ void ni_force_cart(const NiConst &c, const double *cw, double ct, double r2sum,
+                                              double &A1, double &A2, double &A3)
+{
+    double B[NE], D[NE];
+#pragma unroll
+    for (int e = 0; e < NE; e++) { B[e] = 0.0; D[e] = 0.0; }
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        const double u = fma(c.K[NI_KL + l], ct, 1.0);
         const bool ok = u > 0.0;
         const double U0 = ok ? 1.0 : 0.0;
         double U[5];
@@ -190,380 +285,522 @@ __device__ __forceinline__ void ni_visit_cart(const NiTab &t, const NiCart &c, d
         U[1] = U[0] * U[0]; U[2] = U[1] * U[1]; U[3] = U[2] * U[2]; U[4] = U[3] * U[3];
 #pragma unroll
         for (int z = 0; z < NZ; z++) {
-            const double pw = c.pref[z] * ni_ladder_pow(U, U0, c.zint[z]);
-            double dw = 0.0;
-            if (DERIV) dw = (c.zint[z] >= 1) ? c.pref[z] * c.zeta[z] * c.lam[l] * ni_ladder_pow(U, U0, c.zint[z] - 1) : 0.0;
+            const double pw = c.K[NI_KP + z] * ni_ladder_pow(U, U0, NI_BYTE(ZP, z));
+            const double dw = NI_BYTE(ZP, z) >= 1 ? c.K[NI_KD + 8 * l + z] * ni_ladder_pow(U, U0, NI_BYTE(ZP, z) - 1) : 0.0;
 #pragma unroll
-            for (int e = 0; e < NE; e++) body((l * NE + e) * NZ + z, pw * E[e], DERIV ? dw * E[e] : 0.0);
+            for (int e = 0; e < NE; e++) {
+                const double cc = cw[(l * NE + e) * NZ + z];
+                B[e] = fma(cc, pw, B[e]);
+                D[e] = fma(cc, dw, D[e]);
+            }
         }
+    }
+    double E[NE];
+    ni_exps<NE, EM>(c, r2sum, E);
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        A3 = fma(E[e], B[e], A3);
+        A2 = fma(c.K[NI_KE + e] * E[e], B[e], A2);
+        A1 = fma(E[e], D[e], A1);
     }
 }
 
-// Shared by both passes: filter neighbours into LDS.  Record a: xij (3), r, fc_ang, dfc_ang.
+// ---- LDS records of one wave --------------------------------------------------------------
 struct NiLds {
-    double *dx, *dy, *dz, *r, *rinv, *fc, *dfc;   // [NI_NCAP] each
-    double *a0, *a1, *a2;                  // force accumulators
-    int *j;
+    double *dx, *dy, *dz, *r, *rinv, *fc, *dfc;   // [NI_GA * cap] each, atom g at g*cap
+    double *a0, *a1, *a2;                         // force accumulators (force pass)
+    double *coef;                                 // [NI_GA][stride] weights: radial, then angular in visit order
+    double *ctr;                                  // [NI_GA][3] centres
+    int *j;                                       // [NI_GA * cap]
+    int *ci;                                      // [NI_GA] atom index of each group, -1 = none
 };
 
-__device__ __forceinline__ NiLds ni_carve(unsigned char *wbase)
+template <bool FORCE>
+__device__ __forceinline__ NiLds ni_carve(unsigned char *wbase, int cap, int cstride)
 {
     NiLds L;
-    L.dx = reinterpret_cast<double *>(wbase);
-    L.dy = L.dx + NI_NCAP; L.dz = L.dy + NI_NCAP; L.r = L.dz + NI_NCAP; L.rinv = L.r + NI_NCAP;
-    L.fc = L.rinv + NI_NCAP; L.dfc = L.fc + NI_NCAP;
-    L.a0 = L.dfc + NI_NCAP; L.a1 = L.a0 + NI_NCAP; L.a2 = L.a1 + NI_NCAP;
-    L.j = reinterpret_cast<int *>(L.a2 + NI_NCAP);
+    const int R = NI_GA * cap + 2;
+    double *d = reinterpret_cast<double *>(wbase);
+    L.dx = d; L.dy = L.dx + R; L.dz = L.dy + R; L.r = L.dz + R; L.rinv = L.r + R; L.fc = L.rinv + R; L.dfc = L.fc + R;
+    d = L.dfc + R;
+    L.a0 = L.a1 = L.a2 = L.coef = nullptr;
+    if (FORCE) { L.a0 = d; L.a1 = L.a0 + R; L.a2 = L.a1 + R; L.coef = L.a2 + R; d = L.coef + NI_GA * cstride; }
+    L.ctr = d; d += NI_GA * 3;
+    L.j = reinterpret_cast<int *>(d);
+    L.ci = L.j + R;
     return L;
 }
 
-__device__ __forceinline__ int ni_stage(const NiArgs &p, int i, const NiLds &L, int lane)
+__device__ __forceinline__ int sel4(int g, int v0, int v1, int v2, int v3) { return g == 0 ? v0 : g == 1 ? v1 : g == 2 ? v2 : v3; }
+
+// Filter the list rows of atoms ii0 .. ii0+3 into the records.  Returns the largest in-range count of the
+// four (uniform; > p.n_cap means the records overflowed and must not be used); nl = count of this lane's atom.
+template <bool FORCE>
+__device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L, const double *T, int lane, int &nl)
 {
-    const double xi = p.x[3 * (size_t)i], yi = p.x[3 * (size_t)i + 1], zi = p.x[3 * (size_t)i + 2];
-    const long long base = p.first[i];
-    const int jn = p.numneigh[i];
+    const int cap = p.n_cap;
+    // headers: lane g < 4 fetches atom g
+    int hi = -1, hjn = 0;
+    long long hbase = 0;
+    if (lane < NI_GA) {
+        const int ii = ii0 + lane;
+        if (ii < p.inum) {
+            hi = p.ilist ? p.ilist[ii] : ii;
+            hjn = p.numneigh[hi];
+            hbase = p.first[hi];
+            L.ctr[3 * lane] = p.x[3 * (size_t)hi]; L.ctr[3 * lane + 1] = p.x[3 * (size_t)hi + 1]; L.ctr[3 * lane + 2] = p.x[3 * (size_t)hi + 2];
+        } else {
+            L.ctr[3 * lane] = 0.0; L.ctr[3 * lane + 1] = 0.0; L.ctr[3 * lane + 2] = 0.0;
+        }
+        L.ci[lane] = hi;
+    }
+    int jn[NI_GA];
+    long long base[NI_GA];
+#pragma unroll
+    for (int g = 0; g < NI_GA; g++) {
+        jn[g] = __builtin_amdgcn_readlane(hjn, g);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(hbase & 0xffffffffll), g);
+        const int hi32 = __builtin_amdgcn_readlane((int)(hbase >> 32), g);
+        base[g] = ((long long)hi32 << 32) | (long long)lo;
+    }
+    const int o1 = jn[0], o2 = o1 + jn[1], o3 = o2 + jn[2], total = o3 + jn[3];
     const double rcmax = fmax(p.rc_rad, p.rc_ang);
     const double rc2 = (rcmax / ANNP_CFLENGTH) * (rcmax / ANNP_CFLENGTH) * (1.0 + 1e-12);   // coarse filter in A^2
     const double pi_over_rc = ANNP_MY_PI / p.rc_ang;
-    // first sweep: cheap distance filter, candidates compacted raw.  Four 64-candidate groups per
-    // trip so that the index loads, then the 12 coordinate gathers, are all in flight together
-    // (only ~18 of ~224 candidates survive: this sweep is pure memory latency otherwise).
-    int n = 0;
-    for (int c0 = 0; c0 < jn; c0 += 256) {
-        int j[4];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    wave_lds_sync();
+    // first sweep: the four rows as one candidate stream, cheap distance filter, survivors compacted per
+    // atom in list order.  Four 64-candidate groups per trip keep the index loads, then the coordinate
+    // gathers, in flight together (only ~18 of ~224 candidates per row survive: this sweep is memory latency).
+    int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    for (int c0 = 0; c0 < total; c0 += 256) {
+        int j[4], gl[4];
         bool valid[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int jj = c0 + 64 * u + lane;
-            valid[u] = jj < jn;
-            j[u] = valid[u] ? (p.neigh[base + jj] & ANNP_NEIGHMASK) : i;
+            const int c = c0 + 64 * u + lane;
+            valid[u] = c < total;
+            const int g = (c >= o1) + (c >= o2) + (c >= o3);
+            gl[u] = g;
+            const int off = c - sel4(g, 0, o1, o2, o3);
+            const long long b = g == 0 ? base[0] : g == 1 ? base[1] : g == 2 ? base[2] : base[3];
+            j[u] = valid[u] ? (p.neigh[b + off] & ANNP_NEIGHMASK) : 0;
         }
         double dx[4], dy[4], dz[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            dx[u] = xi - p.x[3 * (size_t)j[u]]; dy[u] = yi - p.x[3 * (size_t)j[u] + 1]; dz[u] = zi - p.x[3 * (size_t)j[u] + 2];
+            const double *ctr = L.ctr + 3 * gl[u];
+            dx[u] = ctr[0] - p.x[3 * (size_t)j[u]]; dy[u] = ctr[1] - p.x[3 * (size_t)j[u] + 1]; dz[u] = ctr[2] - p.x[3 * (size_t)j[u] + 2];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const double rsq = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
             const bool in = valid[u] && rsq < rc2 && rsq > 0.0;
-            const unsigned long long m = __ballot(in);
-            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-            if (in && pos < NI_NCAP) { L.dx[pos] = dx[u]; L.dy[pos] = dy[u]; L.dz[pos] = dz[u]; L.r[pos] = rsq; L.j[pos] = j[u]; }
-            n += __popcll(m);
+            const unsigned long long m0 = __ballot(in && gl[u] == 0), m1 = __ballot(in && gl[u] == 1);
+            const unsigned long long m2 = __ballot(in && gl[u] == 2), m3 = __ballot(in && gl[u] == 3);
+            const unsigned long long mm = gl[u] == 0 ? m0 : gl[u] == 1 ? m1 : gl[u] == 2 ? m2 : m3;
+            const int pos = sel4(gl[u], n0, n1, n2, n3) + __popcll(mm & lt);
+            if (in && pos < cap) {
+                const int s = gl[u] * cap + pos;
+                L.dx[s] = dx[u]; L.dy[s] = dy[u]; L.dz[s] = dz[u]; L.r[s] = rsq; L.j[s] = j[u];
+            }
+            n0 += __popcll(m0); n1 += __popcll(m1); n2 += __popcll(m2); n3 += __popcll(m3);
         }
     }
-    n = uniform(n);
-    if (n > NI_NCAP) return n;
+    n0 = uniform(n0); n1 = uniform(n1); n2 = uniform(n2); n3 = uniform(n3);
+    const int g = lane >> 4, l = lane & 15;
+    nl = sel4(g, n0, n1, n2, n3);
+    const int nmax = max(max(n0, n1), max(n2, n3));
+    if (nmax > cap) return nmax;
+    if (lane < 2) {     // dummy records NI_GA*cap, +1: finite geometry, beyond every cutoff, never accumulated into
+        const int s = NI_GA * cap + lane;
+        L.dx[s] = lane == 0 ? 1.0 : 0.0; L.dy[s] = lane == 0 ? 0.0 : 1.0; L.dz[s] = 0.0;
+        L.r[s] = 1e3; L.rinv[s] = 1e-3; L.fc[s] = 0.0; L.dfc[s] = 0.0;   // (exp_neg_tab wants a sane argument)
+    }
     wave_lds_sync();
     // second sweep: the exact test of the reference (r * CFLENGTH < Rc, ni:693/729) and the per-neighbour terms.
     // Entries that fail it keep fc = 0 and r = huge, so every pair they enter is rejected by ni_pair.
-    for (int a = lane; a < n; a += 64) {
-        const double rsq = L.r[a];
-        const double rinv = fast_rsqrt(rsq);
-        const double r = rsq * rinv;
-        const double rm = r * ANNP_CFLENGTH;
-        double fc = 0.0, dfc = 0.0;
-        if (rm < p.rc_ang) {
-            double sn, cs;
-            sincos_0_pi(pi_over_rc * rm, sn, cs);
-            fc = 0.5 * (cs + 1.0);
-            dfc = -0.5 * pi_over_rc * sn;
+    for (int a = l; a < nmax; a += NI_GL) {
+        if (a < nl) {
+            const int s = g * cap + a;
+            const double rsq = L.r[s];
+            const double rinv = fast_rsqrt_ic(rsq);
+            const double r = rsq * rinv;
+            const double rm = r * ANNP_CFLENGTH;
+            double fc = 0.0, dfc = 0.0;
+            if (rm < p.rc_ang) {
+                double sn, cs;
+                sincos_0_pi_tab(pi_over_rc * rm, T, sn, cs);
+                fc = 0.5 * (cs + 1.0);
+                dfc = -0.5 * pi_over_rc * sn;
+            }
+            L.r[s] = r; L.rinv[s] = rinv; L.fc[s] = fc; L.dfc[s] = dfc;
+            if (FORCE) { L.a0[s] = 0.0; L.a1[s] = 0.0; L.a2[s] = 0.0; }
         }
-        L.r[a] = r; L.rinv[a] = rinv; L.fc[a] = fc; L.dfc[a] = dfc;
-        L.a0[a] = 0.0; L.a1[a] = 0.0; L.a2[a] = 0.0;
     }
-    return n;
+    return nmax;
 }
 
-// geometry of one (j,k) pair around the centre
-struct NiPair {
-    double ej[3], ek[3], g[3];      // xij/rij, xik/rik, xjk/rjk
-    double rj, rk, rjk, ct;
-    double fcj, fck, fcjk, dfcj, dfck, dfcjk;
+// What the function visit needs of one (j,k) pair around the centre: cos(theta), the three distances (Bohr)
+// and the product of the cutoff functions.  The force pass re-reads the records for the vectors afterwards
+// (LDS reads are cheap; holding them across the 24-function visit costs the registers of a whole wave slot).
+struct NiPairS {
+    double ct, rjm, rkm, rgm, ig;   // ig = 1/r_jk (A^-1)
+    double fcjk, dfcjk, tfc;
     bool ok;
 };
 
-__device__ __forceinline__ NiPair ni_pair(const NiArgs &p, const NiLds &L, int a, int b)
+// sa, sb: record slots (idle lanes pass the two dummy records: ok = false, everything finite)
+__device__ __forceinline__ NiPairS ni_pair(const NiLds &L, const NiConst &c, int sa, int sb)
 {
-    NiPair q;
-    q.rj = L.r[a]; q.rk = L.r[b];
-    const double xj0 = L.dx[a], xj1 = L.dy[a], xj2 = L.dz[a];
-    const double xk0 = L.dx[b], xk1 = L.dy[b], xk2 = L.dz[b];
-    const double ij = L.rinv[a], ik = L.rinv[b];
-    q.ej[0] = xj0 * ij; q.ej[1] = xj1 * ij; q.ej[2] = xj2 * ij;
-    q.ek[0] = xk0 * ik; q.ek[1] = xk1 * ik; q.ek[2] = xk2 * ik;
+    NiPairS q;
+    const double rj = L.r[sa], rk = L.r[sb];
+    const double xj0 = L.dx[sa], xj1 = L.dy[sa], xj2 = L.dz[sa];
+    const double xk0 = L.dx[sb], xk1 = L.dy[sb], xk2 = L.dz[sb];
+    const double ij = L.rinv[sa], ik = L.rinv[sb];
     // xjk = x_j - x_k = xik - xij
     const double g0 = xk0 - xj0, g1 = xk1 - xj1, g2 = xk2 - xj2;
     const double gsq = g0 * g0 + g1 * g1 + g2 * g2;
-    const double ig = fast_rsqrt(gsq);
-    q.rjk = gsq * ig;
-    q.g[0] = g0 * ig; q.g[1] = g1 * ig; q.g[2] = g2 * ig;
-    q.ct = q.ej[0] * q.ek[0] + q.ej[1] * q.ek[1] + q.ej[2] * q.ek[2];
-    q.fcj = L.fc[a]; q.fck = L.fc[b]; q.dfcj = L.dfc[a]; q.dfck = L.dfc[b];
-    const double rc = p.rc_ang;
-    const double rgm = q.rjk * ANNP_CFLENGTH;
-    q.ok = (q.rj * ANNP_CFLENGTH < rc) && (q.rk * ANNP_CFLENGTH < rc) && (rgm < rc);   // ni:729
-    q.fcjk = 0.0; q.dfcjk = 0.0;
+    q.ig = fast_rsqrt_ic(gsq);
+    q.ct = ((xj0 * ij) * (xk0 * ik) + (xj1 * ij) * (xk1 * ik)) + (xj2 * ij) * (xk2 * ik);
+    const double cfl = c.K[NI_KM + 2];
+    q.rjm = rj * cfl; q.rkm = rk * cfl; q.rgm = (gsq * q.ig) * cfl;
+    const double rc = c.K[NI_KM + 1];
+    q.ok = (q.rjm < rc) && (q.rkm < rc) && (q.rgm < rc);   // ni:729
+    q.fcjk = 0.0; q.dfcjk = 0.0; q.tfc = 0.0;
     if (q.ok) {
         double sn, cs;
-        const double por = ANNP_MY_PI / rc;
-        sincos_0_pi(por * rgm, sn, cs);
+        const double por = c.K[NI_KM];
+        sincos_0_pi_tab(por * q.rgm, c.T, sn, cs);
         q.fcjk = 0.5 * (cs + 1.0);
         q.dfcjk = -0.5 * por * sn;
+        q.tfc = L.fc[sa] * L.fc[sb] * q.fcjk;
     }
     return q;
 }
 
+// compiler-level only: values read from LDS before this point are not kept in registers across it
+__device__ __forceinline__ void ni_forget_lds() { asm volatile("" ::: "memory"); }
+
 // ---------------------------------------------------------------------------------
-template <int NP, int NT, int NL, int NE, int NZ>
-__global__ __launch_bounds__(256) void annp_ni_desc(NiArgs p)
+template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM>
+__global__ __launch_bounds__(256, NI_WAVES_PER_SIMD) void annp_ni_desc(NiArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
-    if (ii >= p.inum) return;
-    unsigned char *wbase = lds_raw + (size_t)wave * ni_lds_per_wave();
-    const NiLds L = ni_carve(wbase);
+    const int ii0 = uniform((xcd_block() * ANNP_WAVES_PER_BLOCK + wave) * NI_GA);
+    if (ii0 >= p.inum) return;
+    const int nsf = p.npsf + p.ntsf;
+    const int cap = p.n_cap;
+    NiTab tab = ni_tab(p.sym, p.isym, p.npsf, p.ntsf, nullptr);
+    const double *srad = tab.rad;
+    const NiConst kc = ni_tables_fill<NL, NE, NZ>(reinterpret_cast<double *>(lds_raw), p, tab, lane);
+    const double *T = kc.T;
+    unsigned char *wbase = lds_raw + NI_TABLE_DOUBLES * 8 + (size_t)wave * ni_lds_per_wave(cap, false, nsf);
+    const NiLds L = ni_carve<false>(wbase, cap, 0);
     double *scratch = reinterpret_cast<double *>(wbase);
-    const int i = p.ilist ? p.ilist[ii] : ii;
-    const int n = ni_stage(p, i, L, lane);
-    if (p.ncount && lane == 0) p.ncount[ii] = min(n, NI_NCAP);
-    double *Gout = p.G + (size_t)ii * ANNP_GPAD;
-    if (n > NI_NCAP) {
-        if (lane == 0) atomicMax(p.errflag, n);
-        if (lane < ANNP_GPAD) Gout[lane] = 0.0;
+    const int g = lane >> 4, l = lane & 15;
+    int nl;
+    const int nmax = ni_stage<false>(p, ii0, L, T, lane, nl);
+    const int ncl = __shfl(nl, NI_GL * (lane & (NI_GA - 1)), 64);     // count of atom (lane & 3), for lanes 0..3
+    if (p.ncount && lane < NI_GA && ii0 + lane < p.inum) p.ncount[ii0 + lane] = min(ncl, cap);
+    if (nmax > cap) {
+        if (lane == 0) atomicMax(p.errflag, nmax);
+        for (int idx = lane; idx < NI_GA * ANNP_GPAD; idx += 64)
+            if (ii0 + idx / ANNP_GPAD < p.inum) p.G[(size_t)ii0 * ANNP_GPAD + idx] = 0.0;
         return;
     }
     wave_lds_sync();
-    const NiTab tab = ni_tab(p.sym, p.isym, p.npsf, p.ntsf);
-    const double *srad = tab.rad;
+    const int sbase = g * cap;
 
     double gr[NP], ga[NT];
 #pragma unroll
     for (int m = 0; m < NP; m++) gr[m] = 0.0;
 #pragma unroll
     for (int m = 0; m < NT; m++) ga[m] = 0.0;      // indexed by visit position
-    // G2 (ni:686-711): lane a owns neighbour a
-    for (int a = lane; a < n; a += 64) {
-        const double rm = L.r[a] * ANNP_CFLENGTH;
+    // G2 (ni:686-711): lane l of the group owns neighbours l, l+16, ...
+    for (int a = l; a < nmax; a += NI_GL) {
+        const double rm = (a < nl ? L.r[sbase + a] : 1e30) * ANNP_CFLENGTH;
         if (rm < p.rc_rad) {
             double sn, cs;
-            sincos_0_pi(ANNP_MY_PI / p.rc_rad * rm, sn, cs);
+            sincos_0_pi_tab(ANNP_MY_PI / p.rc_rad * rm, T, sn, cs);
             const double fc = 0.5 * (cs + 1.0);
 #pragma unroll
             for (int m = 0; m < NP; m++)
-                if (m < p.npsf) gr[m] += exp(-srad[3 * m] * rm * rm) * fc;
+                if (m < p.npsf) gr[m] += exp_neg_tab(-srad[3 * m] * rm * rm, T) * fc;
         }
     }
-    // G4 (ni:713-767)
-    NiCart cart;
-    if constexpr (NL > 0) cart = ni_cart_load<NL, NE, NZ>(tab);
-    const int npairs = n * (n - 1) / 2;
-    for (int p0 = 0; p0 < npairs; p0 += 64) {
-        const int pp = p0 + lane;
-        int a = 0, b = 1;
-        if (pp < npairs) ni_decode_pair(pp, n, a, b);
-        const NiPair q = ni_pair(p, L, a, b);
-        const double rjm = q.rj * ANNP_CFLENGTH, rkm = q.rk * ANNP_CFLENGTH, rgm = q.rjk * ANNP_CFLENGTH;
-        const double r2sum = rjm * rjm + rkm * rkm + rgm * rgm;
-        const double tfc = (pp < npairs && q.ok) ? q.fcj * q.fck * q.fcjk : 0.0;     // masked-off lanes add zeros
-        if constexpr (NL > 0)
-            ni_visit_cart<NL, NE, NZ, false>(tab, cart, q.ct, r2sum,
-                                             [&](int pos, double val, double) { ga[pos] = fma(val, tfc, ga[pos]); });
+    // G4 (ni:713-767): the atom's pairs over its 16 lanes
+    const int npl = nl * (nl - 1) / 2;
+    const int trips = (nmax * (nmax - 1) / 2 + NI_GL - 1) / NI_GL;
+    for (int t = 0; t < trips; t++) {
+        const int pp = t * NI_GL + l;
+        int a, b;
+        ni_decode_pair(pp, nl, a, b);
+        const bool live = pp < npl;
+        const NiPairS q = ni_pair(L, kc, live ? sbase + a : NI_GA * cap, live ? sbase + b : NI_GA * cap + 1);
+        const double r2sum = q.rjm * q.rjm + q.rkm * q.rkm + q.rgm * q.rgm;
+        const double tfc = q.tfc;                                   // dead lanes and rejected pairs add zeros
+        ni_forget_lds();                                            // (keeps the table reads inside the loop)
+        if constexpr (NL > 0) ni_desc_cart<NL, NE, NZ, ZP, EM, NT>(kc, q.ct, r2sum, tfc, ga);
         else
             ni_visit_functions<NT, false>(tab, p.ntsf, q.ct, r2sum,
                                           [&](int pos, double val, double) { ga[pos] = fma(val, tfc, ga[pos]); });
     }
     wave_lds_sync();
-    // reduce through LDS, 8 sums per round (records are dead now)
+    // sum the 16 lane partials of every atom through LDS, NI_RED sums per round (records are dead now)
     constexpr int NS = NP + NT;
-    const int nsf = p.npsf + p.ntsf;
 #pragma unroll
-    for (int c8 = 0; c8 < (NS + 7) / 8; c8++) {
+    for (int c9 = 0; c9 < (NS + NI_RED - 1) / NI_RED; c9++) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int m = c8 * 8 + k;       // slot in the padded (NP | NT) layout
+        for (int k = 0; k < NI_RED; k++) {
+            const int m = c9 * NI_RED + k;       // slot in the padded (NP | NT) layout
             double v = 0.0;
             if (m < NP) v = gr[m < NP ? m : 0];
             else if (m < NS) v = ga[(m - NP) >= 0 && (m - NP) < NT ? (m - NP) : 0];
-            scratch[k * 64 + lane] = v;
+            scratch[(g * NI_RED + k) * NI_REDROW + l] = v;
         }
         wave_lds_sync();
-        {
-            const int k = lane >> 3, part = lane & 7;
-            const double *src = scratch + k * 64 + part * 8;
+        if (lane < NI_GA * NI_RED) {
+            const int gq = lane / NI_RED, k = lane % NI_RED;
+            const double *src = scratch + (gq * NI_RED + k) * NI_REDROW;
             double s = 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; u++) s += src[u];
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
-            const int m = c8 * 8 + k;
-            // padded slot -> function index
-            int fidx = -1;
+            for (int u = 0; u < NI_GL; u++) s += src[u];
+            const int m = c9 * NI_RED + k;
+            int fidx = -1;                       // padded slot -> function index
             if (m < NP) { if (m < p.npsf) fidx = m; }
             else if (m - NP < p.ntsf) fidx = p.npsf + tab.perm[m - NP];
-            if (part == 0 && fidx >= 0) Gout[fidx] = s;
+            if (fidx >= 0 && ii0 + gq < p.inum) p.G[(size_t)(ii0 + gq) * ANNP_GPAD + fidx] = s;
         }
         wave_lds_sync();
     }
-    if (lane >= nsf && lane < ANNP_GPAD) Gout[lane] = 0.0;
+    for (int idx = lane; idx < NI_GA * ANNP_GPAD; idx += 64)
+        if (idx % ANNP_GPAD >= nsf && ii0 + idx / ANNP_GPAD < p.inum) p.G[(size_t)ii0 * ANNP_GPAD + idx] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------
-template <int NP, int NT, int NL, int NE, int NZ, bool VIRIAL>
-__global__ __launch_bounds__(256) void annp_ni_force(NiArgs p)
+template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM, bool VIRIAL>
+__global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(NiArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
-    if (ii >= p.inum) return;
-    unsigned char *wbase = lds_raw + (size_t)wave * ni_lds_per_wave();
-    const NiLds L = ni_carve(wbase);
-    const int i = p.ilist ? p.ilist[ii] : ii;
-    const int n = ni_stage(p, i, L, lane);
-    if (n > NI_NCAP) { if (lane == 0) atomicMax(p.errflag, n); return; }
-    wave_lds_sync();
-    const NiTab tab = ni_tab(p.sym, p.isym, p.npsf, p.ntsf);
+    const int ii0 = uniform((xcd_block() * ANNP_WAVES_PER_BLOCK + wave) * NI_GA);
+    if (ii0 >= p.inum) return;
+    const int nsf = p.npsf + p.ntsf;
+    const int cap = p.n_cap;
+    const int cstride = ni_coef_stride(nsf);
+    NiTab tab = ni_tab(p.sym, p.isym, p.npsf, p.ntsf, nullptr);
     const double *srad = tab.rad;
-    const double *cf = p.coef + (size_t)ii * ANNP_CPAD;
-    double cs_[NT];                                 // weights in visit order
-#pragma unroll
-    for (int m = 0; m < NT; m++) cs_[m] = (m < p.ntsf) ? cf[p.npsf + tab.perm[m]] : 0.0;
+    const NiConst kc = ni_tables_fill<NL, NE, NZ>(reinterpret_cast<double *>(lds_raw), p, tab, lane);
+    const double *T = kc.T;
+    unsigned char *wbase = lds_raw + NI_TABLE_DOUBLES * 8 + (size_t)wave * ni_lds_per_wave(cap, true, nsf);
+    const NiLds L = ni_carve<true>(wbase, cap, cstride);
+    const int g = lane >> 4, l = lane & 15;
+    // this wave's coefficient rows: radial as they are, angular in visit order
+    for (int idx = lane; idx < NI_GA * nsf; idx += 64) {
+        const int gq = idx / nsf, k = idx % nsf;
+        double v = 0.0;
+        if (ii0 + gq < p.inum) v = p.coef[(size_t)(ii0 + gq) * ANNP_CPAD + (k < p.npsf ? k : p.npsf + tab.perm[k - p.npsf])];
+        L.coef[gq * cstride + k] = v;
+    }
+    int nl;
+    const int nmax = ni_stage<true>(p, ii0, L, T, lane, nl);
+    if (nmax > cap) { if (lane == 0) atomicMax(p.errflag, nmax); return; }
+    wave_lds_sync();
+    const double *cr = L.coef + g * cstride;        // radial weights of this lane's atom
+    const double *cw = cr + p.npsf;                 // angular, visit order
+    const int sbase = g * cap;
 
-    NiCart cart;
-    if constexpr (NL > 0) cart = ni_cart_load<NL, NE, NZ>(tab);
-    double ceta[NT];                                // c_m eta_m in visit order (term2, ni:754)
-#pragma unroll
-    for (int m = 0; m < NT; m++) ceta[m] = (m < p.ntsf) ? cs_[m] * tab.sorted[4 * m] : 0.0;
-    const int npairs = n * (n - 1) / 2;
-    for (int p0 = 0; p0 < npairs; p0 += 64) {
-        const int pp = p0 + lane;
-        int a = 0, b = 1;
-        if (pp < npairs) ni_decode_pair(pp, n, a, b);
-        const NiPair q = ni_pair(p, L, a, b);
-        const bool live = pp < npairs && q.ok;
-        const double rjm = q.rj * ANNP_CFLENGTH, rkm = q.rk * ANNP_CFLENGTH, rgm = q.rjk * ANNP_CFLENGTH;
-        const double r2sum = rjm * rjm + rkm * rkm + rgm * rgm;
-        const double tfc = live ? q.fcj * q.fck * q.fcjk : 0.0;
+    const int npl = nl * (nl - 1) / 2;
+    const int trips = (nmax * (nmax - 1) / 2 + NI_GL - 1) / NI_GL;
+    for (int t = 0; t < trips; t++) {
+        const int pp = t * NI_GL + l;
+        int a, b;
+        ni_decode_pair(pp, nl, a, b);
+        const bool lv = pp < npl;
+        const int sa = lv ? sbase + a : NI_GA * cap, sb = lv ? sbase + b : NI_GA * cap + 1;
+        const NiPairS q = ni_pair(L, kc, sa, sb);
+        const double r2sum = q.rjm * q.rjm + q.rkm * q.rkm + q.rgm * q.rgm;
         // A1 = sum c term1 CFLENGTH, A2 = sum c term2, A3 = sum c term3   (ni:752-754)
         double A1 = 0.0, A2 = 0.0, A3 = 0.0;
-        auto acc3 = [&](int pos, double val, double dval) {
-            A3 = fma(cs_[pos], val, A3);
-            A2 = fma(ceta[pos], val, A2);
-            A1 = fma(cs_[pos], dval, A1);
-        };
-        if constexpr (NL > 0) ni_visit_cart<NL, NE, NZ, true>(tab, cart, q.ct, r2sum, acc3);
-        else ni_visit_functions<NT, true>(tab, p.ntsf, q.ct, r2sum, acc3);
-        if (live) {
-            A1 *= tfc * (1.0 / ANNP_CFLENGTH);
-            A2 *= tfc;
-            const double rx = p.compat ? rkm : rgm;           // ni:737-738 vs lal_annp.cu:409-414
-            const double t3j_a = q.fck * q.dfcj * q.fcjk, t3j_g = q.fck * q.fcj * q.dfcjk;
-            const double t3k_a = q.fcj * q.dfck * q.fcjk, t3k_g = q.fcj * q.fck * q.dfcjk;
-            const double irj = L.rinv[a], irk = L.rinv[b];
+        ni_forget_lds();
+        if constexpr (NL > 0) ni_force_cart<NL, NE, NZ, ZP, EM>(kc, cw, q.ct, r2sum, A1, A2, A3);
+        else
+            ni_visit_functions<NT, true>(tab, p.ntsf, q.ct, r2sum, [&](int pos, double val, double dval) {
+                const double cc = cw[pos];
+                A3 = fma(cc, val, A3);
+                A2 = fma(cc * tab.sorted[4 * pos], val, A2);
+                A1 = fma(cc, dval, A1);
+            });
+        ni_forget_lds();
+        if (q.ok) {
+            A1 *= q.tfc * kc.K[NI_KM + 3];
+            A2 *= q.tfc;
+            const double rx = p.compat ? q.rkm : q.rgm;       // ni:737-738 vs lal_annp.cu:409-414
+            const double fcj = L.fc[sa], fck = L.fc[sb], dfcj = L.dfc[sa], dfck = L.dfc[sb];
+            const double t3j_a = fck * dfcj * q.fcjk, t3_g = fck * fcj * q.dfcjk;
+            const double t3k_a = fcj * dfck * q.fcjk;
+            const double irj = L.rinv[sa], irk = L.rinv[sb];
+            const double xj[3] = {L.dx[sa], L.dy[sa], L.dz[sa]}, xk[3] = {L.dx[sb], L.dy[sb], L.dz[sb]};
             double fj[3], fk[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-                const double dctj = (-q.ek[d] + q.ct * q.ej[d]) * irj;     // ni:674, fe:618-628
-                const double dctk = (-q.ej[d] + q.ct * q.ek[d]) * irk;
-                const double drj = -q.ej[d], drk = -q.ek[d], g = q.g[d];
-                const double t2j = 2.0 * (rjm * drj + rx * g), t2k = 2.0 * (rkm * drk - rx * g);
-                const double t3j = t3j_a * drj + t3j_g * g, t3k = t3k_a * drk - t3k_g * g;
+                const double ej = xj[d] * irj, ek = xk[d] * irk, gg = (xk[d] - xj[d]) * q.ig;
+                const double dctj = (-ek + q.ct * ej) * irj;     // ni:674, fe:618-628
+                const double dctk = (-ej + q.ct * ek) * irk;
+                const double t2j = 2.0 * (rx * gg - q.rjm * ej), t2k = -2.0 * (q.rkm * ek + rx * gg);
+                const double t3j = t3_g * gg - t3j_a * ej, t3k = -(t3k_a * ek + t3_g * gg);
                 fj[d] = A1 * dctj - A2 * t2j + A3 * t3j;
                 fk[d] = A1 * dctk - A2 * t2k + A3 * t3k;
             }
-            atomicAdd(&L.a0[a], fj[0]); atomicAdd(&L.a1[a], fj[1]); atomicAdd(&L.a2[a], fj[2]);
-            atomicAdd(&L.a0[b], fk[0]); atomicAdd(&L.a1[b], fk[1]); atomicAdd(&L.a2[b], fk[2]);
+            atomicAdd(&L.a0[sa], fj[0]); atomicAdd(&L.a1[sa], fj[1]); atomicAdd(&L.a2[sa], fj[2]);
+            atomicAdd(&L.a0[sb], fk[0]); atomicAdd(&L.a1[sb], fk[1]); atomicAdd(&L.a2[sb], fk[2]);
         }
     }
     wave_lds_sync();
     double fi0 = 0.0, fi1 = 0.0, fi2 = 0.0;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
-    for (int a = lane; a < n; a += 64) {
-        double g0 = L.a0[a], g1 = L.a1[a], g2 = L.a2[a];
-        const double r = L.r[a], rm = r * ANNP_CFLENGTH;
-        const double d0 = L.dx[a], d1 = L.dy[a], d2 = L.dz[a];
-        if (rm < p.rc_rad) {                                     // ni:693-709
-            double sn, cs;
-            const double por = ANNP_MY_PI / p.rc_rad;
-            sincos_0_pi(por * rm, sn, cs);
-            const double fc = 0.5 * (cs + 1.0), dfc = -0.5 * por * sn;
-            double R = 0.0;
+    for (int a = l; a < nmax; a += NI_GL) {
+        if (a < nl) {
+            const int s = sbase + a;
+            double g0 = L.a0[s], g1 = L.a1[s], g2 = L.a2[s];
+            const double r = L.r[s], rm = r * ANNP_CFLENGTH;
+            const double d0 = L.dx[s], d1 = L.dy[s], d2 = L.dz[s];
+            if (rm < p.rc_rad) {                                     // ni:693-709
+                double sn, cs;
+                const double por = ANNP_MY_PI / p.rc_rad;
+                sincos_0_pi_tab(por * rm, T, sn, cs);
+                const double fc = 0.5 * (cs + 1.0), dfc = -0.5 * por * sn;
+                double R = 0.0;
 #pragma unroll
-            for (int m = 0; m < NP; m++)
-                if (m < p.npsf) {
-                    const double eta = srad[3 * m];
-                    R = fma(cf[m], exp(-eta * rm * rm) * (-fc * 2.0 * eta * rm + dfc), R);
+                for (int m = 0; m < NP; m++)
+                    if (m < p.npsf) {
+                        const double eta = srad[3 * m];
+                        R = fma(cr[m], exp_neg_tab(-eta * rm * rm, T) * (-fc * 2.0 * eta * rm + dfc), R);
+                    }
+                const double sc = -R * L.rinv[s];                     // dr_dj = -xij/rij
+                g0 = fma(sc, d0, g0); g1 = fma(sc, d1, g1); g2 = fma(sc, d2, g2);
+            }
+            const int j = L.j[s];
+            atomicAdd(&p.f[3 * (size_t)j], -g0 * ANNP_CFFORCE);       // ni:186-189
+            atomicAdd(&p.f[3 * (size_t)j + 1], -g1 * ANNP_CFFORCE);
+            atomicAdd(&p.f[3 * (size_t)j + 2], -g2 * ANNP_CFFORCE);
+            fi0 += g0; fi1 += g1; fi2 += g2;
+            if (VIRIAL) {       // the reference tallies the un-converted force (ni:190-198)
+                const double w0 = d0 * g0, w1 = d1 * g1, w2 = d2 * g2, w3 = d0 * g1, w4 = d0 * g2, w5 = d1 * g2;
+                v0 += w0; v1 += w1; v2 += w2; v3 += w3; v4 += w4; v5 += w5;
+                if (p.vatom) {
+                    double *vj = p.vatom + 6 * (size_t)j;
+                    atomicAdd(vj + 0, 0.5 * w0); atomicAdd(vj + 1, 0.5 * w1); atomicAdd(vj + 2, 0.5 * w2);
+                    atomicAdd(vj + 3, 0.5 * w3); atomicAdd(vj + 4, 0.5 * w4); atomicAdd(vj + 5, 0.5 * w5);
                 }
-            const double s = -R * L.rinv[a];                      // dr_dj = -xij/rij
-            g0 = fma(s, d0, g0); g1 = fma(s, d1, g1); g2 = fma(s, d2, g2);
-        }
-        const int j = L.j[a];
-        atomicAdd(&p.f[3 * (size_t)j], -g0 * ANNP_CFFORCE);       // ni:186-189
-        atomicAdd(&p.f[3 * (size_t)j + 1], -g1 * ANNP_CFFORCE);
-        atomicAdd(&p.f[3 * (size_t)j + 2], -g2 * ANNP_CFFORCE);
-        fi0 += g0; fi1 += g1; fi2 += g2;
-        if (VIRIAL) {       // the reference tallies the un-converted force (ni:190-198)
-            const double w0 = d0 * g0, w1 = d1 * g1, w2 = d2 * g2, w3 = d0 * g1, w4 = d0 * g2, w5 = d1 * g2;
-            v0 += w0; v1 += w1; v2 += w2; v3 += w3; v4 += w4; v5 += w5;
-            if (p.vatom) {
-                double *vj = p.vatom + 6 * (size_t)j;
-                atomicAdd(vj + 0, 0.5 * w0); atomicAdd(vj + 1, 0.5 * w1); atomicAdd(vj + 2, 0.5 * w2);
-                atomicAdd(vj + 3, 0.5 * w3); atomicAdd(vj + 4, 0.5 * w4); atomicAdd(vj + 5, 0.5 * w5);
             }
         }
     }
-    fi0 = wave_sum(fi0); fi1 = wave_sum(fi1); fi2 = wave_sum(fi2);
-    if (lane == 0) {
+    // group sums (16 lanes) -> the centre atom
+    const int i = L.ci[g];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        fi0 += __shfl_xor(fi0, off, 64); fi1 += __shfl_xor(fi1, off, 64); fi2 += __shfl_xor(fi2, off, 64);
+    }
+    if (l == 0 && i >= 0) {
         atomicAdd(&p.f[3 * (size_t)i], fi0 * ANNP_CFFORCE);
         atomicAdd(&p.f[3 * (size_t)i + 1], fi1 * ANNP_CFFORCE);
         atomicAdd(&p.f[3 * (size_t)i + 2], fi2 * ANNP_CFFORCE);
     }
     if (VIRIAL) {
-        v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
-        v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
-        if (lane == 0) {
-            if (p.virial) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            v0 += __shfl_xor(v0, off, 64); v1 += __shfl_xor(v1, off, 64); v2 += __shfl_xor(v2, off, 64);
+            v3 += __shfl_xor(v3, off, 64); v4 += __shfl_xor(v4, off, 64); v5 += __shfl_xor(v5, off, 64);
+        }
+        if (l == 0 && i >= 0 && p.vatom) {
+            double *vi = p.vatom + 6 * (size_t)i;
+            atomicAdd(vi + 0, 0.5 * v0); atomicAdd(vi + 1, 0.5 * v1); atomicAdd(vi + 2, 0.5 * v2);
+            atomicAdd(vi + 3, 0.5 * v3); atomicAdd(vi + 4, 0.5 * v4); atomicAdd(vi + 5, 0.5 * v5);
+        }
+        if (p.virial) {
+#pragma unroll
+            for (int off = 32; off >= 16; off >>= 1) {
+                v0 += __shfl_xor(v0, off, 64); v1 += __shfl_xor(v1, off, 64); v2 += __shfl_xor(v2, off, 64);
+                v3 += __shfl_xor(v3, off, 64); v4 += __shfl_xor(v4, off, 64); v5 += __shfl_xor(v5, off, 64);
+            }
+            if (lane == 0) {
                 atomicAdd(&p.virial[0], v0); atomicAdd(&p.virial[1], v1); atomicAdd(&p.virial[2], v2);
                 atomicAdd(&p.virial[3], v3); atomicAdd(&p.virial[4], v4); atomicAdd(&p.virial[5], v5);
-            }
-            if (p.vatom) {
-                double *vi = p.vatom + 6 * (size_t)i;
-                atomicAdd(vi + 0, 0.5 * v0); atomicAdd(vi + 1, 0.5 * v1); atomicAdd(vi + 2, 0.5 * v2);
-                atomicAdd(vi + 3, 0.5 * v3); atomicAdd(vi + 4, 0.5 * v4); atomicAdd(vi + 5, 0.5 * v5);
             }
         }
     }
 }
 
-// product shape of the angular set, filled by annp_hip_init: nl*ne*nz == ntsf when it is a full product, else nl = 0
-struct NiShape { int nl, ne, nz; };
+// product shape of the angular set, filled by annp_hip_init: nl*ne*nz == ntsf when it is a full product
+// {lambda} x {eta} x {zeta} (else nl = 0); zp packs the zetas, em the integer ratios eta_e / eta_0 (0 = not one)
+struct NiShape { int nl, ne, nz; unsigned zp, em; };
 
-inline int ni_launch_desc(const NiArgs &a, NiShape sh, int blocks, hipStream_t s)
+// the shape of the shipped ni_annp_potential_2.ann: lambda = -1,+1; eta = 0.01 x {1,2,5}; zeta = 1,2,4,16
+#define NI_SHIPPED 3, 24, 2, 3, 4, (1u | 2u << 8 | 4u << 16 | 16u << 24), (1u | 2u << 8 | 5u << 16)
+#define NI_GENERIC NI_MAXP, NI_MAXT, 0, 0, 0, 0u, 0u
+inline bool ni_is_shipped_shape(const NiArgs &a, NiShape sh)
 {
-    const size_t lds = ni_lds_per_wave() * ANNP_WAVES_PER_BLOCK;
+    return a.npsf <= 3 && a.ntsf == 24 && sh.nl == 2 && sh.ne == 3 && sh.nz == 4 &&
+           sh.zp == (1u | 2u << 8 | 4u << 16 | 16u << 24) && sh.em == (1u | 2u << 8 | 5u << 16);
+}
+
+inline size_t ni_lds_block(int cap, bool force, int nsf) { return NI_TABLE_DOUBLES * 8 + ni_lds_per_wave(cap, force, nsf) * ANNP_WAVES_PER_BLOCK; }
+
+// largest record capacity whose 4-wave block still fits the 160 KB of a CU
+inline int ni_max_cap(bool force, int nsf)
+{
+    int cap = 8;
+    while (ni_lds_block(cap + 8, force, nsf) <= 160 * 1024) cap += 8;
+    return cap;
+}
+
+inline int ni_blocks(int inum) { return (inum + ANNP_WAVES_PER_BLOCK * NI_GA - 1) / (ANNP_WAVES_PER_BLOCK * NI_GA); }
+
+inline int ni_launch_desc(const NiArgs &a, NiShape sh, hipStream_t s)
+{
+    const size_t lds = ni_lds_block(a.n_cap, false, a.npsf + a.ntsf);
     if (a.npsf > NI_MAXP || a.ntsf > NI_MAXT) return -1;
-    if (a.npsf <= 3 && a.ntsf == 24 && sh.nl == 2 && sh.ne == 3 && sh.nz == 4)
-        hipLaunchKernelGGL((annp_ni_desc<3, 24, 2, 3, 4>), dim3(blocks), dim3(256), lds, s, a);
+    const int blocks = ni_blocks(a.inum);
+    if (ni_is_shipped_shape(a, sh))
+        hipLaunchKernelGGL((annp_ni_desc<NI_SHIPPED>), dim3(blocks), dim3(256), lds, s, a);
     else
-        hipLaunchKernelGGL((annp_ni_desc<NI_MAXP, NI_MAXT, 0, 0, 0>), dim3(blocks), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((annp_ni_desc<NI_GENERIC>), dim3(blocks), dim3(256), lds, s, a);
     return 0;
 }
 
-inline void ni_launch_force(const NiArgs &a, NiShape sh, int blocks, bool virial, hipStream_t s)
+inline void ni_launch_force(const NiArgs &a, NiShape sh, bool virial, hipStream_t s)
 {
-    const size_t lds = ni_lds_per_wave() * ANNP_WAVES_PER_BLOCK;
-    if (a.npsf <= 3 && a.ntsf == 24 && sh.nl == 2 && sh.ne == 3 && sh.nz == 4) {
-        if (virial) hipLaunchKernelGGL((annp_ni_force<3, 24, 2, 3, 4, true>), dim3(blocks), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((annp_ni_force<3, 24, 2, 3, 4, false>), dim3(blocks), dim3(256), lds, s, a);
+    const size_t lds = ni_lds_block(a.n_cap, true, a.npsf + a.ntsf);
+    const int blocks = ni_blocks(a.inum);
+    if (ni_is_shipped_shape(a, sh)) {
+        if (virial) hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, true>), dim3(blocks), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, false>), dim3(blocks), dim3(256), lds, s, a);
     } else {
-        if (virial) hipLaunchKernelGGL((annp_ni_force<NI_MAXP, NI_MAXT, 0, 0, 0, true>), dim3(blocks), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((annp_ni_force<NI_MAXP, NI_MAXT, 0, 0, 0, false>), dim3(blocks), dim3(256), lds, s, a);
+        if (virial) hipLaunchKernelGGL((annp_ni_force<NI_GENERIC, true>), dim3(blocks), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((annp_ni_force<NI_GENERIC, false>), dim3(blocks), dim3(256), lds, s, a);
     }
+}
+
+
+// the kernels may ask for more than the default 64 KB of dynamic LDS
+inline hipError_t ni_set_lds_attributes()
+{
+    const int full = 160 * 1024;
+    hipError_t e;
+#define NI_ATTR(k) if ((e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, full)) != hipSuccess) return e
+    NI_ATTR((annp_ni_desc<NI_SHIPPED>));
+    NI_ATTR((annp_ni_desc<NI_GENERIC>));
+    NI_ATTR((annp_ni_force<NI_SHIPPED, true>));
+    NI_ATTR((annp_ni_force<NI_SHIPPED, false>));
+    NI_ATTR((annp_ni_force<NI_GENERIC, true>));
+    NI_ATTR((annp_ni_force<NI_GENERIC, false>));
+#undef NI_ATTR
+    return hipSuccess;
 }
 
 }  // namespace annp
