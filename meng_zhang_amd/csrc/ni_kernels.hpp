@@ -14,7 +14,7 @@
 // atoms: the four list rows are filtered as one flat candidate stream (all 64 lanes,
 // four 64-candidate groups in flight), and from then on each atom owns a 16-lane
 // group: its n(n-1)/2 in-range pairs are dealt over those 16 lanes (153 pairs ->
-// 10 trips, 96 % of the lane slots used), per-lane partial sums are private to the
+// 10 trips, 96 % of the lane slots used; round-robin enumeration, see NiWalk), per-lane partial sums are private to the
 // atom, and the closing reductions are over 16 lanes.
 // Roles follow list order (j before k) because compat mode is not symmetric in j,k.
 #pragma once
@@ -59,29 +59,38 @@ struct NiArgs {
 };
 
 // per-wave LDS: records of NI_GA atoms (7 doubles + index; the force pass adds 3 accumulators and the
-// atoms' coefficient rows), 4 centres, or the reduction scratch of the descriptor pass, whichever is larger
+// atoms' coefficient rows), or the reduction scratch of the descriptor pass, whichever is larger
 __host__ __device__ inline int ni_coef_stride(int nsf) { return nsf | 1; }
 __host__ __device__ inline size_t ni_lds_per_wave(int cap, bool force, int nsf)
 {
     const size_t R = (size_t)NI_GA * cap + 2;          // + two dummy records for idle lanes
-    size_t b = R * 7 * 8 + (force ? R * 3 * 8 + (size_t)NI_GA * ni_coef_stride(nsf) * 8 : 0) + NI_GA * 3 * 8 + R * 4 + NI_GA * 4;
+    size_t b = R * 7 * 8 + (force ? R * 3 * 8 + (size_t)NI_GA * ni_coef_stride(nsf) * 8 : 0) + R * 4 + NI_GA * 4;
     const size_t scratch = (size_t)NI_GA * NI_RED * NI_REDROW * 8;
     if (!force && b < scratch) b = scratch;
     return (b + 15) / 16 * 16;
 }
 
-// flat pair index -> (a,b), a < b < n, rows a=0: (0,1)..(0,n-1), a=1: ...   start(r) = r(2n-r-1)/2.
-// The float estimate is within one row of the answer (all operands are integers below 2^24), so one
-// step down and one step up settle it without a loop.
-__device__ __forceinline__ void ni_decode_pair(int p, int n, int &a, int &b)
+// Pair enumeration of one atom over its 16 lanes, without decoding a flat index: item `it` is row
+// a = it mod n with partner (a + t) mod n, t = it / n + 1 = 1 .. n/2 (for even n the last offset only for
+// a < n/2, which is where the item count n(n-1)/2 ends) -- every unordered pair exactly once.  A lane's
+// items are l, l+16, l+32, ...: the step (16 mod n, 16 / n) is constant, so advancing costs a few adds.
+struct NiWalk { int a, t, da, dt, n; };
+__device__ __forceinline__ NiWalk ni_walk_init(int l, int n)
 {
-    const float fn = (float)(2 * n - 1);
-    int r = (int)((fn - sqrtf(fn * fn - 8.0f * (float)p)) * 0.5f);
-    r = max(0, min(r, n - 2));
-    if (r * (2 * n - r - 1) / 2 > p) r--;
-    if ((r + 1) * (2 * n - r - 2) / 2 <= p) r++;
-    a = r;
-    b = p - r * (2 * n - r - 1) / 2 + r + 1;
+    NiWalk w;
+    w.n = max(n, 1);
+    w.a = l % w.n; w.t = l / w.n + 1;
+    w.da = NI_GL % w.n; w.dt = NI_GL / w.n;
+    return w;
+}
+// current pair in list order (lo < hi), then step to this lane's next item
+__device__ __forceinline__ void ni_walk_next(NiWalk &w, int &lo, int &hi)
+{
+    int b = w.a + w.t;
+    if (b >= w.n) b -= w.n;
+    lo = min(w.a, b); hi = max(w.a, b);
+    w.a += w.da; w.t += w.dt;
+    if (w.a >= w.n) { w.a -= w.n; w.t += 1; }
 }
 
 // ---- per-function tables, prepared on the host (annp_hip_init) --------------------------
@@ -275,6 +284,17 @@ __device__ __forceinline__ void ni_force_cart(const NiConst &c, const double *cw
     double B[NE], D[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) { B[e] = 0.0; D[e] = 0.0; }
+    // Software-pipelined by hand: the weights and constants of step s+1 are read while step s computes, and a
+    // scheduling fence closes each step.  Left alone the compiler issues all LDS reads of the visit (and of
+    // the exponential after it) at the top and holds ~110 registers of operands.
+    double cc[NE], kp, kd;
+    auto fetch = [&](int l, int z) {
+#pragma unroll
+        for (int e = 0; e < NE; e++) cc[e] = cw[(l * NE + e) * NZ + z];
+        kp = c.K[NI_KP + z];
+        kd = c.K[NI_KD + 8 * l + z];
+    };
+    fetch(0, 0);
 #pragma unroll
     for (int l = 0; l < NL; l++) {
         const double u = fma(c.K[NI_KL + l], ct, 1.0);
@@ -285,14 +305,19 @@ __device__ __forceinline__ void ni_force_cart(const NiConst &c, const double *cw
         U[1] = U[0] * U[0]; U[2] = U[1] * U[1]; U[3] = U[2] * U[2]; U[4] = U[3] * U[3];
 #pragma unroll
         for (int z = 0; z < NZ; z++) {
-            const double pw = c.K[NI_KP + z] * ni_ladder_pow(U, U0, NI_BYTE(ZP, z));
-            const double dw = NI_BYTE(ZP, z) >= 1 ? c.K[NI_KD + 8 * l + z] * ni_ladder_pow(U, U0, NI_BYTE(ZP, z) - 1) : 0.0;
+            double c0[NE];
+#pragma unroll
+            for (int e = 0; e < NE; e++) c0[e] = cc[e];
+            const double pw = kp * ni_ladder_pow(U, U0, NI_BYTE(ZP, z));
+            const double dw = NI_BYTE(ZP, z) >= 1 ? kd * ni_ladder_pow(U, U0, NI_BYTE(ZP, z) - 1) : 0.0;
+            if (z + 1 < NZ) fetch(l, z + 1);
+            else if (l + 1 < NL) fetch(l + 1, 0);
 #pragma unroll
             for (int e = 0; e < NE; e++) {
-                const double cc = cw[(l * NE + e) * NZ + z];
-                B[e] = fma(cc, pw, B[e]);
-                D[e] = fma(cc, dw, D[e]);
+                B[e] = fma(c0[e], pw, B[e]);
+                D[e] = fma(c0[e], dw, D[e]);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     double E[NE];
@@ -310,7 +335,6 @@ struct NiLds {
     double *dx, *dy, *dz, *r, *rinv, *fc, *dfc;   // [NI_GA * cap] each, atom g at g*cap
     double *a0, *a1, *a2;                         // force accumulators (force pass)
     double *coef;                                 // [NI_GA][stride] weights: radial, then angular in visit order
-    double *ctr;                                  // [NI_GA][3] centres
     int *j;                                       // [NI_GA * cap]
     int *ci;                                      // [NI_GA] atom index of each group, -1 = none
 };
@@ -325,13 +349,18 @@ __device__ __forceinline__ NiLds ni_carve(unsigned char *wbase, int cap, int cst
     d = L.dfc + R;
     L.a0 = L.a1 = L.a2 = L.coef = nullptr;
     if (FORCE) { L.a0 = d; L.a1 = L.a0 + R; L.a2 = L.a1 + R; L.coef = L.a2 + R; d = L.coef + NI_GA * cstride; }
-    L.ctr = d; d += NI_GA * 3;
     L.j = reinterpret_cast<int *>(d);
     L.ci = L.j + R;
     return L;
 }
 
-__device__ __forceinline__ int sel4(int g, int v0, int v1, int v2, int v3) { return g == 0 ? v0 : g == 1 ? v1 : g == 2 ? v2 : v3; }
+__device__ __forceinline__ double readlane_f64(double v, int srclane)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), srclane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), srclane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 
 // Filter the list rows of atoms ii0 .. ii0+3 into the records.  Returns the largest in-range count of the
 // four (uniform; > p.n_cap means the records overflowed and must not be used); nl = count of this lane's atom.
@@ -342,75 +371,66 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
     // headers: lane g < 4 fetches atom g
     int hi = -1, hjn = 0;
     long long hbase = 0;
+    double hx = 0.0, hy = 0.0, hz = 0.0;
     if (lane < NI_GA) {
         const int ii = ii0 + lane;
         if (ii < p.inum) {
             hi = p.ilist ? p.ilist[ii] : ii;
             hjn = p.numneigh[hi];
             hbase = p.first[hi];
-            L.ctr[3 * lane] = p.x[3 * (size_t)hi]; L.ctr[3 * lane + 1] = p.x[3 * (size_t)hi + 1]; L.ctr[3 * lane + 2] = p.x[3 * (size_t)hi + 2];
-        } else {
-            L.ctr[3 * lane] = 0.0; L.ctr[3 * lane + 1] = 0.0; L.ctr[3 * lane + 2] = 0.0;
+            hx = p.x[3 * (size_t)hi]; hy = p.x[3 * (size_t)hi + 1]; hz = p.x[3 * (size_t)hi + 2];
         }
         L.ci[lane] = hi;
     }
-    int jn[NI_GA];
-    long long base[NI_GA];
-#pragma unroll
-    for (int g = 0; g < NI_GA; g++) {
-        jn[g] = __builtin_amdgcn_readlane(hjn, g);
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(hbase & 0xffffffffll), g);
-        const int hi32 = __builtin_amdgcn_readlane((int)(hbase >> 32), g);
-        base[g] = ((long long)hi32 << 32) | (long long)lo;
-    }
-    const int o1 = jn[0], o2 = o1 + jn[1], o3 = o2 + jn[2], total = o3 + jn[3];
     const double rcmax = fmax(p.rc_rad, p.rc_ang);
     const double rc2 = (rcmax / ANNP_CFLENGTH) * (rcmax / ANNP_CFLENGTH) * (1.0 + 1e-12);   // coarse filter in A^2
     const double pi_over_rc = ANNP_MY_PI / p.rc_ang;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    wave_lds_sync();
-    // first sweep: the four rows as one candidate stream, cheap distance filter, survivors compacted per
-    // atom in list order.  Four 64-candidate groups per trip keep the index loads, then the coordinate
-    // gathers, in flight together (only ~18 of ~224 candidates per row survive: this sweep is memory latency).
-    int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-    for (int c0 = 0; c0 < total; c0 += 256) {
-        int j[4], gl[4];
-        bool valid[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int c = c0 + 64 * u + lane;
-            valid[u] = c < total;
-            const int g = (c >= o1) + (c >= o2) + (c >= o3);
-            gl[u] = g;
-            const int off = c - sel4(g, 0, o1, o2, o3);
-            const long long b = g == 0 ? base[0] : g == 1 ? base[1] : g == 2 ? base[2] : base[3];
-            j[u] = valid[u] ? (p.neigh[b + off] & ANNP_NEIGHMASK) : 0;
-        }
-        double dx[4], dy[4], dz[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const double *ctr = L.ctr + 3 * gl[u];
-            dx[u] = ctr[0] - p.x[3 * (size_t)j[u]]; dy[u] = ctr[1] - p.x[3 * (size_t)j[u] + 1]; dz[u] = ctr[2] - p.x[3 * (size_t)j[u] + 2];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const double rsq = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
-            const bool in = valid[u] && rsq < rc2 && rsq > 0.0;
-            const unsigned long long m0 = __ballot(in && gl[u] == 0), m1 = __ballot(in && gl[u] == 1);
-            const unsigned long long m2 = __ballot(in && gl[u] == 2), m3 = __ballot(in && gl[u] == 3);
-            const unsigned long long mm = gl[u] == 0 ? m0 : gl[u] == 1 ? m1 : gl[u] == 2 ? m2 : m3;
-            const int pos = sel4(gl[u], n0, n1, n2, n3) + __popcll(mm & lt);
-            if (in && pos < cap) {
-                const int s = gl[u] * cap + pos;
-                L.dx[s] = dx[u]; L.dy[s] = dy[u]; L.dz[s] = dz[u]; L.r[s] = rsq; L.j[s] = j[u];
-            }
-            n0 += __popcll(m0); n1 += __popcll(m1); n2 += __popcll(m2); n3 += __popcll(m3);
-        }
-    }
-    n0 = uniform(n0); n1 = uniform(n1); n2 = uniform(n2); n3 = uniform(n3);
     const int g = lane >> 4, l = lane & 15;
-    nl = sel4(g, n0, n1, n2, n3);
-    const int nmax = max(max(n0, n1), max(n2, n3));
+    // first sweep, one row at a time (everything about the row is wave-uniform): cheap distance filter, survivors
+    // compacted in list order.  Four 64-candidate groups per trip keep the index loads, then the coordinate
+    // gathers, in flight together (only ~18 of ~224 candidates survive: this sweep is memory latency).
+    int nmax = 0;
+    nl = 0;
+    for (int ga = 0; ga < NI_GA; ga++) {
+        const int jn = __builtin_amdgcn_readlane(hjn, ga);
+        const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)(hbase & 0xffffffffll), ga);
+        const int bhi = __builtin_amdgcn_readlane((int)(hbase >> 32), ga);
+        const int *row = p.neigh + (((long long)bhi << 32) | (long long)blo);
+        const double xi = readlane_f64(hx, ga), yi = readlane_f64(hy, ga), zi = readlane_f64(hz, ga);
+        const int sb = ga * cap;
+        int n = 0;
+        for (int c0 = 0; c0 < jn; c0 += 256) {
+            int j[4];
+            bool valid[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int jj = c0 + 64 * u + lane;
+                valid[u] = jj < jn;
+                j[u] = valid[u] ? (row[jj] & ANNP_NEIGHMASK) : 0;
+            }
+            double dx[4], dy[4], dz[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                dx[u] = xi - p.x[3 * (size_t)j[u]]; dy[u] = yi - p.x[3 * (size_t)j[u] + 1]; dz[u] = zi - p.x[3 * (size_t)j[u] + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const double rsq = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
+                const bool in = valid[u] && rsq < rc2 && rsq > 0.0;
+                const unsigned long long m = __ballot(in);
+                const int pos = n + __popcll(m & lt);
+                if (in && pos < cap) {
+                    const int s = sb + pos;
+                    L.dx[s] = dx[u]; L.dy[s] = dy[u]; L.dz[s] = dz[u]; L.r[s] = rsq; L.j[s] = j[u];
+                }
+                n += __popcll(m);
+            }
+        }
+        n = uniform(n);
+        if (g == ga) nl = n;
+        nmax = max(nmax, n);
+    }
     if (nmax > cap) return nmax;
     if (lane < 2) {     // dummy records NI_GA*cap, +1: finite geometry, beyond every cutoff, never accumulated into
         const int s = NI_GA * cap + lane;
@@ -534,10 +554,11 @@ __global__ __launch_bounds__(256, NI_WAVES_PER_SIMD) void annp_ni_desc(NiArgs p)
     // G4 (ni:713-767): the atom's pairs over its 16 lanes
     const int npl = nl * (nl - 1) / 2;
     const int trips = (nmax * (nmax - 1) / 2 + NI_GL - 1) / NI_GL;
+    NiWalk walk = ni_walk_init(l, nl);
     for (int t = 0; t < trips; t++) {
         const int pp = t * NI_GL + l;
         int a, b;
-        ni_decode_pair(pp, nl, a, b);
+        ni_walk_next(walk, a, b);
         const bool live = pp < npl;
         const NiPairS q = ni_pair(L, kc, live ? sbase + a : NI_GA * cap, live ? sbase + b : NI_GA * cap + 1);
         const double r2sum = q.rjm * q.rjm + q.rkm * q.rkm + q.rgm * q.rgm;
@@ -616,27 +637,30 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
 
     const int npl = nl * (nl - 1) / 2;
     const int trips = (nmax * (nmax - 1) / 2 + NI_GL - 1) / NI_GL;
+    NiWalk walk = ni_walk_init(l, nl);
     for (int t = 0; t < trips; t++) {
         const int pp = t * NI_GL + l;
         int a, b;
-        ni_decode_pair(pp, nl, a, b);
+        ni_walk_next(walk, a, b);
         const bool lv = pp < npl;
         const int sa = lv ? sbase + a : NI_GA * cap, sb = lv ? sbase + b : NI_GA * cap + 1;
         const NiPairS q = ni_pair(L, kc, sa, sb);
         const double r2sum = q.rjm * q.rjm + q.rkm * q.rkm + q.rgm * q.rgm;
-        // A1 = sum c term1 CFLENGTH, A2 = sum c term2, A3 = sum c term3   (ni:752-754)
-        double A1 = 0.0, A2 = 0.0, A3 = 0.0;
-        ni_forget_lds();
-        if constexpr (NL > 0) ni_force_cart<NL, NE, NZ, ZP, EM>(kc, cw, q.ct, r2sum, A1, A2, A3);
-        else
-            ni_visit_functions<NT, true>(tab, p.ntsf, q.ct, r2sum, [&](int pos, double val, double dval) {
-                const double cc = cw[pos];
-                A3 = fma(cc, val, A3);
-                A2 = fma(cc * tab.sorted[4 * pos], val, A2);
-                A1 = fma(cc, dval, A1);
-            });
-        ni_forget_lds();
+        // everything below only matters for pairs inside the cutoffs; keeping the visit inside the branch also keeps
+        // its LDS reads next to their use (hoisted out, they would all be live across the branch)
         if (q.ok) {
+            // A1 = sum c term1 CFLENGTH, A2 = sum c term2, A3 = sum c term3   (ni:752-754)
+            double A1 = 0.0, A2 = 0.0, A3 = 0.0;
+            ni_forget_lds();
+            if constexpr (NL > 0) ni_force_cart<NL, NE, NZ, ZP, EM>(kc, cw, q.ct, r2sum, A1, A2, A3);
+            else
+                ni_visit_functions<NT, true>(tab, p.ntsf, q.ct, r2sum, [&](int pos, double val, double dval) {
+                    const double cc = cw[pos];
+                    A3 = fma(cc, val, A3);
+                    A2 = fma(cc * tab.sorted[4 * pos], val, A2);
+                    A1 = fma(cc, dval, A1);
+                });
+            ni_forget_lds();
             A1 *= q.tfc * kc.K[NI_KM + 3];
             A2 *= q.tfc;
             const double rx = p.compat ? q.rkm : q.rgm;       // ni:737-738 vs lal_annp.cu:409-414
