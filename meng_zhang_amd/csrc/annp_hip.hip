@@ -59,7 +59,7 @@ struct annp_hip_handle {
     std::vector<double> sym_rad, sym_ang;
     // work buffers
     DevBuf<double> G, coef, x, f, eatom, vatom;
-    DevBuf<int> type, ilist, numneigh, neigh, ncount;
+    DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr;
     DevBuf<long long> first;
     double *d_scalars = nullptr;        // [0] energy, [1..6] virial
     int *d_flags = nullptr;             // [0] capacity-overflow max n, [1] max in-cutoff n
@@ -229,6 +229,8 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         const int cap_max = ni_max_cap(true, h->nsf);
         for (int attempt = 0;; attempt++) {
             a.n_cap = std::min(h->ni_cap, cap_max);
+            if ((rc = ensure(h, h->ni_nbr, (size_t)inum * a.n_cap))) return rc;
+            a.nbr = h->ni_nbr.p; a.nbr_stride = a.n_cap;
             ni_launch_desc(a, h->ni_shape, s);
             HIP_TRY(h, hipGetLastError());
             hipLaunchKernelGGL(annp_max_int, dim3(std::min(1024, (inum + 255) / 256)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
@@ -294,7 +296,7 @@ void annp_hip_clear(annp_hip_handle *h)
     if (h->d_isym) (void)hipFree(h->d_isym);
     if (h->d_coefmat) (void)hipFree(h->d_coefmat);
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom); release(h, h->vatom);
-    release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount);
+    release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr);
     release(h, h->first);
     neigh_release(h->nb);
     if (h->d_scalars) (void)hipFree(h->d_scalars);

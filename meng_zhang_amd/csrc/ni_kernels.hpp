@@ -54,7 +54,9 @@ struct NiArgs {
     double *f;
     double *virial;
     double *vatom;              // nullable, [nall][6] accumulated (VIRIAL variant)
-    int *ncount;
+    int *ncount;                // [inum] in-range neighbours found by the descriptor pass
+    int *nbr;                   // [inum][nbr_stride] their indices, in list order (written by pass 1, read by pass 3)
+    int nbr_stride;
     int *errflag;
 };
 
@@ -461,6 +463,60 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
     return nmax;
 }
 
+// Force pass: rebuild the records from the compact lists the descriptor pass left (same entries, same order).
+__device__ __forceinline__ int ni_stage_compact(const NiArgs &p, int ii0, const NiLds &L, const double *T, int lane, int &nl)
+{
+    const int cap = p.n_cap;
+    int hi = -1, hn = 0;
+    double hx = 0.0, hy = 0.0, hz = 0.0;
+    if (lane < NI_GA) {
+        const int ii = ii0 + lane;
+        if (ii < p.inum) {
+            hi = p.ilist ? p.ilist[ii] : ii;
+            hn = p.ncount[ii];
+            hx = p.x[3 * (size_t)hi]; hy = p.x[3 * (size_t)hi + 1]; hz = p.x[3 * (size_t)hi + 2];
+        }
+        L.ci[lane] = hi;
+    }
+    const int g = lane >> 4, l = lane & 15;
+    nl = __shfl(hn, g, 64);
+    const double xi = __shfl(hx, g, 64), yi = __shfl(hy, g, 64), zi = __shfl(hz, g, 64);
+    int nmax = 0;
+#pragma unroll
+    for (int ga = 0; ga < NI_GA; ga++) nmax = max(nmax, __builtin_amdgcn_readlane(hn, ga));
+    if (nmax > cap) return nmax;
+    const double pi_over_rc = ANNP_MY_PI / p.rc_ang;
+    if (lane < 2) {     // dummy records, as in ni_stage
+        const int s = NI_GA * cap + lane;
+        L.dx[s] = lane == 0 ? 1.0 : 0.0; L.dy[s] = lane == 0 ? 0.0 : 1.0; L.dz[s] = 0.0;
+        L.r[s] = 1e3; L.rinv[s] = 1e-3; L.fc[s] = 0.0; L.dfc[s] = 0.0;
+    }
+    wave_lds_sync();        // math table and coefficient rows written above are visible from here on
+    const int *row = p.nbr + (size_t)(ii0 + g) * p.nbr_stride;
+    for (int a = l; a < nmax; a += NI_GL) {
+        if (a < nl) {
+            const int s = g * cap + a;
+            const int j = row[a];
+            const double dx = xi - p.x[3 * (size_t)j], dy = yi - p.x[3 * (size_t)j + 1], dz = zi - p.x[3 * (size_t)j + 2];
+            const double rsq = dx * dx + dy * dy + dz * dz;
+            const double rinv = fast_rsqrt_ic(rsq);
+            const double r = rsq * rinv;
+            const double rm = r * ANNP_CFLENGTH;
+            double fc = 0.0, dfc = 0.0;
+            if (rm < p.rc_ang) {
+                double sn, cs;
+                sincos_0_pi_tab(pi_over_rc * rm, T, sn, cs);
+                fc = 0.5 * (cs + 1.0);
+                dfc = -0.5 * pi_over_rc * sn;
+            }
+            L.dx[s] = dx; L.dy[s] = dy; L.dz[s] = dz; L.j[s] = j;
+            L.r[s] = r; L.rinv[s] = rinv; L.fc[s] = fc; L.dfc[s] = dfc;
+            L.a0[s] = 0.0; L.a1[s] = 0.0; L.a2[s] = 0.0;
+        }
+    }
+    return nmax;
+}
+
 // What the function visit needs of one (j,k) pair around the centre: cos(theta), the three distances (Bohr)
 // and the product of the cutoff functions.  The force pass re-reads the records for the vectors afterwards
 // (LDS reads are cheap; holding them across the 24-function visit costs the registers of a whole wave slot).
@@ -533,6 +589,8 @@ __global__ __launch_bounds__(256, NI_WAVES_PER_SIMD) void annp_ni_desc(NiArgs p)
     }
     wave_lds_sync();
     const int sbase = g * cap;
+    // the survivors, for the force pass (which then need not filter the full list rows again)
+    for (int a = l; a < nl; a += NI_GL) p.nbr[(size_t)(ii0 + g) * p.nbr_stride + a] = L.j[sbase + a];
 
     double gr[NP], ga[NT];
 #pragma unroll
@@ -628,7 +686,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
         L.coef[gq * cstride + k] = v;
     }
     int nl;
-    const int nmax = ni_stage<true>(p, ii0, L, T, lane, nl);
+    const int nmax = ni_stage_compact(p, ii0, L, T, lane, nl);
     if (nmax > cap) { if (lane == 0) atomicMax(p.errflag, nmax); return; }
     wave_lds_sync();
     const double *cr = L.coef + g * cstride;        // radial weights of this lane's atom
