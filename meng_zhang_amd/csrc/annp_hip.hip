@@ -49,10 +49,8 @@ struct annp_hip_handle {
     int ni_cap_last = 0;                // ... and what the last force pass ran with
     int flagact[MLP_MAXL] = {0, 0, 0, 0};
     double e_scale = 0, e_shift = 0, e_atom = 0, cut = 0, cutsq = 0;
-    double *dW[MLP_MAXL] = {nullptr, nullptr, nullptr, nullptr};
-    double *dB[MLP_MAXL] = {nullptr, nullptr, nullptr, nullptr};
     double *d_norm = nullptr;           // nmul | nsub | nden, ANNP_GPAD each
-    double *d_coefmat = nullptr;        // [ANNP_CPAD][nnod]: coef = coefmat . dE/dZ_0 (network pass epilogue)
+    double *d_mlp_img = nullptr;        // network pass: MFMA operand image (weights, biases, coefmat), mlp_build_image
     double *d_sym = nullptr;            // BEHLER: function tables (ni_kernels.hpp, "per-function tables")
     int *d_isym = nullptr;
     NiShape ni_shape = {0, 0, 0};       // {lambda} x {eta} x {zeta} product shape of the angular set (0 = none)
@@ -141,14 +139,35 @@ int launch_mlp(annp_hip_handle *h, const MlpArgs &a, hipStream_t s)
     return 0;
 }
 
+// (KS0, MT, NL) the network pass is compiled for: nsf <= 28 or 32 inputs, nnod <= 16 or 32 nodes, 2..4 weight layers
+#define ANNP_MLP_SHAPES(X) X(7, 1, 2) X(7, 1, 3) X(7, 1, 4) X(7, 2, 2) X(7, 2, 3) X(7, 2, 4) \
+                           X(8, 1, 2) X(8, 1, 3) X(8, 1, 4) X(8, 2, 2) X(8, 2, 3) X(8, 2, 4)
+void mlp_shape(const annp_hip_handle *h, int &ks0, int &mt) { ks0 = h->nsf <= 28 ? 7 : 8; mt = h->nnod <= 16 ? 1 : 2; }
+
 int run_mlp(annp_hip_handle *h, const MlpArgs &a, hipStream_t s)
 {
-    const int ks0 = (h->nsf + 3) / 4, mt = (h->nnod + 15) / 16;
-    if (h->nl == 3 && ks0 == 7 && mt == 1) return launch_mlp<7, 1, 3>(h, a, s);
-    if (h->nl == 3 && ks0 == 7 && mt == 2) return launch_mlp<7, 2, 3>(h, a, s);
-    if (h->nl == 3 && ks0 == 8 && mt == 1) return launch_mlp<8, 1, 3>(h, a, s);
-    if (h->nl == 3 && ks0 == 8 && mt == 2) return launch_mlp<8, 2, 3>(h, a, s);
+    int ks0, mt;
+    mlp_shape(h, ks0, mt);
+#define X(K, M, L) if (ks0 == K && mt == M && h->nl == L) return launch_mlp<K, M, L>(h, a, s);
+    ANNP_MLP_SHAPES(X)
+#undef X
     return fail(h, ANNP_HIP_ESHAPE, "no network kernel for nsf=%d nnod=%d layers=%d", h->nsf, h->nnod, h->nl);
+}
+
+// operand image of the network pass for this handle's shape (empty when the shape is not compiled)
+std::vector<double> mlp_image(const annp_hip_handle *h, const double *const *W, const double *const *B, const double *coefmat)
+{
+    int ks0, mt;
+    mlp_shape(h, ks0, mt);
+    std::vector<double> img;
+#define X(K, M, L)                                                                         \
+    if (ks0 == K && mt == M && h->nl == L) {                                               \
+        img.resize((size_t)MlpSlots<K, M, L>::total * 64);                                 \
+        mlp_build_image<K, M, L>(img.data(), W, B, coefmat, h->nsf, h->nnod);              \
+    }
+    ANNP_MLP_SHAPES(X)
+#undef X
+    return img;
 }
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -174,8 +193,8 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
 
     MlpArgs m{};
     m.inum = inum; m.ilist = d_ilist; m.nsf = h->nsf; m.nnod = h->nnod; m.nl = h->nl;
-    for (int l = 0; l < h->nl; l++) { m.act[l] = h->flagact[l]; m.W[l] = h->dW[l]; m.B[l] = h->dB[l]; }
-    m.nmul = h->d_norm; m.nsub = h->d_norm + ANNP_GPAD; m.nden = h->d_norm + 2 * ANNP_GPAD; m.coefmat = h->d_coefmat;
+    for (int l = 0; l < h->nl; l++) m.act[l] = h->flagact[l];
+    m.nmul = h->d_norm; m.nsub = h->d_norm + ANNP_GPAD; m.nden = h->d_norm + 2 * ANNP_GPAD; m.img = h->d_mlp_img;
     m.e_scale = h->e_scale; m.e_shift = h->e_shift; m.e_atom = h->e_atom;
     m.G = h->G.p; m.coef = h->coef.p; m.eatom = d_eatom; m.eng = d_eng;
 
@@ -290,11 +309,10 @@ void annp_hip_clear(annp_hip_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (int l = 0; l < MLP_MAXL; l++) { if (h->dW[l]) (void)hipFree(h->dW[l]); if (h->dB[l]) (void)hipFree(h->dB[l]); }
     if (h->d_norm) (void)hipFree(h->d_norm);
     if (h->d_sym) (void)hipFree(h->d_sym);
     if (h->d_isym) (void)hipFree(h->d_isym);
-    if (h->d_coefmat) (void)hipFree(h->d_coefmat);
+    if (h->d_mlp_img) (void)hipFree(h->d_mlp_img);
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom); release(h, h->vatom);
     release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr);
     release(h, h->first);
@@ -353,14 +371,6 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     h->cutsq = p->cutsq ? p->cutsq[(p->ntypes + 1) * 1 + 1] : p->cut * p->cut;
     for (int l = 0; l < nl; l++) h->flagact[l] = p->flagact[l];
 
-    for (int l = 0; l < nl; l++) {
-        const int nr = (l == nl - 1) ? 1 : p->nnod, nc = (l == 0) ? p->nsf : p->nnod;
-        INIT_TRY(hipMalloc((void **)&h->dW[l], sizeof(double) * nr * nc));
-        INIT_TRY(hipMalloc((void **)&h->dB[l], sizeof(double) * nr));
-        INIT_TRY(hipMemcpy(h->dW[l], p->weight_all[l], sizeof(double) * nr * nc, hipMemcpyHostToDevice));
-        INIT_TRY(hipMemcpy(h->dB[l], p->bias_all[l], sizeof(double) * nr, hipMemcpyHostToDevice));
-        h->bytes += sizeof(double) * (nr * nc + nr);
-    }
     {   // normalisation of the descriptor and the linear map dE/dZ_0 -> coef
         std::vector<double> t(3 * ANNP_GPAD, 0.0), cmul(ANNP_GPAD, 0.0);
         for (int k = 0; k < ANNP_GPAD; k++) t[2 * ANNP_GPAD + k] = 1.0;
@@ -375,7 +385,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
                 // Ghat = (G - sf_min)/(sf_max - sf_min) (ni:168-170);  F = -dE/dGhat dG / (sf_max-sf_min) * CFFORCE (ni:186-189)
                 t[k] = 1.0;
                 t[ANNP_GPAD + k] = p->sfnor_avg[k];
-                t[2 * ANNP_GPAD + k] = p->sfnor_scal[k];
+                t[2 * ANNP_GPAD + k] = 1.0 / p->sfnor_scal[k];
                 cmul[k] = 1.0 / p->sfnor_scal[k];
             }
         }
@@ -415,9 +425,11 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
                 for (int k = 0; k < nsf; k++) acc += T[(size_t)o * nsf + k] * (long double)cmul[k] * (long double)p->weight_all[0][(size_t)i * nsf + k];
                 cm[(size_t)o * nnod + i] = (double)acc;
             }
-        INIT_TRY(hipMalloc((void **)&h->d_coefmat, sizeof(double) * cm.size()));
-        INIT_TRY(hipMemcpy(h->d_coefmat, cm.data(), sizeof(double) * cm.size(), hipMemcpyHostToDevice));
-        h->bytes += sizeof(double) * cm.size();
+        const std::vector<double> img = mlp_image(h, p->weight_all, p->bias_all, cm.data());
+        if (img.empty()) { fail(h, 0, "no network kernel for nsf=%d nnod=%d layers=%d", h->nsf, h->nnod, h->nl); return bail(ANNP_HIP_ESHAPE); }
+        INIT_TRY(hipMalloc((void **)&h->d_mlp_img, sizeof(double) * img.size()));
+        INIT_TRY(hipMemcpy(h->d_mlp_img, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
+        h->bytes += sizeof(double) * img.size();
     }
     if (p->descriptor == ANNP_HIP_DESC_BEHLER) {
         h->sym_rad.assign(p->cofsymrad, p->cofsymrad + 3 * p->npsf);

@@ -38,10 +38,8 @@ struct MlpArgs {
     int nsf, nnod, nl;            // nl = ntl-1 weight layers
     int act[MLP_MAXL];
     int act_plain;                // ni: activations 3,4 are plain tanh
-    const double *W[MLP_MAXL];    // device, row-major [d_{l+1}][d_l]
-    const double *B[MLP_MAXL];
-    const double *nmul, *nsub, *nden;   // [ANNP_GPAD] normalisation: Ghat = (raw*nmul - nsub)/nden
-    const double *coefmat;              // [ANNP_CPAD][nnod] row-major: coef = coefmat . dE/dZ_0
+    const double *img;            // device: the MFMA operand image, [MlpSlots::total][64] (mlp_build_image)
+    const double *nmul, *nsub, *nden;   // [ANNP_GPAD] normalisation: Ghat = (raw*nmul - nsub) * nden (nden: reciprocal range)
     double e_scale, e_shift, e_atom;
     int energy_raw;               // ni: E_i = network output (ni:858-860)
     const double *G;              // [inum][ANNP_GPAD]
@@ -50,15 +48,57 @@ struct MlpArgs {
     double *eng;                  // nullable, one double
 };
 
-// fe_v2/src/pair_annp.cpp:709-739 (ni variant: ni/src/pair_annp.cpp:781-808)
-__device__ __forceinline__ void activation(int flag, int plain, double a, double &h, double &dh)
+// tanh(y) to a few ulp without libm's branches: e^{-2|y|} = 2^k (1 + q), q = expm1 of the reduced argument, so
+// that e - 1 is formed without cancellation where it matters (k = 0), then tanh|y| = -(e - 1) / (2 + (e - 1)).
+__device__ __forceinline__ double tanh_fast(double y)
+{
+    const double x = fmax(-2.0 * fabs(y), -80.0);          // <= 0; e^-80 is already far below one ulp of 1
+    const double kf = rint(x * 1.4426950408889634074);
+    double r = fma(-kf, 6.93147180369123816490e-01, x);
+    r = fma(-kf, 1.90821492927058770002e-10, r);
+    double q = 1.0 / 6227020800.0;                          // r^13/13! ... : q = e^r - 1
+    q = fma(q, r, 1.0 / 479001600.0);
+    q = fma(q, r, 1.0 / 39916800.0);
+    q = fma(q, r, 1.0 / 3628800.0);
+    q = fma(q, r, 1.0 / 362880.0);
+    q = fma(q, r, 1.0 / 40320.0);
+    q = fma(q, r, 1.0 / 5040.0);
+    q = fma(q, r, 1.0 / 720.0);
+    q = fma(q, r, 1.0 / 120.0);
+    q = fma(q, r, 1.0 / 24.0);
+    q = fma(q, r, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = q * r;
+    const int k = (int)kf;
+    const double em1 = (k == 0) ? q : __builtin_ldexp(1.0 + q, k) - 1.0;
+    const double t = -em1 / (2.0 + em1);
+    return copysign(t, y);
+}
+
+// Activations of fe_v2/src/pair_annp.cpp:709-739 (ni variant: ni/src/pair_annp.cpp:781-808), all written on one
+// tanh so that a layer's flag only selects five wave-uniform numbers:
+//     h = A tanh(s a) + C a + D,    dh = P (1 - tanh^2(s a)) + C
+//   0 linear                      A 0       s 0    C 1    D 0    P 0
+//   1 tanh (ni: also 3, 4)        A 1       s 1    C 0    D 0    P 1
+//   2 1/(1+exp(+a)) (sic, 715)    A -1/2    s 1/2  C 0    D 1/2  P +1/4   (the reference's derivative h(1-h), sign as written there)
+//   3 1.7159 tanh(2a/3)           A 1.7159  s 2/3  C 0    D 0    P 1.7159*2/3
+//   4 ... + 0.1 a                 A 1.7159  s 2/3  C 0.1  D 0    P 1.7159*2/3
+struct ActParam { double A, s, C, D, P; };
+__host__ __device__ inline ActParam act_param(int flag, int plain)
 {
     const double ca = 1.7159, cb = 0.666666666666667, cc = 0.1;
-    if (flag == 0) { h = a; dh = 1.0; }
-    else if (flag == 1 || (plain && flag >= 3)) { const double t = tanh(a); h = t; dh = 1.0 - t * t; }
-    else if (flag == 2) { h = 1.0 / (1.0 + exp(a)); dh = h * (1.0 - h); }
-    else if (flag == 3) { const double t = tanh(cb * a); h = ca * t; dh = ca * (1.0 - t * t) * cb; }
-    else { const double t = tanh(cb * a); h = ca * t + cc * a; dh = ca * (1.0 - t * t) * cb + cc; }
+    if (flag == 0) return ActParam{0.0, 0.0, 1.0, 0.0, 0.0};
+    if (flag == 1 || (plain && flag >= 3)) return ActParam{1.0, 1.0, 0.0, 0.0, 1.0};
+    if (flag == 2) return ActParam{-0.5, 0.5, 0.0, 0.5, 0.25};
+    if (flag == 3) return ActParam{ca, cb, 0.0, 0.0, ca * cb};
+    return ActParam{ca, cb, cc, 0.0, ca * cb};
+}
+__device__ __forceinline__ void activation(const ActParam &q, double a, double &h, double &dh)
+{
+    const double t = tanh_fast(q.s * a);
+    h = fma(q.A, t, fma(q.C, a, q.D));
+    dh = fma(q.P, fma(-t, t, 1.0), q.C);
 }
 
 __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c)
@@ -81,6 +121,55 @@ struct MlpSlots {
     static constexpr int total = bias + (NL - 1) * MT * 4 + 4;
 };
 
+// Host side: lay the weights out as the A operands of the MFMA chains, one double per lane and slot.
+// W[l] row-major [d_{l+1}][d_l], B[l], coefmat [ANNP_CPAD][nnod] row-major (coef = coefmat . dE/dZ_0).
+template <int KS0, int MT, int NL>
+inline void mlp_build_image(double *img, const double *const *W, const double *const *B, const double *coefmat, int nsf, int nnod)
+{
+    using S = MlpSlots<KS0, MT, NL>;
+    constexpr int KSH = S::KSH;
+    for (int slot = 0; slot < S::total; slot++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int lr = lane & 15, lq = lane >> 4;
+            double v = 0.0;
+            if (slot < S::fwdh) {                                   // fwd layer 0: W0[16mt+lr][4s+lq]
+                const int mt = slot / KS0, s = slot % KS0;
+                const int r = 16 * mt + lr, c = 4 * s + lq;
+                if (r < nnod && c < nsf) v = W[0][r * nsf + c];
+            } else if (slot < S::fwdo) {                            // fwd hidden l
+                const int q = slot - S::fwdh;
+                const int l = 1 + q / (MT * KSH), mt = (q / KSH) % MT, s = q % KSH;
+                const int r = 16 * mt + lr, c = 4 * s + lq;
+                if (r < nnod && c < nnod) v = W[l][r * nnod + c];
+            } else if (slot < S::bwdo) {                            // fwd output: W_last[lr][4s+lq]
+                const int s = slot - S::fwdo;
+                const int c = 4 * s + lq;
+                if (lr == 0 && c < nnod) v = W[NL - 1][c];
+            } else if (slot < S::bwdh) {                            // bwd output: W_last^T[16mt+lr][lq]
+                const int mt = slot - S::bwdo;
+                const int r = 16 * mt + lr;
+                if (lq == 0 && r < nnod) v = W[NL - 1][r];
+            } else if (slot < S::bwd0) {                            // bwd hidden l: W_l[4s+lq][16mt+lr]
+                const int q = slot - S::bwdh;
+                const int l = (NL - 2) - q / (MT * KSH), mt = (q / KSH) % MT, s = q % KSH;
+                const int r = 4 * s + lq, c = 16 * mt + lr;
+                if (r < nnod && c < nnod) v = W[l][r * nnod + c];
+            } else if (slot < S::bias) {                            // coef rows: coefmat[16mt+lr][4s+lq]
+                const int q = slot - S::bwd0;
+                const int mt = q / KSH, s = q % KSH;
+                const int r = 16 * mt + lr, c = 4 * s + lq;
+                if (r < ANNP_CPAD && c < nnod) v = coefmat[r * nnod + c];
+            } else {                                                // bias in C layout: row 16mt+lq+4r
+                const int q = slot - S::bias;
+                const int l = q / (MT * 4), mt = (q / 4) % MT, r = q % 4;
+                const int row = 16 * mt + lq + 4 * r;
+                if (l < NL - 1) { if (row < nnod) v = B[l][row]; }
+                else if (row == 0) v = B[NL - 1][0];
+            }
+            img[(size_t)slot * 64 + lane] = v;
+        }
+}
+
 template <int KS0, int MT, int NL>
 __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
 {
@@ -93,49 +182,19 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int nsf = p.nsf, nnod = p.nnod;
+    const int nsf = p.nsf;
 
-    // ---- stage the weights once per block, already in A-fragment order
-    for (int slot = wave; slot < S::total; slot += ANNP_WAVES_PER_BLOCK) {
-        double v = 0.0;
-        if (slot < S::fwdh) {                                   // fwd layer 0: W0[16mt+lr][4s+lq]
-            const int mt = slot / KS0, s = slot % KS0;
-            const int r = 16 * mt + lr, c = 4 * s + lq;
-            if (r < nnod && c < nsf) v = p.W[0][r * nsf + c];
-        } else if (slot < S::fwdo) {                            // fwd hidden l
-            const int q = slot - S::fwdh;
-            const int l = 1 + q / (MT * KSH), mt = (q / KSH) % MT, s = q % KSH;
-            const int r = 16 * mt + lr, c = 4 * s + lq;
-            if (r < nnod && c < nnod) v = p.W[l][r * nnod + c];
-        } else if (slot < S::bwdo) {                            // fwd output: W_last[lr][4s+lq]
-            const int s = slot - S::fwdo;
-            const int c = 4 * s + lq;
-            if (lr == 0 && c < nnod) v = p.W[NL - 1][c];
-        } else if (slot < S::bwdh) {                            // bwd output: W_last^T[16mt+lr][lq]
-            const int mt = slot - S::bwdo;
-            const int r = 16 * mt + lr;
-            if (lq == 0 && r < nnod) v = p.W[NL - 1][r];
-        } else if (slot < S::bwd0) {                            // bwd hidden l: W_l[4s+lq][16mt+lr]
-            const int q = slot - S::bwdh;
-            const int l = (NL - 2) - q / (MT * KSH), mt = (q / KSH) % MT, s = q % KSH;
-            const int r = 4 * s + lq, c = 16 * mt + lr;
-            if (r < nnod && c < nnod) v = p.W[l][r * nnod + c];
-        } else if (slot < S::bias) {                            // coef rows: coefmat[16mt+lr][4s+lq]
-            const int q = slot - S::bwd0;
-            const int mt = q / KSH, s = q % KSH;
-            const int r = 16 * mt + lr, c = 4 * s + lq;
-            if (r < ANNP_CPAD && c < nnod) v = p.coefmat[r * nnod + c];
-        } else {                                                // bias in C layout: row 16mt+lq+4r
-            const int q = slot - S::bias;
-            const int l = q / (MT * 4), mt = (q / 4) % MT, r = q % 4;
-            const int row = 16 * mt + lq + 4 * r;
-            if (l < NL - 1) { if (row < nnod) v = p.B[l][row]; }
-            else if (row == 0) v = p.B[NL - 1][0];
-        }
-        opnd[(size_t)slot * 64 + lane] = v;
+    // ---- the operand image (weights already in A-fragment order, built once by the host) -> LDS
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(p.img);
+        double2 *dst = reinterpret_cast<double2 *>(opnd);
+        for (int idx = threadIdx.x; idx < S::total * 32; idx += 256) dst[idx] = src[idx];
     }
     __syncthreads();
     double *cbuf = cbuf_all + (size_t)wave * 16 * ANNP_CPAD;
+    ActParam ap[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) ap[l] = act_param(p.act[l], p.act_plain);
 
     double e_wave = 0.0;
     const int ntiles = (p.inum + 15) / 16;
@@ -152,7 +211,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
             double g = 0.0;
             if (aval && k < nsf) {
                 const double raw = p.G[(size_t)ia * ANNP_GPAD + k];
-                g = fma(raw, p.nmul[k], -p.nsub[k]) / p.nden[k];
+                g = fma(raw, p.nmul[k], -p.nsub[k]) * p.nden[k];
             }
             hin[s] = g;
         }
@@ -166,7 +225,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
 #pragma unroll
             for (int s = 0; s < KS0; s++) acc = mfma_f64(opnd[(size_t)(S::fwd0 + mt * KS0 + s) * 64 + lane], hin[s], acc);
 #pragma unroll
-            for (int r = 0; r < 4; r++) { double h, d; activation(p.act[0], p.act_plain, acc[r], h, d); H[0][mt][r] = h; D[0][mt][r] = d; }
+            for (int r = 0; r < 4; r++) { double h, d; activation(ap[0], acc[r], h, d); H[0][mt][r] = h; D[0][mt][r] = d; }
         }
 #pragma unroll
         for (int l = 1; l < NL - 1; l++) {
@@ -179,7 +238,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
                 for (int s = 0; s < KSH; s++)
                     acc = mfma_f64(opnd[(size_t)(S::fwdh + ((l - 1) * MT + mt) * KSH + s) * 64 + lane], H[l - 1][s / 4][s % 4], acc);
 #pragma unroll
-                for (int r = 0; r < 4; r++) { double h, d; activation(p.act[l], p.act_plain, acc[r], h, d); H[l][mt][r] = h; D[l][mt][r] = d; }
+                for (int r = 0; r < 4; r++) { double h, d; activation(ap[l], acc[r], h, d); H[l][mt][r] = h; D[l][mt][r] = d; }
             }
         }
         double4_t zo;
@@ -190,7 +249,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
             for (int s = 0; s < KSH; s++) zo = mfma_f64(opnd[(size_t)(S::fwdo + s) * 64 + lane], H[NL - 2][s / 4][s % 4], zo);
         }
         double out, dout;
-        activation(p.act[NL - 1], p.act_plain, zo[0], out, dout);   // row 0 lives in reg 0 of lanes 0..15
+        activation(ap[NL - 1], zo[0], out, dout);   // row 0 lives in reg 0 of lanes 0..15
 
         // ---- energy (fe:790-793 / ni:858-860)
         if (lq == 0 && aval) {
