@@ -44,6 +44,7 @@ struct annp_hip_handle {
     std::string err;
     // parameters (copied at init)
     int descriptor = 0, ntypes = 1, ntl = 0, nhl = 0, nnod = 0, nsf = 0, npsf = 0, ntsf = 0, nl = 0;
+    int nsf_dev = 0;                    // features in the device layout (Chebyshev: always 9 + 19 slots, unused ones carry zero weights)
     int ni_compat = 0;
     int ni_cap = 24;                    // Behler kernels: record capacity per atom for the next descriptor pass
     int ni_cap_last = 0;                // ... and what the last force pass ran with
@@ -142,7 +143,7 @@ int launch_mlp(annp_hip_handle *h, const MlpArgs &a, hipStream_t s)
 // (KS0, MT, NL) the network pass is compiled for: nsf <= 28 or 32 inputs, nnod <= 16 or 32 nodes, 2..4 weight layers
 #define ANNP_MLP_SHAPES(X) X(7, 1, 2) X(7, 1, 3) X(7, 1, 4) X(7, 2, 2) X(7, 2, 3) X(7, 2, 4) \
                            X(8, 1, 2) X(8, 1, 3) X(8, 1, 4) X(8, 2, 2) X(8, 2, 3) X(8, 2, 4)
-void mlp_shape(const annp_hip_handle *h, int &ks0, int &mt) { ks0 = h->nsf <= 28 ? 7 : 8; mt = h->nnod <= 16 ? 1 : 2; }
+void mlp_shape(const annp_hip_handle *h, int &ks0, int &mt) { ks0 = h->nsf_dev <= 28 ? 7 : 8; mt = h->nnod <= 16 ? 1 : 2; }
 
 int run_mlp(annp_hip_handle *h, const MlpArgs &a, hipStream_t s)
 {
@@ -163,7 +164,7 @@ std::vector<double> mlp_image(const annp_hip_handle *h, const double *const *W, 
 #define X(K, M, L)                                                                         \
     if (ks0 == K && mt == M && h->nl == L) {                                               \
         img.resize((size_t)MlpSlots<K, M, L>::total * 64);                                 \
-        mlp_build_image<K, M, L>(img.data(), W, B, coefmat, h->nsf, h->nnod);              \
+        mlp_build_image<K, M, L>(img.data(), W, B, coefmat, h->nsf_dev, h->nnod);              \
     }
     ANNP_MLP_SHAPES(X)
 #undef X
@@ -192,15 +193,13 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     const int cap_list = std::max(16, round_up(max_numneigh, 16));
 
     MlpArgs m{};
-    m.inum = inum; m.ilist = d_ilist; m.nsf = h->nsf; m.nnod = h->nnod; m.nl = h->nl;
+    m.inum = inum; m.ilist = d_ilist; m.nsf = h->nsf_dev; m.nnod = h->nnod; m.nl = h->nl;
     for (int l = 0; l < h->nl; l++) m.act[l] = h->flagact[l];
     m.nmul = h->d_norm; m.nsub = h->d_norm + ANNP_GPAD; m.nden = h->d_norm + 2 * ANNP_GPAD; m.img = h->d_mlp_img;
     m.e_scale = h->e_scale; m.e_shift = h->e_shift; m.e_atom = h->e_atom;
     m.G = h->G.p; m.coef = h->coef.p; m.eatom = d_eatom; m.eng = d_eng;
 
     if (h->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
-        if (!(h->npsf == 9 && h->ntsf == 19))
-            return fail(h, ANNP_HIP_ESHAPE, "Chebyshev kernels are built for npsf=9 ntsf=19 (got %d %d)", h->npsf, h->ntsf);
         FeArgs a{};
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
         a.cutsq = h->cutsq; a.rc_list = std::sqrt(h->cutsq); a.rc_par = h->cut;
@@ -210,7 +209,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.n_cap = cap_list;
         size_t lds1 = fe_desc_lds_per_wave(a.n_cap) * ANNP_WAVES_PER_BLOCK;
         if (lds1 > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "neighbour list too long for LDS (%d)", max_numneigh);
-        hipLaunchKernelGGL((annp_fe_desc<9, 19>), dim3(blocks), dim3(256), lds1, s, a);
+        hipLaunchKernelGGL((annp_fe_desc<FE_NP, FE_NT>), dim3(blocks), dim3(256), lds1, s, a);
         HIP_TRY(h, hipGetLastError());
         hipLaunchKernelGGL(annp_max_int, dim3(std::min(1024, (inum + 255) / 256)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
         HIP_TRY(h, hipGetLastError());
@@ -229,11 +228,11 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         if (lds3 > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "too many in-cutoff neighbours for LDS (%d)", h->h_flags[1]);
         const bool vir = d_virial || d_vatom;
         if (fe_force_auxreg(a.n_cap)) {
-            if (vir) hipLaunchKernelGGL((annp_fe_force<9, 19, true, true>), dim3(blocks), dim3(256), lds3, s, a);
-            else hipLaunchKernelGGL((annp_fe_force<9, 19, false, true>), dim3(blocks), dim3(256), lds3, s, a);
+            if (vir) hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, true, true>), dim3(blocks), dim3(256), lds3, s, a);
+            else hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, false, true>), dim3(blocks), dim3(256), lds3, s, a);
         } else {
-            if (vir) hipLaunchKernelGGL((annp_fe_force<9, 19, true, false>), dim3(blocks), dim3(256), lds3, s, a);
-            else hipLaunchKernelGGL((annp_fe_force<9, 19, false, false>), dim3(blocks), dim3(256), lds3, s, a);
+            if (vir) hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, true, false>), dim3(blocks), dim3(256), lds3, s, a);
+            else hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, false, false>), dim3(blocks), dim3(256), lds3, s, a);
         }
         HIP_TRY(h, hipGetLastError());
     } else {
@@ -337,6 +336,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (nl < 2 || nl > MLP_MAXL || p->nsf < 1 || p->nsf > ANNP_GPAD || p->nnod < 1 || p->nnod > 32 ||
         p->npsf + p->ntsf != p->nsf || !p->flagact || !p->sfnor_scal || !p->sfnor_avg || !p->weight_all || !p->bias_all)
         return fail(nullptr, ANNP_HIP_ESHAPE, "unsupported network shape ntl=%d nnod=%d nsf=%d (%d+%d)", p->ntl, p->nnod, p->nsf, p->npsf, p->ntsf);
+    if (p->descriptor == ANNP_HIP_DESC_CHEBYSHEV && (p->npsf > FE_NP || p->ntsf > FE_NT))
+        return fail(nullptr, ANNP_HIP_ESHAPE, "Chebyshev kernels hold up to %d radial and %d angular orders (got %d %d)", FE_NP, FE_NT, p->npsf, p->ntsf);
     if (p->descriptor == ANNP_HIP_DESC_BEHLER && (!p->cofsymrad || !p->cofsymang))
         return fail(nullptr, ANNP_HIP_EARG, "Behler descriptor needs cofsymrad/cofsymang");
     if (p->map) {
@@ -372,31 +373,44 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     for (int l = 0; l < nl; l++) h->flagact[l] = p->flagact[l];
 
     {   // normalisation of the descriptor and the linear map dE/dZ_0 -> coef
+        // Device feature layout.  Behler: the file's order.  Chebyshev: the kernels always produce FE_NP radial
+        // and FE_NT angular sums, so feature k of a smaller basis sits in slot k (radial) or FE_NP + (k - npsf)
+        // (angular) and the remaining slots get zero weights: exact, whatever the basis size.
+        const bool cheb = p->descriptor == ANNP_HIP_DESC_CHEBYSHEV;
+        const int np_ = cheb ? FE_NP : p->npsf, nt = cheb ? FE_NT : p->ntsf, nnod = p->nnod;
+        const int nsf = np_ + nt;
+        h->nsf_dev = nsf;
+        std::vector<int> slot(p->nsf);
+        for (int k = 0; k < p->nsf; k++) slot[k] = (cheb && k >= p->npsf) ? FE_NP + (k - p->npsf) : k;
         std::vector<double> t(3 * ANNP_GPAD, 0.0), cmul(ANNP_GPAD, 0.0);
         for (int k = 0; k < ANNP_GPAD; k++) t[2 * ANNP_GPAD + k] = 1.0;
         for (int k = 0; k < p->nsf; k++) {
-            if (p->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
+            const int q = slot[k];
+            if (cheb) {
                 // G_k = s_k * sum  (fe:647,678);  Ghat = G - s_k avg_k (fe:178-180);  c_k = e_scale s_k dE/dGhat_k (fe:197)
-                t[k] = p->sfnor_scal[k];
-                t[ANNP_GPAD + k] = p->sfnor_scal[k] * p->sfnor_avg[k];
-                t[2 * ANNP_GPAD + k] = 1.0;
-                cmul[k] = p->e_scale * p->sfnor_scal[k];
+                t[q] = p->sfnor_scal[k];
+                t[ANNP_GPAD + q] = p->sfnor_scal[k] * p->sfnor_avg[k];
+                t[2 * ANNP_GPAD + q] = 1.0;
+                cmul[q] = p->e_scale * p->sfnor_scal[k];
             } else {
                 // Ghat = (G - sf_min)/(sf_max - sf_min) (ni:168-170);  F = -dE/dGhat dG / (sf_max-sf_min) * CFFORCE (ni:186-189)
-                t[k] = 1.0;
-                t[ANNP_GPAD + k] = p->sfnor_avg[k];
-                t[2 * ANNP_GPAD + k] = 1.0 / p->sfnor_scal[k];
-                cmul[k] = 1.0 / p->sfnor_scal[k];
+                t[q] = 1.0;
+                t[ANNP_GPAD + q] = p->sfnor_avg[k];
+                t[2 * ANNP_GPAD + q] = 1.0 / p->sfnor_scal[k];
+                cmul[q] = 1.0 / p->sfnor_scal[k];
             }
         }
         INIT_TRY(hipMalloc((void **)&h->d_norm, sizeof(double) * t.size()));
         INIT_TRY(hipMemcpy(h->d_norm, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
         h->bytes += sizeof(double) * t.size();
+        // first-layer weights in the device layout
+        std::vector<double> w0((size_t)nnod * nsf, 0.0);
+        for (int i = 0; i < nnod; i++)
+            for (int k = 0; k < p->nsf; k++) w0[(size_t)i * nsf + slot[k]] = p->weight_all[0][(size_t)i * p->nsf + k];
 
         // T: rows of coef as linear forms of c_k = cmul_k dE/dGhat_k
-        const int nsf = p->nsf, np_ = p->npsf, nt = p->ntsf, nnod = p->nnod;
         std::vector<long double> T((size_t)ANNP_CPAD * nsf, 0.0L);
-        if (p->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
+        if (cheb) {
             if (np_ + 2 * nt - 1 > ANNP_CPAD) { fail(h, 0, "descriptor too large for the coefficient buffer"); return bail(ANNP_HIP_ESHAPE); }
             // coefficients of z^k in T_n((z+1)/2): T_0 = 1, T_1 = (1+z)/2, T_n = (1+z) T_{n-1} - T_{n-2}.
             // All entries are dyadic rationals below 2^53, so this recurrence is exact.
@@ -422,10 +436,12 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         for (int o = 0; o < ANNP_CPAD; o++)
             for (int i = 0; i < nnod; i++) {
                 long double acc = 0.0L;
-                for (int k = 0; k < nsf; k++) acc += T[(size_t)o * nsf + k] * (long double)cmul[k] * (long double)p->weight_all[0][(size_t)i * nsf + k];
+                for (int k = 0; k < nsf; k++) acc += T[(size_t)o * nsf + k] * (long double)cmul[k] * (long double)w0[(size_t)i * nsf + k];
                 cm[(size_t)o * nnod + i] = (double)acc;
             }
-        const std::vector<double> img = mlp_image(h, p->weight_all, p->bias_all, cm.data());
+        std::vector<const double *> Wl(p->weight_all, p->weight_all + nl);
+        Wl[0] = w0.data();
+        const std::vector<double> img = mlp_image(h, Wl.data(), p->bias_all, cm.data());
         if (img.empty()) { fail(h, 0, "no network kernel for nsf=%d nnod=%d layers=%d", h->nsf, h->nnod, h->nl); return bail(ANNP_HIP_ESHAPE); }
         INIT_TRY(hipMalloc((void **)&h->d_mlp_img, sizeof(double) * img.size()));
         INIT_TRY(hipMemcpy(h->d_mlp_img, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
@@ -511,11 +527,11 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     // kernels may ask for the whole LDS
     {
         const int full = 160 * 1024;
-        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc<9, 19>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
-        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
-        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
-        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
-        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<9, 19, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(ni_set_lds_attributes());
     }
     // sizing hints, as annp_gpu_init takes them (buffers still grow on demand)

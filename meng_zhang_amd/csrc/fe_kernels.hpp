@@ -32,6 +32,8 @@
 
 namespace annp {
 
+constexpr int FE_NP = 9;      // radial Chebyshev orders the kernels are instantiated for (T_0..T_8)
+constexpr int FE_NT = 19;     // angular orders (T_0..T_18); smaller bases are embedded with zero weights (annp_hip_init)
 constexpr int FE_Q = 4;       // chunks per tournament row
 constexpr int FE_DUMP = 8;    // null / dump slots behind the records: where masked-off pair steps read and scatter
 

@@ -231,3 +231,40 @@ def load_fe_st():
     arr = np.loadtxt(lines[start:start + n])
     x = np.ascontiguousarray(arr[np.argsort(arr[:, 0]), 2:5])
     return x, np.array([xlo, ylo, zlo, xhi, yhi, zhi])
+
+
+# ---------------------------------------------------------------- synthetic potential files
+def write_ann(path, npsf=9, ntsf=19, nnod=10, ntl=4, acts=("tanh", "tanh", "linear"), cut=6.5, seed=1, element="Fe"):
+    """A Chebyshev-descriptor .ann file in the layout the reference's read_file expects (same line positions,
+    CRLF, tab-separated: fe_v2/src/pair_annp.cpp:335-585) with seeded random weights.  Used to exercise network
+    shapes and activation names the shipped potentials do not use."""
+    assert len(acts) == ntl - 1
+    rng = np.random.default_rng(seed)
+    nsf = npsf + ntsf
+    avg = rng.uniform(-3.0, 3.0, nsf)
+    cov = avg * avg + rng.uniform(0.5, 5.0, nsf)
+
+    def row(v):
+        return "\t".join("%.12f" % x for x in v) + "\t"
+    L = ["#Source: synthetic test potential", "#Date: -", "#contact information: -", "",
+         "#element parameters_(nelement #n element mass)", "1", "1\t%s\t55.847" % element, "",
+         "#artificial neural network parameters_(TL HL Nodes_HL Num_SF Num_PSF Num_TSF Cut) ",
+         "%d\t%d\t%d\t%d\t%d\t%d\t%g " % (ntl, ntl - 2, nnod, nsf, npsf, ntsf, cut), "",
+         "#symmetry function normization_(sfval_cov sfval_avg)", row(cov), row(avg), "",
+         "#types of symmetry function and activation function", "Chebyshev\t" + "\t".join(acts), "",
+         "#energy scale_(E_scale E_shift E_atom)", "0.80684104305538540", "-1019.0781365280557", "-3460.0000000000000", "",
+         "#weight_bias_matrix_(#1.....#TL)"]
+    for l in range(ntl - 1):
+        nr = 1 if l == ntl - 2 else nnod
+        nc = nsf if l == 0 else nnod
+        W = rng.normal(0.0, 0.35, (nr, nc))
+        B = rng.normal(0.0, 0.5, nr)
+        L.append("#%s" % element)
+        L.append("#%d_(weight)" % (l + 1))
+        L.extend(row(W[r]) for r in range(nr))
+        L.append("#%d_(bias)" % (l + 1))
+        L.append(row(B))
+        L.append("")
+    with open(path, "w", newline="") as fh:
+        fh.write("\r\n".join(L) + "\r\n")
+    return path

@@ -139,3 +139,15 @@ def test_truncated_potential_files_fail_cleanly(tmp_path):
         with pytest.raises(RuntimeError, match="All pair coeffs are not set"):
             p.init_style()
         p.close()
+
+
+def test_activation_names_are_probed_like_the_reference(tmp_path):
+    """fe_v2/src/pair_annp.cpp:413-424 tests every two-character window of the names line, so a spelled-out
+    'hyperbolic' registers hy and li, 'sigmoid' si and mo; both parsers must read it that way."""
+    from annp_testlib import write_ann
+    path = write_ann(str(tmp_path / "names.ann"), 6, 11, 7, 6, ("hyperbolic", "sigmoid", "li", "li", "li"), seed=2)
+    want = [1, 0, 2, 3, 0]                                  # hy, li (hyperboLIc), si, mo (sigMOid), li
+    assert list(read_pot(path).flagact)[:5] == want
+    p = _potential(path, "Fe")
+    assert list(p.potential()["flagact"]) == want
+    p.close()
