@@ -234,15 +234,24 @@ def load_fe_st():
 
 
 # ---------------------------------------------------------------- synthetic potential files
-def write_ann(path, npsf=9, ntsf=19, nnod=10, ntl=4, acts=("tanh", "tanh", "linear"), cut=6.5, seed=1, element="Fe"):
-    """A Chebyshev-descriptor .ann file in the layout the reference's read_file expects (same line positions,
-    CRLF, tab-separated: fe_v2/src/pair_annp.cpp:335-585) with seeded random weights.  Used to exercise network
-    shapes and activation names the shipped potentials do not use."""
+def write_ann(path, npsf=9, ntsf=19, nnod=10, ntl=4, acts=("tanh", "tanh", "linear"), cut=6.5, seed=1, element="Fe",
+              behler=None):
+    """A .ann file in the layout the reference's read_file expects (same line positions, CRLF, tab-separated:
+    fe_v2/src/pair_annp.cpp:335-585; ni/src/pair_annp.cpp:324-638) with seeded random weights.  Used to exercise
+    network shapes, activation names and function sets the shipped potentials do not use.
+    behler = (rad, ang): rows (eta, Rs, Rc) and (eta, lambda, zeta, Rc) of a G2/G4 set -> Ni-style file
+    (sf_min / sf_max normalisation, '#coefficent' section); npsf/ntsf are then taken from the rows."""
     assert len(acts) == ntl - 1
     rng = np.random.default_rng(seed)
+    if behler is not None:
+        npsf, ntsf = len(behler[0]), len(behler[1])
     nsf = npsf + ntsf
-    avg = rng.uniform(-3.0, 3.0, nsf)
-    cov = avg * avg + rng.uniform(0.5, 5.0, nsf)
+    if behler is None:
+        avg = rng.uniform(-3.0, 3.0, nsf)
+        cov = avg * avg + rng.uniform(0.5, 5.0, nsf)
+    else:
+        cov = rng.uniform(0.0, 0.5, nsf)                   # sf_min
+        avg = cov + rng.uniform(0.5, 2.0, nsf)              # sf_max
 
     def row(v):
         return "\t".join("%.12f" % x for x in v) + "\t"
@@ -265,6 +274,12 @@ def write_ann(path, npsf=9, ntsf=19, nnod=10, ntl=4, acts=("tanh", "tanh", "line
         L.append("#%d_(bias)" % (l + 1))
         L.append(row(B))
         L.append("")
+    if behler is not None:
+        L.append("#coefficent of symmetry funciton")
+        L.append("#rad\t%d\t\t\t\t" % npsf)
+        L.extend("%s\t%.7f \t%.7f \t%.7f\t\t" % ((element,) + tuple(r)) for r in behler[0])
+        L.append("#angl\t%d\t\t\t\t" % ntsf)
+        L.extend("%s\t%s\t%.7f \t%.7f \t%.7f \t%.7f " % ((element, element) + tuple(r)) for r in behler[1])
     with open(path, "w", newline="") as fh:
         fh.write("\r\n".join(L) + "\r\n")
     return path

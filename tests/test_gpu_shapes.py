@@ -73,3 +73,45 @@ def test_oversized_shapes_are_refused(tmp_path):
         with pytest.raises(RuntimeError, match="code -9"):    # ANNP_HIP_ESHAPE, from annp_hip_init through init_style
             p = make_pair(path, "Fe")
             p.close()
+
+
+# ---- Behler G2/G4 sets other than the shipped 2 x 3 x 4 product (generic visit of ni_kernels.hpp) -------------
+RC = 7.3699319
+BEHLER = {
+    # not a product set, eta not multiples of each other, assorted integer zetas
+    "assorted": ([(0.013, 0.0, RC), (0.041, 0.0, RC)],
+                 [(0.013, -1.0, 1.0, RC), (0.013, 1.0, 3.0, RC), (0.027, 1.0, 2.0, RC), (0.027, -1.0, 5.0, RC),
+                  (0.013, 1.0, 8.0, RC), (0.05, -1.0, 2.0, RC), (0.05, 1.0, 1.0, RC)], 11),
+    # a product set, but not the shipped exponents: 2 lambdas x 2 etas x 3 zetas
+    "product_2x2x3": ([(0.02, 0.0, RC)],
+                      [(e, l, z, RC) for e in (0.01, 0.03) for z in (1.0, 3.0, 6.0) for l in (-1.0, 1.0)], 9),
+    # the shipped lambdas and zetas with etas that are not integer multiples
+    "shipped_like_etas_off": ([(0.01, 0.0, RC), (0.02, 0.0, RC), (0.05, 0.0, RC)],
+                              [(e, l, z, RC) for e in (0.01, 0.025, 0.07) for z in (1.0, 2.0, 4.0, 16.0) for l in (-1.0, 1.0)], 24),
+    # different radial and angular cutoffs
+    "two_cutoffs": ([(0.02, 0.0, 8.2), (0.06, 0.0, 8.2)],
+                    [(0.015, l, z, 6.9) for z in (1.0, 2.0) for l in (-1.0, 1.0)], 6),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compat", [False, True])
+@pytest.mark.parametrize("name", sorted(BEHLER))
+def test_behler_function_sets(name, compat, tmp_path):
+    from annp_testlib import A_NI, KIND_NI_COMPAT, KIND_NI_FIXED, fcc
+    rad, ang, nnod = BEHLER[name]
+    path = write_ann(str(tmp_path / (name + ".ann")), nnod=nnod, ntl=4, acts=("ta", "ta", "li"), seed=11, element="Ni",
+                     behler=(rad, ang))
+    pot = read_pot(path)
+    assert pot.has_symcoef == 1 and (pot.npsf, pot.ntsf) == (len(rad), len(ang))
+    x0, box = fcc(4, 4, 4, A_NI)
+    s = System(perturb(x0, 5, 0.08), box, rc_list=6.5)
+    o = oracle_compute(pot, s, KIND_NI_COMPAT if compat else KIND_NI_FIXED, FAST, want_virial=True)
+    p = make_pair(path, "Ni", ni_compat=compat)
+    try:
+        r = run(p, s, vflag=1)
+    finally:
+        p.close()
+    assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6 * max(1.0, np.abs(o["eatom"]).max())
+    assert np.abs(r["f"] - o["f"]).max() < 1e-5 * max(1.0, np.abs(o["f"]).max())
+    assert np.abs(r["virial"] - o["virial"]).max() < 1e-5 * max(1.0, np.abs(o["virial"]).max())
