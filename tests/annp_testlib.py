@@ -18,6 +18,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 FE_POT = os.path.join(GOLDEN, "potentials", "fe_annp_potential_2.ann")
 NI_POT = os.path.join(GOLDEN, "potentials", "ni_annp_potential_2.ann")
 
+ANNA_POT = os.path.join(GOLDEN, "potentials", "fe_adp_potential_2310.anna")
 MAXSF, MAXNOD, MAXLAY = 64, 64, 6
 KIND_FE, KIND_NI_COMPAT, KIND_NI_FIXED = 0, 1, 2
 LITERAL, FAST = 0, 1
@@ -46,6 +47,23 @@ class OraclePot(C.Structure):
     ]
 
 
+class AnnaPot(C.Structure):
+    """anna_oracle_pot (oracle/anna_oracle.h)"""
+    _fields_ = [
+        ("nelements", C.c_int),
+        ("ntl", C.c_int), ("nhl", C.c_int), ("nnod", C.c_int), ("nout", C.c_int),
+        ("nsf", C.c_int), ("npsf", C.c_int), ("ntsf", C.c_int), ("ngp", C.c_int),
+        ("flagsym", C.c_int),
+        ("flagact", C.c_int * MAXLAY),
+        ("cut", C.c_double), ("mass", C.c_double),
+        ("e_base", C.c_double), ("e_scal", C.c_double),
+        ("gparams", C.c_double * 32),
+        ("W", (C.c_double * (MAXNOD * MAXSF)) * MAXLAY),
+        ("B", (C.c_double * MAXNOD) * MAXLAY),
+        ("element", C.c_char * 16),
+    ]
+
+
 _lib = None
 
 
@@ -59,7 +77,7 @@ def oracle_lib():
         so = os.path.join(ORACLE_DIR, "libannp_oracle.so")
         src_newer = (not os.path.exists(so)) or any(
             os.path.getmtime(os.path.join(ORACLE_DIR, s)) > os.path.getmtime(so)
-            for s in ("annp_oracle.c", "annp_oracle.h", "lmp_harness.c"))
+            for s in ("annp_oracle.c", "annp_oracle.h", "anna_oracle.c", "anna_oracle.h", "lmp_harness.c"))
         if src_newer:
             build_oracle()
         lib = C.CDLL(so)
@@ -74,6 +92,11 @@ def oracle_lib():
         lib.annp_oracle_compute_vatom.argtypes = [C.POINTER(OraclePot), C.c_int, C.c_int, dp, C.c_int, ip, ip, lp, ip,
                                                   C.c_double, C.c_int, dp]
         lib.annp_oracle_compute_vatom.restype = C.c_int
+        lib.anna_oracle_read_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(AnnaPot)]
+        lib.anna_oracle_read_file.restype = C.c_int
+        lib.anna_oracle_compute.argtypes = [C.POINTER(AnnaPot), C.c_int, dp, C.c_int, ip, ip, lp, ip, C.c_double,
+                                            dp, dp, dp, dp, dp, dp, dp, dp]
+        lib.anna_oracle_compute.restype = C.c_int
         lib.harness_ghosts.argtypes = [C.c_int, dp, dp, ip, C.c_double, C.c_longlong, dp, ip]
         lib.harness_ghosts.restype = C.c_longlong
         lib.harness_neigh.argtypes = [C.c_int, C.c_int, dp, C.c_double, ip, lp, ip]
@@ -100,6 +123,35 @@ def read_pot(path):
     if rc != 0:
         raise RuntimeError("annp_oracle_read_file(%s) -> %d" % (path, rc))
     return pot
+
+
+def read_anna(path):
+    pot = AnnaPot()
+    rc = oracle_lib().anna_oracle_read_file(path.encode(), 1, C.byref(pot))
+    if rc != 0:
+        raise RuntimeError("anna_oracle_read_file(%s) -> %d" % (path, rc))
+    return pot
+
+
+def anna_compute(pot, sysm, want_virial=False, want_vatom=False, frozen=None, inum=None):
+    """pair_style anna_adp on the oracle: dict like oracle_compute's plus G and the network outputs"""
+    lib = oracle_lib()
+    inum = sysm.inum if inum is None else inum
+    f = np.zeros((sysm.nall, 3))
+    eatom = np.zeros(sysm.nall)
+    eng = np.zeros(1)
+    vir = np.zeros(6) if want_virial else None
+    vat = np.zeros((sysm.nall, 6)) if want_vatom else None
+    G = np.zeros((inum, pot.nsf))
+    Lp = np.zeros((inum, pot.nout))
+    fr = np.ascontiguousarray(frozen, dtype=np.float64) if frozen is not None else None
+    rc = lib.anna_oracle_compute(C.byref(pot), sysm.nall, _dp(sysm.x), inum, _ip(sysm.ilist), _ip(sysm.numneigh),
+                                 _lp(sysm.first), _ip(sysm.neigh), pot.cut * pot.cut, _dp(f), _dp(eatom), _dp(eng),
+                                 _dp(vir), _dp(vat), _dp(G), _dp(Lp), _dp(fr))
+    if rc != 0:
+        raise RuntimeError("anna_oracle_compute -> %d" % rc)
+    return dict(f_all=f, f=sysm.fold(f), eatom=eatom[: sysm.nlocal], energy=float(eng[0]), virial=vir, vatom=vat,
+                G=G, lparams=Lp)
 
 
 # ---------------------------------------------------------------- synthetic inputs
