@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define ANNP_HIP_ABI_VERSION 1
+#define ANNP_HIP_ABI_VERSION 2
 
 #define ANNP_HIP_OK 0
 #define ANNP_HIP_EARG (-1)
@@ -56,6 +56,8 @@ extern "C" {
 /* which reference translation unit's arithmetic is evaluated */
 #define ANNP_HIP_DESC_CHEBYSHEV 0   /* fe, fe_v2: fe_v2/src/pair_annp.cpp:633-695         */
 #define ANNP_HIP_DESC_BEHLER 1      /* ni: G2/G4 in atomic units, ni/src/pair_annp.cpp:686-767 */
+#define ANNP_HIP_DESC_ANNA_ADP 2    /* pair_style anna_adp: un-normalised Chebyshev descriptor -> network ->
+                                       (d2, q2) of an analytic ADP form, anna-gpu-lammps/bcc_fe/src/pair_anna_adp.cpp:71-298 */
 
 typedef struct annp_hip_handle annp_hip_handle;
 
@@ -86,6 +88,12 @@ typedef struct annp_hip_params {
     const double *const *bias_all;   /* [ntl-1] pointers, [nnod] ... [1]                     */
     const double *cofsymrad;  /* BEHLER: [npsf*3] eta, Rs, Rc(Bohr); else NULL              */
     const double *cofsymang;  /* BEHLER: [ntsf*4] eta, lambda, zeta, Rc(Bohr); else NULL    */
+    /* ANNA_ADP only (the arguments anna_adp_gpu_init adds, bcc_fe/src/pair_anna_adp_gpu.cpp:31-41) */
+    int nout;                 /* network outputs: 2 (d2, q2); weight_all[ntl-2] is (nout x nnod)   */
+    int ngp;                  /* number of analytic parameters: 17                                 */
+    const double *gparams;    /* [ngp] A0 yy gamma C0 c1F c2F V0 b1 b2 delta r0 r1 hc d1 q1 d3 q3  */
+    double e_base;            /* added to every atom's energy (pair_anna_adp.cpp:212); sfnor_*,
+                                 e_scale/e_shift/e_atom are not used by this descriptor           */
 } annp_hip_params;
 
 /* Replaces annp_gpu_init.  device = HIP device ordinal.  nlocal/nall/max_nbors are

@@ -1,0 +1,240 @@
+// anna_kernels.hpp -- pair_style anna_adp: network -> ADP sums -> energy -> forces, one wave per atom.
+//
+// Arithmetic restated from anna-gpu-lammps/bcc_fe/src/pair_anna_adp.cpp ("adp:" below).  The descriptor of that
+// pair style is the Chebyshev one of pair_style annp without normalisation (adp:584-612), so pass 1 is
+// annp_fe_desc (fe_kernels.hpp) unchanged.  This file is everything after it (adp:161-280):
+//   * the small network G[28] -> 6 -> 6 -> (d2, q2): forward only, its outputs are the decay constants of the
+//     dipole and quadrupole functions u(r), w(r); forces treat them as constants, exactly as the reference does;
+//   * per-neighbour analytic terms (density, pair repulsion, u, w) and the atom's sums mu (3), lambda (6), rho;
+//   * the energy (adp:205-212) and one force per neighbour (adp:215-280), scattered with global atomics.
+// There is no pair loop here: cost is O(n) per atom, a few libm-class functions per neighbour, so a plain
+// wave-per-atom mapping (lane = neighbour) is enough; the heavy pass is the descriptor.
+#pragma once
+#include "annp_common.hpp"
+#include "mlp_kernels.hpp"
+
+namespace annp {
+
+constexpr int ANNA_MAXL = 6;        // weight layers
+constexpr int ANNA_NR = 2;          // neighbours per lane held in registers: in-range neighbours <= 128
+
+struct AnnaArgs {
+    int inum, n_cap;                // n_cap: records per wave (multiple of 64, <= 64 * ANNA_NR)
+    const int *ilist;
+    const double *x;
+    const int *numneigh;
+    const long long *first;
+    const int *neigh;
+    double rc;                      // adp:172,219 test r (not r^2) against the file's cutoff
+    const double *G;                // [inum][ANNP_GPAD] raw descriptor sums (pass 1)
+    const double *net;              // per layer: W row-major [rows][cols], then B [rows]; layer 0 in the device layout
+    int nl, nin, nnod, nout;        // nin = columns of layer 0 (device layout)
+    int act[ANNA_MAXL];
+    double gp[17];                  // A0 yy gamma C0 c1F c2F V0 b1 b2 delta r0 r1 hc d1 q1 d3 q3
+    double e_base;
+    double *f, *eatom, *eng, *virial, *vatom;
+    int *errflag;
+};
+
+__host__ __device__ inline size_t anna_lds_per_wave(int n_cap) { return (size_t)n_cap * (4 * 8 + 4) + 2 * 64 * 8; }
+
+// adp:607-631 (3 and 4 are the same function here: 1.7 tanh(0.3 a))
+__device__ __forceinline__ double anna_act(int flag, double a)
+{
+    if (flag == 0) return a;
+    if (flag == 1) return tanh_fast(a);
+    if (flag == 2) return 1.0 / (1.0 + exp(a));
+    return 1.7 * tanh_fast(0.3 * a);
+}
+
+template <bool VIRIAL>
+__global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const int wave = uniform(threadIdx.x >> 6);
+    const int ii = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
+    if (ii >= p.inum) return;
+    const int cap = p.n_cap;
+    unsigned char *wbase = lds_raw + (size_t)wave * anna_lds_per_wave(cap);
+    double *Ldx = reinterpret_cast<double *>(wbase), *Ldy = Ldx + cap, *Ldz = Ldy + cap, *Lr = Ldz + cap;
+    double *hbuf = Lr + cap;                                   // [2][64] network activations
+    int *Lj = reinterpret_cast<int *>(hbuf + 128);
+
+    const int i = p.ilist ? p.ilist[ii] : ii;
+    const double xi = p.x[3 * (size_t)i], yi = p.x[3 * (size_t)i + 1], zi = p.x[3 * (size_t)i + 2];
+    const int *row = p.neigh + p.first[i];
+    const int jn = p.numneigh[i];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    // ---- in-range neighbours (adp:171-173: r > Rc or r < 1e-12 skipped), compacted in list order
+    int n = 0;
+    for (int c0 = 0; c0 < jn; c0 += 256) {
+        int j[4];
+        bool valid[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int jj = c0 + 64 * u + lane;
+            valid[u] = jj < jn;
+            j[u] = valid[u] ? (row[jj] & ANNP_NEIGHMASK) : 0;
+        }
+        double dx[4], dy[4], dz[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            dx[u] = xi - p.x[3 * (size_t)j[u]]; dy[u] = yi - p.x[3 * (size_t)j[u] + 1]; dz[u] = zi - p.x[3 * (size_t)j[u] + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double r = sqrt(dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u]);      // adp:125 all_xij[jj][3]
+            const bool in = valid[u] && !(r > p.rc) && !(r < 1.0e-12);
+            const unsigned long long m = __ballot(in);
+            const int pos = n + __popcll(m & lt);
+            if (in && pos < cap) { Ldx[pos] = dx[u]; Ldy[pos] = dy[u]; Ldz[pos] = dz[u]; Lr[pos] = r; Lj[pos] = j[u]; }
+            n += __popcll(m);
+        }
+    }
+    n = uniform(n);
+    if (n > cap) { if (lane == 0) atomicMax(p.errflag, n); return; }
+
+    // ---- the network (adp:633-667): lane r owns output row r of the current layer; sums run over the inputs
+    //      in file order, bias added last, as dot_add_wxb does (adp:599-604)
+    {
+        double *hin = hbuf, *hout = hbuf + 64;
+        if (lane < p.nin) hin[lane] = p.G[(size_t)ii * ANNP_GPAD + lane];
+        wave_lds_sync();
+        const double *w = p.net;
+        for (int l = 0; l < p.nl; l++) {
+            const int nr = (l == p.nl - 1) ? p.nout : p.nnod;
+            const int nc = (l == 0) ? p.nin : p.nnod;
+            if (lane < nr) {
+                const double *wr = w + (size_t)lane * nc;
+                double a = 0.0;
+                for (int c = 0; c < nc; c++) a = fma(wr[c], hin[c], a);
+                a += w[(size_t)nr * nc + lane];
+                hout[lane] = anna_act(p.act[l], a);
+            }
+            w += (size_t)nr * nc + nr;
+            wave_lds_sync();
+            double *t = hin; hin = hout; hout = t;
+        }
+        // hin now holds the outputs
+        hbuf = hin;
+    }
+    const double d2 = hbuf[0], q2 = hbuf[1];                   // adp:162
+
+    const double A0 = p.gp[0], yy = p.gp[1], gamma = p.gp[2], C0 = p.gp[3], c1F = p.gp[4], c2F = p.gp[5], V0 = p.gp[6];
+    const double b1 = p.gp[7], b2 = p.gp[8], delta = p.gp[9], r0 = p.gp[10], r1 = p.gp[11], hc = p.gp[12];
+    const double d1 = p.gp[13], q1 = p.gp[14], d3 = p.gp[15], q3 = p.gp[16];
+    const double rep_coeff = V0 / (b2 - b1);
+
+    // ---- per-neighbour functions, kept in registers for the force loop, and the atom's sums (adp:165-196)
+    double stpf[ANNA_NR], dstpf[ANNA_NR], uterm[ANNA_NR], wterm[ANNA_NR], expz[ANNA_NR], zyy[ANNA_NR], zb1[ANNA_NR], zb2[ANNA_NR];
+    double mu0 = 0.0, mu1 = 0.0, mu2 = 0.0, l00 = 0.0, l11 = 0.0, l22 = 0.0, l01 = 0.0, l02 = 0.0, l12 = 0.0, rho = 0.0, rep = 0.0;
+#pragma unroll
+    for (int k = 0; k < ANNA_NR; k++) {
+        const int a = lane + 64 * k;
+        stpf[k] = dstpf[k] = uterm[k] = wterm[k] = expz[k] = zyy[k] = 0.0; zb1[k] = zb2[k] = 1.0;
+        if (a < n) {
+            const double r = Lr[a], dx = Ldx[a], dy = Ldy[a], dz = Ldz[a];
+            const double sx = (r - p.rc) / hc;
+            const double sx2 = sx * sx, sx4 = sx2 * sx2, t1 = 1.0 + sx4;
+            stpf[k] = sx4 / t1;
+            dstpf[k] = 4.0 * (sx2 * sx) / (t1 * t1) / hc;
+            uterm[k] = d1 * exp(-d2 * r);
+            wterm[k] = q1 * exp(-q2 * r);
+            const double u = stpf[k] * (uterm[k] + d3), w = stpf[k] * (wterm[k] + q3);
+            mu0 = fma(u, dx, mu0); mu1 = fma(u, dy, mu1); mu2 = fma(u, dz, mu2);
+            l00 = fma(w * dx, dx, l00); l11 = fma(w * dy, dy, l11); l22 = fma(w * dz, dz, l22);
+            l01 = fma(w * dx, dy, l01); l02 = fma(w * dx, dz, l02); l12 = fma(w * dy, dz, l12);
+            const double rho_z = r - r0;
+            expz[k] = exp(-gamma * rho_z);
+            zyy[k] = A0 * pow(rho_z, yy);
+            rho += stpf[k] * (zyy[k] * expz[k] * (1.0 + expz[k]) + C0);
+            const double repul_z = r / r1;
+            zb1[k] = pow(repul_z, b1); zb2[k] = pow(repul_z, b2);
+            rep += stpf[k] * (rep_coeff * (b2 / zb1[k] - b1 / zb2[k]) + delta);
+        }
+    }
+    mu0 = wave_sum(mu0); mu1 = wave_sum(mu1); mu2 = wave_sum(mu2);
+    l00 = wave_sum(l00); l11 = wave_sum(l11); l22 = wave_sum(l22);
+    l01 = wave_sum(l01); l02 = wave_sum(l02); l12 = wave_sum(l12);
+    rho = wave_sum(rho); rep = wave_sum(rep);
+
+    // ---- energy (adp:198-212)
+    const double v_i = l00 + l11 + l22;
+    const double sum_mu = mu0 * mu0 + mu1 * mu1 + mu2 * mu2;
+    const double sum_lam = l00 * l00 + l11 * l11 + l22 * l22 + 2.0 * (l01 * l01 + l02 * l02 + l12 * l12);
+    const double f_v = -1.0 / 3.0 * v_i;
+    const double e_ang = 0.5 * sum_mu + 0.5 * sum_lam - 1.0 / 6.0 * v_i * v_i;
+    const double e_emb = c1F * sqrt(rho) + c2F * rho * rho;
+    const double evdwl = 0.5 * rep + e_emb + e_ang + p.e_base;
+    if (lane == 0) {
+        if (p.eatom) p.eatom[i] += evdwl;
+        if (p.eng) atomicAdd(p.eng, evdwl);
+    }
+    const double demb = 0.5 * c1F / sqrt(rho) + 2.0 * c2F * rho;       // adp:237
+
+    // ---- forces (adp:215-280)
+    double fi0 = 0.0, fi1 = 0.0, fi2 = 0.0;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
+#pragma unroll
+    for (int k = 0; k < ANNA_NR; k++) {
+        const int a = lane + 64 * k;
+        if (a < n) {
+            const double rij = Lr[a], dx = Ldx[a], dy = Ldy[a], dz = Ldz[a];
+            const double rho_z = rij - r0;
+            const double ga_zyy = zyy[k] * gamma;
+            const double d_rho = expz[k] * (1.0 + expz[k]) * (zyy[k] * (dstpf[k] + stpf[k] * yy / rho_z) - ga_zyy) + C0 * dstpf[k] -
+                                 ga_zyy * expz[k] * expz[k];
+            const double d_embed = demb * d_rho;
+            const double repul_z = rij / r1;
+            const double drep_t = b2 * b1 / r1;
+            const double rep_t1 = rep_coeff * (b2 / zb1[k] - b1 / zb2[k]) + delta;
+            const double d_repul = dstpf[k] * rep_t1 + stpf[k] * rep_coeff * (drep_t / repul_z * (-1.0 / zb1[k] + 1.0 / zb2[k]));
+            const double adp_u = stpf[k] * (uterm[k] + d3);
+            const double adp_w = 2.0 * stpf[k] * (wterm[k] + q3);
+            const double d_adp_u = dstpf[k] * (uterm[k] + d3) + stpf[k] * (-d2 * uterm[k]);
+            const double d_adp_w = dstpf[k] * (wterm[k] + q3) + stpf[k] * (-q2 * wterm[k]);
+            const double lamb1 = d_adp_w * (l00 * dx * dx + l11 * dy * dy + l22 * dz * dz);
+            const double lamb2 = d_adp_w * (l01 * dx * dy + l02 * dx * dz + l12 * dy * dz) * 2.0 + lamb1;
+            const double df1 = 0.5 * d_repul + d_embed + d_adp_u * (mu0 * dx + mu1 * dy + mu2 * dz) + lamb2;
+            const double df3 = f_v * (d_adp_w * rij + adp_w);
+            const double fx = df1 * dx / rij + adp_w * (dy * l01 + dz * l02 + dx * l00) + mu0 * adp_u + dx * df3;
+            const double fy = df1 * dy / rij + adp_w * (dy * l11 + dz * l12 + dx * l01) + mu1 * adp_u + dy * df3;
+            const double fz = df1 * dz / rij + adp_w * (dy * l12 + dz * l22 + dx * l02) + mu2 * adp_u + dz * df3;
+            const int j = Lj[a];
+            atomicAdd(&p.f[3 * (size_t)j], fx); atomicAdd(&p.f[3 * (size_t)j + 1], fy); atomicAdd(&p.f[3 * (size_t)j + 2], fz);
+            fi0 -= fx; fi1 -= fy; fi2 -= fz;
+            if (VIRIAL) {       // ev_tally_xyz(i, j, ..., -fx, -fy, -fz, delx, dely, delz), adp:276-278
+                const double w0 = -dx * fx, w1 = -dy * fy, w2 = -dz * fz, w3 = -dx * fy, w4 = -dx * fz, w5 = -dy * fz;
+                v0 += w0; v1 += w1; v2 += w2; v3 += w3; v4 += w4; v5 += w5;
+                if (p.vatom) {
+                    double *vj = p.vatom + 6 * (size_t)j;
+                    atomicAdd(vj + 0, 0.5 * w0); atomicAdd(vj + 1, 0.5 * w1); atomicAdd(vj + 2, 0.5 * w2);
+                    atomicAdd(vj + 3, 0.5 * w3); atomicAdd(vj + 4, 0.5 * w4); atomicAdd(vj + 5, 0.5 * w5);
+                }
+            }
+        }
+    }
+    fi0 = wave_sum(fi0); fi1 = wave_sum(fi1); fi2 = wave_sum(fi2);
+    if (lane == 0) {
+        atomicAdd(&p.f[3 * (size_t)i], fi0); atomicAdd(&p.f[3 * (size_t)i + 1], fi1); atomicAdd(&p.f[3 * (size_t)i + 2], fi2);
+    }
+    if (VIRIAL) {
+        v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
+        v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
+        if (lane == 0) {
+            if (p.virial) {
+                atomicAdd(&p.virial[0], v0); atomicAdd(&p.virial[1], v1); atomicAdd(&p.virial[2], v2);
+                atomicAdd(&p.virial[3], v3); atomicAdd(&p.virial[4], v4); atomicAdd(&p.virial[5], v5);
+            }
+            if (p.vatom) {
+                double *vi = p.vatom + 6 * (size_t)i;
+                atomicAdd(vi + 0, 0.5 * v0); atomicAdd(vi + 1, 0.5 * v1); atomicAdd(vi + 2, 0.5 * v2);
+                atomicAdd(vi + 3, 0.5 * v3); atomicAdd(vi + 4, 0.5 * v4); atomicAdd(vi + 5, 0.5 * v5);
+            }
+        }
+    }
+}
+
+}  // namespace annp

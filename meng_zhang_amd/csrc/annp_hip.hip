@@ -23,6 +23,7 @@
 #include "mlp_kernels.hpp"
 #include "neigh_kernels.hpp"
 #include "ni_kernels.hpp"
+#include "anna_kernels.hpp"
 
 using namespace annp;
 
@@ -46,6 +47,10 @@ struct annp_hip_handle {
     int descriptor = 0, ntypes = 1, ntl = 0, nhl = 0, nnod = 0, nsf = 0, npsf = 0, ntsf = 0, nl = 0;
     int nsf_dev = 0;                    // features in the device layout (Chebyshev: always 9 + 19 slots, unused ones carry zero weights)
     int ni_compat = 0;
+    // pair_style anna_adp
+    int nout = 1;
+    double e_base = 0.0, gp[17] = {0};
+    double *d_net = nullptr;            // network image for annp_anna_adp (layer 0 in the device feature layout)
     int ni_cap = 24;                    // Behler kernels: record capacity per atom for the next descriptor pass
     int ni_cap_last = 0;                // ... and what the last force pass ran with
     int flagact[MLP_MAXL] = {0, 0, 0, 0};
@@ -235,6 +240,35 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             else hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, false, false>), dim3(blocks), dim3(256), lds3, s, a);
         }
         HIP_TRY(h, hipGetLastError());
+    } else if (h->descriptor == ANNP_HIP_DESC_ANNA_ADP) {
+        // pass 1: the same Chebyshev descriptor kernel, raw sums (adp:584-612 has no normalisation)
+        FeArgs a{};
+        a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
+        a.cutsq = h->cutsq; a.rc_list = h->cut; a.rc_par = h->cut;          // fc and the radial argument both use the file's cutoff (adp:105,130,588)
+        a.G = h->G.p; a.ncount = h->ncount.p; a.errflag = h->d_flags;
+        a.n_cap = cap_list;
+        size_t lds1 = fe_desc_lds_per_wave(a.n_cap) * ANNP_WAVES_PER_BLOCK;
+        if (lds1 > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "neighbour list too long for LDS (%d)", max_numneigh);
+        hipLaunchKernelGGL((annp_fe_desc<FE_NP, FE_NT>), dim3(blocks), dim3(256), lds1, s, a);
+        HIP_TRY(h, hipGetLastError());
+        if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[1], s)); HIP_TRY(h, hipEventRecord(h->ev[2], s)); }
+        // pass 2: network, ADP sums, energy, forces
+        AnnaArgs q{};
+        q.inum = inum; q.ilist = d_ilist; q.x = d_x; q.numneigh = d_numneigh; q.first = d_first; q.neigh = d_neigh;
+        q.n_cap = 64 * ANNA_NR; q.rc = h->cut; q.G = h->G.p; q.net = h->d_net;
+        q.nl = h->nl; q.nin = h->nsf_dev; q.nnod = h->nnod; q.nout = h->nout;
+        for (int l = 0; l < h->nl; l++) q.act[l] = h->flagact[l];
+        for (int k = 0; k < 17; k++) q.gp[k] = h->gp[k];
+        q.e_base = h->e_base;
+        q.f = d_f; q.eatom = d_eatom; q.eng = d_eng; q.virial = d_virial; q.vatom = d_vatom; q.errflag = h->d_flags;
+        const size_t lds2 = anna_lds_per_wave(q.n_cap) * ANNP_WAVES_PER_BLOCK;
+        if (d_virial || d_vatom) hipLaunchKernelGGL((annp_anna_adp<true>), dim3(blocks), dim3(256), lds2, s, q);
+        else hipLaunchKernelGGL((annp_anna_adp<false>), dim3(blocks), dim3(256), lds2, s, q);
+        HIP_TRY(h, hipGetLastError());
+        // more in-range neighbours than a wave holds (128) is reported at the next sync point
+        HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        h->flags_pending = true;
+        h->ni_cap_last = q.n_cap;
     } else {
         NiArgs a{};
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
@@ -312,6 +346,7 @@ void annp_hip_clear(annp_hip_handle *h)
     if (h->d_sym) (void)hipFree(h->d_sym);
     if (h->d_isym) (void)hipFree(h->d_isym);
     if (h->d_mlp_img) (void)hipFree(h->d_mlp_img);
+    if (h->d_net) (void)hipFree(h->d_net);
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom); release(h, h->vatom);
     release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr);
     release(h, h->first);
@@ -333,7 +368,14 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (p->struct_bytes != (int)sizeof(annp_hip_params))
         return fail(nullptr, ANNP_HIP_EARG, "annp_hip_params size mismatch (%d vs %d)", p->struct_bytes, (int)sizeof(annp_hip_params));
     const int nl = p->ntl - 1;
-    if (nl < 2 || nl > MLP_MAXL || p->nsf < 1 || p->nsf > ANNP_GPAD || p->nnod < 1 || p->nnod > 32 ||
+    const bool anna = p->descriptor == ANNP_HIP_DESC_ANNA_ADP;
+    if (anna) {
+        if (nl < 1 || nl > ANNA_MAXL || p->nsf < 1 || p->nnod < 1 || p->nnod > 64 || p->npsf + p->ntsf != p->nsf ||
+            p->npsf > FE_NP || p->ntsf > FE_NT || p->nout != 2 || p->ngp < 17 || !p->gparams || !p->flagact || !p->weight_all ||
+            !p->bias_all)
+            return fail(nullptr, ANNP_HIP_ESHAPE, "unsupported anna_adp shape ntl=%d nnod=%d nout=%d nsf=%d (%d+%d) ngp=%d",
+                        p->ntl, p->nnod, p->nout, p->nsf, p->npsf, p->ntsf, p->ngp);
+    } else if (nl < 2 || nl > MLP_MAXL || p->nsf < 1 || p->nsf > ANNP_GPAD || p->nnod < 1 || p->nnod > 32 ||
         p->npsf + p->ntsf != p->nsf || !p->flagact || !p->sfnor_scal || !p->sfnor_avg || !p->weight_all || !p->bias_all)
         return fail(nullptr, ANNP_HIP_ESHAPE, "unsupported network shape ntl=%d nnod=%d nsf=%d (%d+%d)", p->ntl, p->nnod, p->nsf, p->npsf, p->ntsf);
     if (p->descriptor == ANNP_HIP_DESC_CHEBYSHEV && (p->npsf > FE_NP || p->ntsf > FE_NT))
@@ -372,7 +414,28 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     h->cutsq = p->cutsq ? p->cutsq[(p->ntypes + 1) * 1 + 1] : p->cut * p->cut;
     for (int l = 0; l < nl; l++) h->flagact[l] = p->flagact[l];
 
-    {   // normalisation of the descriptor and the linear map dE/dZ_0 -> coef
+    if (anna) {
+        // network image for annp_anna_adp: layer 0 with its columns in the device feature layout (FE_NP + FE_NT slots)
+        h->nout = p->nout; h->e_base = p->e_base;
+        for (int k = 0; k < 17; k++) h->gp[k] = p->gparams[k];
+        h->nsf_dev = FE_NP + FE_NT;
+        std::vector<double> img;
+        for (int l = 0; l < nl; l++) {
+            const int nr = (l == nl - 1) ? p->nout : p->nnod, nc_file = (l == 0) ? p->nsf : p->nnod, nc = (l == 0) ? h->nsf_dev : p->nnod;
+            for (int r = 0; r < nr; r++) {
+                std::vector<double> rowv(nc, 0.0);
+                for (int c = 0; c < nc_file; c++) {
+                    const int q = (l == 0 && c >= p->npsf) ? FE_NP + (c - p->npsf) : c;
+                    rowv[q] = p->weight_all[l][(size_t)r * nc_file + c];
+                }
+                img.insert(img.end(), rowv.begin(), rowv.end());
+            }
+            img.insert(img.end(), p->bias_all[l], p->bias_all[l] + nr);
+        }
+        INIT_TRY(hipMalloc((void **)&h->d_net, sizeof(double) * img.size()));
+        INIT_TRY(hipMemcpy(h->d_net, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
+        h->bytes += sizeof(double) * img.size();
+    } else {   // normalisation of the descriptor and the linear map dE/dZ_0 -> coef
         // Device feature layout.  Behler: the file's order.  Chebyshev: the kernels always produce FE_NP radial
         // and FE_NT angular sums, so feature k of a smaller basis sits in slot k (radial) or FE_NP + (k - npsf)
         // (angular) and the remaining slots get zero weights: exact, whatever the basis size.
@@ -533,6 +596,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(ni_set_lds_attributes());
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_anna_adp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_anna_adp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
     }
     // sizing hints, as annp_gpu_init takes them (buffers still grow on demand)
     if (nlocal_hint > 0) {

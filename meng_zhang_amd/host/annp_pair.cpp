@@ -8,7 +8,7 @@
 
 namespace annp_host {
 
-PairANNP::PairANNP(int ntypes) : ntypes_(ntypes < 1 ? 1 : ntypes)
+PairANNP::PairANNP(int ntypes, const char *style) : ntypes_(ntypes < 1 ? 1 : ntypes), anna_(style && std::strcmp(style, "anna_adp") == 0)
 {
     const size_t n = (size_t)ntypes_ + 1;
     map_.assign(n, -1);
@@ -42,7 +42,9 @@ int PairANNP::coeff(int narg, const char *const *arg)
         if (j == elements_.size()) elements_.push_back(arg[i]);
     }
     std::string perr;
-    if (!read_potential(arg[2], (int)elements_.size(), pot_, perr)) return fail(ANNP_HIP_EARG, perr);
+    const bool ok = anna_ ? read_potential_anna(arg[2], (int)elements_.size(), pot_, perr)
+                          : read_potential(arg[2], (int)elements_.size(), pot_, perr);
+    if (!ok) return fail(ANNP_HIP_EARG, perr);
     if ((int)elements_.size() != (int)pot_.elements.size()) return fail(ANNP_HIP_EARG, "Incorrect args for pair coefficients");
     cutmax_ = pot_.cut;                                            // fe:291-292
     int count = 0;
@@ -68,7 +70,9 @@ double PairANNP::init_one(int i, int j)
 int PairANNP::init_style(int newton_pair, int device)
 {
     if (!coeff_done_) return fail(ANNP_HIP_EARG, "All pair coeffs are not set");
-    if (newton_pair == 0) return fail(ANNP_HIP_EARG, "Pair style annp/hip requires newton pair on");   // fe:311-312
+    if (newton_pair == 0)                                          // fe:311-312; adp:375-376
+        return fail(ANNP_HIP_EARG, anna_ ? "Pair style Neural Network Potential requires newton pair on"
+                                         : "Pair style annp/hip requires newton pair on");
     const int n = ntypes_ + 1;
     for (int i = 1; i <= ntypes_; ++i)                             // pair_annp_gpu.cpp:170-183
         for (int j = i; j <= ntypes_; ++j) {
@@ -81,7 +85,9 @@ int PairANNP::init_style(int newton_pair, int device)
         }
     const int nsf = pot_.nsf, nl = pot_.ntl - 1;
     std::vector<double> scal(nsf), avg(nsf);
-    if (!pot_.has_symcoef) {                                       // pair_annp_gpu.cpp:207-216
+    if (anna_) {
+        // no normalisation in this pair style (adp:584-612)
+    } else if (!pot_.has_symcoef) {                                       // pair_annp_gpu.cpp:207-216
         for (int k = 0; k < nsf; ++k) {
             const double t_avg = pot_.norm_b[k], t_cov = pot_.norm_a[k];
             const double t_scale = std::sqrt(t_cov - t_avg * t_avg);
@@ -98,7 +104,9 @@ int PairANNP::init_style(int newton_pair, int device)
     std::memset(&prm, 0, sizeof(prm));
     prm.struct_bytes = (int)sizeof(prm);
     // the shipped Ni file still names "Chebyshev" (SURVEY.md 8a): the coefficient section decides
-    prm.descriptor = pot_.has_symcoef ? ANNP_HIP_DESC_BEHLER : ANNP_HIP_DESC_CHEBYSHEV;
+    prm.descriptor = anna_ ? ANNP_HIP_DESC_ANNA_ADP : pot_.has_symcoef ? ANNP_HIP_DESC_BEHLER : ANNP_HIP_DESC_CHEBYSHEV;
+    prm.nout = pot_.nout; prm.ngp = (int)pot_.gparams.size(); prm.gparams = pot_.gparams.empty() ? nullptr : pot_.gparams.data();
+    prm.e_base = pot_.e_base;
     prm.ntypes = ntypes_;
     prm.ntl = pot_.ntl; prm.nhl = pot_.nhl; prm.nnod = pot_.nnod;
     prm.nsf = nsf; prm.npsf = pot_.npsf; prm.ntsf = pot_.ntsf;
@@ -155,12 +163,27 @@ double PairANNP::memory_usage() const
 // -------------------------------------------------------------------------------------
 struct annp_pair {
     annp_host::PairANNP impl;
-    explicit annp_pair(int ntypes) : impl(ntypes) {}
+    explicit annp_pair(int ntypes, const char *style = "annp") : impl(ntypes, style) {}
 };
 
 extern "C" {
 
 annp_pair *annp_pair_create(int ntypes) { return new (std::nothrow) annp_pair(ntypes); }
+annp_pair *annp_pair_create_style(int ntypes, const char *style)
+{
+    if (!style || (std::strcmp(style, "annp") != 0 && std::strcmp(style, "anna_adp") != 0)) return nullptr;
+    return new (std::nothrow) annp_pair(ntypes, style);
+}
+int annp_pair_potential_anna(const annp_pair *p, int *nout, double *e_base, double *e_scal, double *gparams, int max_gp)
+{
+    if (!p || !p->impl.potential().is_anna) return ANNP_HIP_EARG;
+    const annp_host::Potential &q = p->impl.potential();
+    if (nout) *nout = q.nout;
+    if (e_base) *e_base = q.e_base;
+    if (e_scal) *e_scal = q.e_scal;
+    for (int k = 0; gparams && k < max_gp && k < (int)q.gparams.size(); k++) gparams[k] = q.gparams[k];
+    return (int)q.gparams.size();
+}
 void annp_pair_destroy(annp_pair *p) { delete p; }
 int annp_pair_settings(annp_pair *p, int narg, const char *const *arg) { return p ? p->impl.settings(narg, arg) : ANNP_HIP_EARG; }
 int annp_pair_coeff(annp_pair *p, int narg, const char *const *arg) { return p ? p->impl.coeff(narg, arg) : ANNP_HIP_EARG; }
@@ -194,8 +217,8 @@ int annp_pair_potential_info(const annp_pair *p, int *dims, double *scal, int *f
     if (dims) { dims[0] = q.ntl; dims[1] = q.nhl; dims[2] = q.nnod; dims[3] = q.nsf; dims[4] = q.npsf; dims[5] = q.ntsf; dims[6] = q.flagsym; dims[7] = q.has_symcoef ? 1 : 0; }
     if (scal) { scal[0] = q.cut; scal[1] = q.e_scale; scal[2] = q.e_shift; scal[3] = q.e_atom; scal[4] = q.elements.empty() ? 0.0 : q.elements[0].mass; }
     if (flagact) for (size_t l = 0; l < q.flagact.size(); ++l) flagact[l] = q.flagact[l];
-    if (norm_a) for (int k = 0; k < q.nsf; ++k) norm_a[k] = q.norm_a[k];
-    if (norm_b) for (int k = 0; k < q.nsf; ++k) norm_b[k] = q.norm_b[k];
+    if (norm_a) for (int k = 0; k < q.nsf && k < (int)q.norm_a.size(); ++k) norm_a[k] = q.norm_a[k];
+    if (norm_b) for (int k = 0; k < q.nsf && k < (int)q.norm_b.size(); ++k) norm_b[k] = q.norm_b[k];
     return 0;
 }
 int annp_pair_potential_layer(const annp_pair *p, int layer, double *w, double *b)

@@ -22,7 +22,9 @@ namespace annp_host {
 
 class PairANNP {
    public:
-    explicit PairANNP(int ntypes);
+    // style: "annp" (default) or "anna_adp" (reference: anna-gpu-lammps/bcc_fe/src/pair_anna_adp.{h,cpp},
+    // same life cycle and pair_coeff syntax, a `.anna` potential file)
+    explicit PairANNP(int ntypes, const char *style = "annp");
     ~PairANNP();
     PairANNP(const PairANNP &) = delete;
     PairANNP &operator=(const PairANNP &) = delete;
@@ -50,9 +52,11 @@ class PairANNP {
     annp_hip_handle *handle() const { return handle_; }
     void set_ni_compat(int v) { ni_compat_ = v; }
     bool behler() const { return pot_.has_symcoef; }
+    bool anna() const { return anna_; }
 
    private:
     int ntypes_;
+    bool anna_ = false;
     int ni_compat_ = 0;
     bool coeff_done_ = false;
     double cutmax_ = 0.0;
@@ -71,6 +75,7 @@ class PairANNP {
 extern "C" {
 typedef struct annp_pair annp_pair;
 annp_pair *annp_pair_create(int ntypes);
+annp_pair *annp_pair_create_style(int ntypes, const char *style);   /* "annp" | "anna_adp"; NULL on an unknown style */
 void annp_pair_destroy(annp_pair *p);
 int annp_pair_settings(annp_pair *p, int narg, const char *const *arg);
 int annp_pair_coeff(annp_pair *p, int narg, const char *const *arg);
@@ -89,6 +94,8 @@ const char *annp_pair_error(const annp_pair *p);
 annp_hip_handle *annp_pair_handle(const annp_pair *p);
 /* parsed potential, for tests: dims[8] = ntl nhl nnod nsf npsf ntsf flagsym has_symcoef;
  * scal[5] = cut e_scale e_shift e_atom mass */
+/* anna_adp extras: nout, e_base, e_scal and the ngp analytic parameters (returns ngp, or <0) */
+int annp_pair_potential_anna(const annp_pair *p, int *nout, double *e_base, double *e_scal, double *gparams, int max_gp);
 int annp_pair_potential_info(const annp_pair *p, int *dims, double *scal, int *flagact, double *norm_a, double *norm_b);
 int annp_pair_potential_layer(const annp_pair *p, int layer, double *w, double *b);
 int annp_pair_potential_sym(const annp_pair *p, double *rad, double *ang);

@@ -156,4 +156,95 @@ bool read_potential(const std::string &path, int nelements_coeff, Potential &pot
     return true;
 }
 
+// `.anna` layout (0-based lines; adp = bcc_fe/src/pair_anna_adp.cpp):
+//   5 nelements | 6.. id symbol mass | 8+ne TL HL nodes nout nsf npsf ntsf cut (adp:426-443)
+//   11+ne names (adp:444-461) | 14+ne e_base <TAB> e_scale (adp:462-470) | 17+ne ngp | 18+ne the ngp parameters
+//   then the weight / bias blocks; the last layer has nout rows (adp:497-553).  No normalisation rows.
+bool read_potential_anna(const std::string &path, int nelements_coeff, Potential &pot, std::string &err)
+{
+    std::ifstream fin(path.c_str());
+    if (!fin.is_open()) { err = "Cannot open physically informed neural network potential file"; return false; }   // adp:401
+    pot = Potential();
+    pot.is_anna = true;
+    std::string line;
+    int ne = 0, ngp = 0;
+    for (int i = 0; i < 19 + nelements_coeff; ++i) {
+        if (!std::getline(fin, line)) { err = "potential file ends inside the header"; return false; }
+        if (i == 5) {
+            ne = std::atoi(line.c_str());
+            if (ne < 1) { err = "potential file: bad element count"; return false; }
+            pot.elements.resize(ne);
+        } else if (i >= 6 && i < 6 + ne) {
+            Element &e = pot.elements[i - 6];
+            e.id = std::atoi(line.c_str());
+            for (char c : line) if (std::isalpha((unsigned char)c)) e.name += c;
+            const std::vector<double> m = unsigned_after_tabs(line);
+            if (!m.empty()) e.mass = m.back();
+        } else if (i == 8 + ne) {
+            pot.ntl = std::atoi(line.c_str());
+            const std::vector<double> v = unsigned_after_tabs(line);
+            if (v.size() < 7) { err = "potential file: network parameter line is short"; return false; }
+            pot.nhl = (int)v[0]; pot.nnod = (int)v[1]; pot.nout = (int)v[2]; pot.nsf = (int)v[3];
+            pot.npsf = (int)v[4]; pot.ntsf = (int)v[5]; pot.cut = v[6];
+            if (pot.ntl < 2 || pot.nnod < 1 || pot.nout < 1 || pot.nsf < 1 || pot.npsf + pot.ntsf != pot.nsf) {
+                err = "potential file: inconsistent network dimensions";
+                return false;
+            }
+        } else if (i == 11 + ne) {
+            for (size_t j = 0; j + 1 < line.size(); ++j) {
+                const char a = line[j], b = line[j + 1];
+                if (a == 'C' && b == 'h') pot.flagsym = 0;
+                if (a == 'B' && (b == 'e' || b == 'P')) pot.flagsym = 1;
+                if (a == 'C' && b == 'u') pot.flagsym = 2;
+                const int act = activation_code(a, b);
+                if (act >= 0) pot.flagact.push_back(act);
+            }
+        } else if (i == 14 + ne) {
+            pot.e_base = std::atof(line.c_str());
+            const std::vector<double> v = unsigned_after_tabs(line);
+            if (!v.empty()) pot.e_scal = v.back();
+        } else if (i == 17 + ne) {
+            ngp = std::atoi(line.c_str());
+            if (ngp < 17 || ngp > 64) { err = "potential file: the ADP form needs 17 parameters"; return false; }
+        } else if (i == 18 + ne) {
+            pot.gparams = row_values(line, true);
+            if ((int)pot.gparams.size() < ngp) { err = "potential file: ADP parameter row is short"; return false; }
+            pot.gparams.resize(ngp);
+        }
+    }
+    const int nl = pot.ntl - 1;
+    if ((int)pot.flagact.size() < nl) { err = "potential file: fewer activation names than layers"; return false; }
+    pot.flagact.resize(nl);
+    pot.weights.assign(nl, std::vector<double>());
+    pot.biases.assign(nl, std::vector<double>());
+    for (int l = 0; l < nl; ++l) {
+        pot.weights[l].assign((size_t)pot.rows(l) * pot.cols(l), 0.0);
+        pot.biases[l].assign(pot.rows(l), 0.0);
+    }
+    while (std::getline(fin, line)) {
+        if (line.size() < 2 || line[0] != '#' || !std::isdigit((unsigned char)line[1])) continue;
+        int layer = 0;
+        bool is_bias = false;
+        for (char c : line) {
+            if (c >= '0' && c <= '9') layer = layer * 10 + (c - '0');
+            if (c == 'w') is_bias = false;
+            if (c == 'b') is_bias = true;
+        }
+        const int l = layer - 1;
+        if (l < 0 || l >= nl) { err = "potential file: layer number out of range"; return false; }
+        if (!is_bias) {
+            for (int r = 0; r < pot.rows(l); ++r) {
+                if (!std::getline(fin, line)) { err = "potential file ends inside a weight block"; return false; }
+                const std::vector<double> v = row_values(line, true);
+                for (int c = 0; c < pot.cols(l) && c < (int)v.size(); ++c) pot.weights[l][(size_t)r * pot.cols(l) + c] = v[c];
+            }
+        } else {
+            if (!std::getline(fin, line)) { err = "potential file ends inside a bias block"; return false; }
+            const std::vector<double> v = row_values(line, true);
+            for (int c = 0; c < pot.rows(l) && c < (int)v.size(); ++c) pot.biases[l][c] = v[c];
+        }
+    }
+    return true;
+}
+
 }  // namespace annp_host

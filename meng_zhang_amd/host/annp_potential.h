@@ -31,7 +31,14 @@ struct Potential {
     std::vector<double> sym_rad;           // [npsf][3] eta, Rs, Rc
     std::vector<double> sym_ang;           // [ntsf][4] eta, lambda, zeta, Rc
 
-    int rows(int l) const { return l == ntl - 2 ? 1 : nnod; }
+    // pair_style anna_adp (anna-gpu-lammps/bcc_fe/src/pair_anna_adp.h:58-67): the network ends in `nout`
+    // local parameters of an analytic ADP form instead of an energy
+    bool is_anna = false;
+    int nout = 1;
+    double e_base = 0.0, e_scal = 0.0;
+    std::vector<double> gparams;           // A0 yy gamma C0 c1F c2F V0 b1 b2 delta r0 r1 hc d1 q1 d3 q3
+
+    int rows(int l) const { return l == ntl - 2 ? nout : nnod; }
     int cols(int l) const { return l == 0 ? nsf : nnod; }
 };
 
@@ -39,5 +46,9 @@ struct Potential {
 // Returns true on success; on failure `err` says why (text matches the reference's
 // error where it has one: "Cannot open neural network potential file").
 bool read_potential(const std::string &path, int nelements_coeff, Potential &pot, std::string &err);
+
+// The `.anna` file of pair_style anna_adp, as PairANNA_ADP::read_file consumes it
+// (anna-gpu-lammps/bcc_fe/src/pair_anna_adp.cpp:392-566).
+bool read_potential_anna(const std::string &path, int nelements_coeff, Potential &pot, std::string &err);
 
 }  // namespace annp_host

@@ -16,7 +16,7 @@ PAIR_SYMBOLS = [
     "annp_pair_create", "annp_pair_destroy", "annp_pair_settings", "annp_pair_coeff", "annp_pair_set_ni_compat",
     "annp_pair_init_style", "annp_pair_init_one", "annp_pair_compute", "annp_pair_compute_n",
     "annp_pair_memory_usage", "annp_pair_error", "annp_pair_handle", "annp_pair_potential_info",
-    "annp_pair_potential_layer", "annp_pair_potential_sym",
+    "annp_pair_potential_layer", "annp_pair_potential_sym", "annp_pair_create_style", "annp_pair_potential_anna",
 ]
 
 
@@ -56,6 +56,11 @@ def load_library():
                                                 C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), ip, vp]
     lib.annp_pair_create.argtypes = [C.c_int]
     lib.annp_pair_create.restype = vp
+    lib.annp_pair_create_style.argtypes = [C.c_int, C.c_char_p]
+    lib.annp_pair_create_style.restype = vp
+    lib.annp_pair_potential_anna.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                             C.POINTER(C.c_double), C.c_int]
+    lib.annp_pair_potential_anna.restype = C.c_int
     lib.annp_pair_destroy.argtypes = [vp]
     lib.annp_pair_destroy.restype = None
     lib.annp_pair_settings.argtypes = [vp, C.c_int, cpp]

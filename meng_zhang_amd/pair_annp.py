@@ -53,11 +53,13 @@ def _ip(a):
 
 
 class PairANNP:
-    def __init__(self, ntypes=1, device=0, newton_pair=1):
+    def __init__(self, ntypes=1, device=0, newton_pair=1, style="annp"):
+        """style: "annp" (pair_style annp, .ann files) or "anna_adp" (pair_style anna_adp, .anna files)"""
         self._lib = load_library()
-        self._p = self._lib.annp_pair_create(ntypes)
+        self._p = self._lib.annp_pair_create_style(ntypes, style.encode())
         if not self._p:
-            raise MemoryError("annp_pair_create failed")
+            raise ValueError("unknown pair style %r" % style)
+        self.style = style
         self.ntypes = ntypes
         self.device = device
         self.newton_pair = newton_pair
@@ -169,8 +171,16 @@ class PairANNP:
         out = dict(ntl=ntl, nhl=nhl, nnod=nnod, nsf=nsf, npsf=npsf, ntsf=ntsf, flagsym=flagsym, has_symcoef=has_sym,
                    cut=scal[0], e_scale=scal[1], e_shift=scal[2], e_atom=scal[3], mass=scal[4],
                    flagact=act[: ntl - 1].copy(), norm_a=na[:nsf].copy(), norm_b=nb[:nsf].copy(), W=[], B=[])
+        nout = 1
+        if self.style == "anna_adp":
+            no, eb, es, gp = C.c_int(0), C.c_double(0), C.c_double(0), np.zeros(64)
+            ngp = self._lib.annp_pair_potential_anna(self._p, C.byref(no), C.byref(eb), C.byref(es), _dp(gp), 64)
+            if ngp < 0:
+                self._check(ngp)
+            nout = no.value
+            out.update(nout=nout, e_base=eb.value, e_scal=es.value, gparams=gp[:ngp].copy())
         for l in range(ntl - 1):
-            nr = 1 if l == ntl - 2 else nnod
+            nr = nout if l == ntl - 2 else nnod
             nc = nsf if l == 0 else nnod
             w, b = np.zeros(nr * nc), np.zeros(nr)
             self._check(self._lib.annp_pair_potential_layer(self._p, l, _dp(w), _dp(b)))
