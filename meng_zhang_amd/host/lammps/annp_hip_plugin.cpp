@@ -13,6 +13,11 @@ static Pair *annp_hip_creator(LAMMPS *lmp)
   return new PairANNPHIP(lmp);
 }
 
+static Pair *anna_adp_hip_creator(LAMMPS *lmp)
+{
+  return new PairANNAADPHIP(lmp);
+}
+
 extern "C" void lammpsplugin_init(void *lmp, void *handle, void *regfunc)
 {
   lammpsplugin_t plugin;
@@ -25,5 +30,10 @@ extern "C" void lammpsplugin_init(void *lmp, void *handle, void *regfunc)
   plugin.author = "annp-hip";
   plugin.creator.v1 = (lammpsplugin_factory1 *) &annp_hip_creator;
   plugin.handle = handle;
+  (*register_plugin)(&plugin, lmp);
+
+  plugin.name = "anna_adp/hip";
+  plugin.info = "ANN-parametrised ADP potential (pair_style anna_adp) evaluated on AMD MI355X through libannp_hip";
+  plugin.creator.v1 = (lammpsplugin_factory1 *) &anna_adp_hip_creator;
   (*register_plugin)(&plugin, lmp);
 }

@@ -20,7 +20,7 @@
 
 using namespace LAMMPS_NS;
 
-PairANNPHIP::PairANNPHIP(LAMMPS *lmp) : Pair(lmp), impl(nullptr), cutmax(0.0), device_id(0), device_neigh(0)
+PairANNPHIP::PairANNPHIP(LAMMPS *lmp) : Pair(lmp), impl(nullptr), host_style("annp"), cutmax(0.0), device_id(0), device_neigh(0)
 {
   restartinfo = 0;      // fe_v2/src/pair_annp.cpp:45-47
   one_coeff = 1;
@@ -49,14 +49,14 @@ void PairANNPHIP::allocate()
 
 void PairANNPHIP::settings(int narg, char **arg)
 {
-  if (!impl) impl = new annp_host::PairANNP(atom->ntypes);
+  if (!impl) impl = new annp_host::PairANNP(atom->ntypes, host_style);
   if (impl->settings(narg, arg) != 0) error->all(FLERR, impl->error());
 }
 
 void PairANNPHIP::coeff(int narg, char **arg)
 {
   if (!allocated) allocate();
-  if (!impl) impl = new annp_host::PairANNP(atom->ntypes);
+  if (!impl) impl = new annp_host::PairANNP(atom->ntypes, host_style);
   if (impl->coeff(narg, arg) != 0) error->all(FLERR, impl->error());
   cutmax = impl->cutmax();
   for (int i = 1; i <= atom->ntypes; i++)

@@ -10,12 +10,19 @@
  * requirements (newton_pair on, full neighbour list, one_coeff, manybody).
  * It owns no arithmetic: everything is forwarded to annp_host::PairANNP
  * (annp_pair.h), i.e. to the C ABI in include/annp_hip.h.
+ *
+ * pair_style anna_adp/hip is the same adaptor over the reference's second pair style
+ * (anna-gpu-lammps/bcc_fe/src/pair_anna_adp.h:24-31: identical surface, `.anna` potential
+ * file, `pair_coeff * * fe_adp_potential_2310.anna Fe`); newton_pair must be on, as for the
+ * reference's CPU style (bcc_fe/README.md "MD simulation in Lammps").
  */
 #ifdef PAIR_CLASS
 // clang-format off
 PairStyle(annp/hip, PairANNPHIP);
+PairStyle(anna_adp/hip, PairANNAADPHIP);
 #ifdef ANNP_HIP_OVERRIDE_ANNP
 PairStyle(annp, PairANNPHIP);
+PairStyle(anna_adp, PairANNAADPHIP);
 #endif
 // clang-format on
 #else
@@ -42,10 +49,16 @@ class PairANNPHIP : public Pair {
 
  protected:
   annp_host::PairANNP *impl;
+  const char *host_style;   // "annp" | "anna_adp": which reference pair style the host mirror follows
   double cutmax;
   int device_id;      // GPU of this rank: ANNP_HIP_DEVICE or (local rank mod visible devices)
   int device_neigh;   // ANNP_HIP_NEIGH=device: list built on the GPU (annp_gpu_compute_n analogue, `package gpu neigh yes`)
   void allocate();
+};
+
+class PairANNAADPHIP : public PairANNPHIP {
+ public:
+  PairANNAADPHIP(class LAMMPS *lmp) : PairANNPHIP(lmp) { host_style = "anna_adp"; }
 };
 
 }    // namespace LAMMPS_NS
