@@ -28,6 +28,8 @@ struct AnnaArgs {
     double rc;                      // adp:172,219 test r (not r^2) against the file's cutoff
     const double *G;                // [inum][ANNP_GPAD] raw descriptor sums (pass 1)
     const double *net;              // per layer: W row-major [rows][cols], then B [rows]; layer 0 in the device layout
+    int net_doubles;                // size of `net`
+    int net_in_lds;                 // 1: the block keeps a copy of `net` in LDS (it fits ANNA_NET_LDS_MAX doubles)
     int nl, nin, nnod, nout;        // nin = columns of layer 0 (device layout)
     int act[ANNA_MAXL];
     double gp[17];                  // A0 yy gamma C0 c1F c2F V0 b1 b2 delta r0 r1 hc d1 q1 d3 q3
@@ -36,14 +38,50 @@ struct AnnaArgs {
     int *errflag;
 };
 
+constexpr int ANNA_NET_LDS_MAX = 4096;     // doubles: 32 KB
 __host__ __device__ inline size_t anna_lds_per_wave(int n_cap) { return (size_t)n_cap * (4 * 8 + 4) + 2 * 64 * 8; }
+__host__ __device__ inline size_t anna_lds_net(int net_doubles) { return net_doubles <= ANNA_NET_LDS_MAX ? ((size_t)net_doubles * 8 + 15) / 16 * 16 : 0; }
+
+// exp(x) without libm's special-case branches: x = k ln2 + r, degree-13 Taylor on |r| <= ln2/2 (truncation 4e-18),
+// scaled by 2^k.  Arguments here are a few tens at most; the clamp only keeps garbage finite.
+__device__ __forceinline__ double exp_fast(double x)
+{
+    x = fmin(fmax(x, -700.0), 700.0);
+    const double kf = rint(x * 1.4426950408889634074);
+    double r = fma(-kf, 6.93147180369123816490e-01, x);
+    r = fma(-kf, 1.90821492927058770002e-10, r);
+    double q = 1.0 / 6227020800.0;
+    q = fma(q, r, 1.0 / 479001600.0);
+    q = fma(q, r, 1.0 / 39916800.0);
+    q = fma(q, r, 1.0 / 3628800.0);
+    q = fma(q, r, 1.0 / 362880.0);
+    q = fma(q, r, 1.0 / 40320.0);
+    q = fma(q, r, 1.0 / 5040.0);
+    q = fma(q, r, 1.0 / 720.0);
+    q = fma(q, r, 1.0 / 120.0);
+    q = fma(q, r, 1.0 / 24.0);
+    q = fma(q, r, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return __builtin_ldexp(q, (int)kf);
+}
+
+// 1/x to ~1 ulp: hardware estimate + two Newton steps
+__device__ __forceinline__ double rcp_fast(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(y, fma(-x, y, 1.0), y);
+    y = fma(y, fma(-x, y, 1.0), y);
+    return y;
+}
 
 // adp:607-631 (3 and 4 are the same function here: 1.7 tanh(0.3 a))
 __device__ __forceinline__ double anna_act(int flag, double a)
 {
     if (flag == 0) return a;
     if (flag == 1) return tanh_fast(a);
-    if (flag == 2) return 1.0 / (1.0 + exp(a));
+    if (flag == 2) return 1.0 / (1.0 + exp_fast(a));
     return 1.7 * tanh_fast(0.3 * a);
 }
 
@@ -53,14 +91,22 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
-    if (ii >= p.inum) return;
     const int cap = p.n_cap;
-    unsigned char *wbase = lds_raw + (size_t)wave * anna_lds_per_wave(cap);
+    // the network's weights: a per-lane dot product reads one weight per step, and from global memory every one of
+    // those steps is a full memory round trip (40 in a row for 28-6-6-2); the block keeps them in LDS instead.
+    // Every wave writes the same values, so no ordering between waves is needed.
+    double *Lnet = reinterpret_cast<double *>(lds_raw);
+    if (p.net_in_lds)
+        for (int idx = lane; idx < p.net_doubles; idx += 64) Lnet[idx] = p.net[idx];
+    unsigned char *wbase = lds_raw + (p.net_in_lds ? anna_lds_net(p.net_doubles) : 0) + (size_t)wave * anna_lds_per_wave(cap);
     double *Ldx = reinterpret_cast<double *>(wbase), *Ldy = Ldx + cap, *Ldz = Ldy + cap, *Lr = Ldz + cap;
-    double *hbuf = Lr + cap;                                   // [2][64] network activations
-    int *Lj = reinterpret_cast<int *>(hbuf + 128);
-
+    double *hbuf0 = Lr + cap;                                  // [2][64] network activations
+    int *Lj = reinterpret_cast<int *>(hbuf0 + 128);
+    // a wave walks over many atoms and adds its energies once at the end: one atomic per atom on the single
+    // energy word would serialise the whole launch (1 M same-address atomics ~ 12 ms)
+    double e_wave = 0.0;
+    for (int ii = uniform(blockIdx.x * ANNP_WAVES_PER_BLOCK + wave); ii < p.inum; ii += gridDim.x * ANNP_WAVES_PER_BLOCK) {
+    double *hbuf = hbuf0;
     const int i = p.ilist ? p.ilist[ii] : ii;
     const double xi = p.x[3 * (size_t)i], yi = p.x[3 * (size_t)i + 1], zi = p.x[3 * (size_t)i + 2];
     const int *row = p.neigh + p.first[i];
@@ -94,31 +140,35 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
         }
     }
     n = uniform(n);
-    if (n > cap) { if (lane == 0) atomicMax(p.errflag, n); return; }
+    if (n > cap) { if (lane == 0) atomicMax(p.errflag, n); continue; }
 
-    // ---- the network (adp:633-667): lane r owns output row r of the current layer; sums run over the inputs
-    //      in file order, bias added last, as dot_add_wxb does (adp:599-604)
+    // ---- the network (adp:633-667).  A row's dot product is split over P = 2^k lanes (as many as fit 64 / rows)
+    //      and folded with xor-shuffles: a 28-term sum is then 4 FMAs + 3 shuffles deep instead of 28 dependent
+    //      LDS reads.  Bias added last as dot_add_wxb does (adp:599-604); the order of the terms differs from the
+    //      reference's left-to-right sum by rounding only.
     {
         double *hin = hbuf, *hout = hbuf + 64;
         if (lane < p.nin) hin[lane] = p.G[(size_t)ii * ANNP_GPAD + lane];
         wave_lds_sync();
-        const double *w = p.net;
+        const double *w = p.net_in_lds ? Lnet : p.net;
         for (int l = 0; l < p.nl; l++) {
             const int nr = (l == p.nl - 1) ? p.nout : p.nnod;
             const int nc = (l == 0) ? p.nin : p.nnod;
-            if (lane < nr) {
-                const double *wr = w + (size_t)lane * nc;
-                double a = 0.0;
-                for (int c = 0; c < nc; c++) a = fma(wr[c], hin[c], a);
-                a += w[(size_t)nr * nc + lane];
-                hout[lane] = anna_act(p.act[l], a);
+            int P = 1;
+            while (2 * P * nr <= 64) P *= 2;
+            const int r = lane / P, part = lane % P;
+            double a = 0.0;
+            if (r < nr) {
+                const double *wr = w + (size_t)r * nc;
+                for (int c = part; c < nc; c += P) a = fma(wr[c], hin[c], a);
             }
+            for (int off = P >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+            if (r < nr && part == 0) hout[r] = anna_act(p.act[l], a + w[(size_t)nr * nc + r]);
             w += (size_t)nr * nc + nr;
             wave_lds_sync();
             double *t = hin; hin = hout; hout = t;
         }
-        // hin now holds the outputs
-        hbuf = hin;
+        hbuf = hin;      // the outputs
     }
     const double d2 = hbuf[0], q2 = hbuf[1];                   // adp:162
 
@@ -127,32 +177,35 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
     const double d1 = p.gp[13], q1 = p.gp[14], d3 = p.gp[15], q3 = p.gp[16];
     const double rep_coeff = V0 / (b2 - b1);
 
-    // ---- per-neighbour functions, kept in registers for the force loop, and the atom's sums (adp:165-196)
-    double stpf[ANNA_NR], dstpf[ANNA_NR], uterm[ANNA_NR], wterm[ANNA_NR], expz[ANNA_NR], zyy[ANNA_NR], zb1[ANNA_NR], zb2[ANNA_NR];
+    // ---- per-neighbour functions, kept in registers for the force loop, and the atom's sums (adp:165-196).
+    //      The reference's pow(z, b) are exp(b log z) here (one log serves both repulsive powers, and their
+    //      reciprocals are what the formulas use), its divisions are reciprocals: same values to a few ulp.
+    double stpf[ANNA_NR], dstpf[ANNA_NR], uterm[ANNA_NR], wterm[ANNA_NR], expz[ANNA_NR], zyy[ANNA_NR], izb1[ANNA_NR], izb2[ANNA_NR];
     double mu0 = 0.0, mu1 = 0.0, mu2 = 0.0, l00 = 0.0, l11 = 0.0, l22 = 0.0, l01 = 0.0, l02 = 0.0, l12 = 0.0, rho = 0.0, rep = 0.0;
+    const double inv_hc = 1.0 / hc, inv_r1 = 1.0 / r1;
 #pragma unroll
     for (int k = 0; k < ANNA_NR; k++) {
         const int a = lane + 64 * k;
-        stpf[k] = dstpf[k] = uterm[k] = wterm[k] = expz[k] = zyy[k] = 0.0; zb1[k] = zb2[k] = 1.0;
+        stpf[k] = dstpf[k] = uterm[k] = wterm[k] = expz[k] = zyy[k] = 0.0; izb1[k] = izb2[k] = 1.0;
         if (a < n) {
             const double r = Lr[a], dx = Ldx[a], dy = Ldy[a], dz = Ldz[a];
-            const double sx = (r - p.rc) / hc;
-            const double sx2 = sx * sx, sx4 = sx2 * sx2, t1 = 1.0 + sx4;
-            stpf[k] = sx4 / t1;
-            dstpf[k] = 4.0 * (sx2 * sx) / (t1 * t1) / hc;
-            uterm[k] = d1 * exp(-d2 * r);
-            wterm[k] = q1 * exp(-q2 * r);
+            const double sx = (r - p.rc) * inv_hc;
+            const double sx2 = sx * sx, sx4 = sx2 * sx2, it1 = rcp_fast(1.0 + sx4);
+            stpf[k] = sx4 * it1;
+            dstpf[k] = 4.0 * (sx2 * sx) * (it1 * it1) * inv_hc;
+            uterm[k] = d1 * exp_fast(-d2 * r);
+            wterm[k] = q1 * exp_fast(-q2 * r);
             const double u = stpf[k] * (uterm[k] + d3), w = stpf[k] * (wterm[k] + q3);
             mu0 = fma(u, dx, mu0); mu1 = fma(u, dy, mu1); mu2 = fma(u, dz, mu2);
             l00 = fma(w * dx, dx, l00); l11 = fma(w * dy, dy, l11); l22 = fma(w * dz, dz, l22);
             l01 = fma(w * dx, dy, l01); l02 = fma(w * dx, dz, l02); l12 = fma(w * dy, dz, l12);
             const double rho_z = r - r0;
-            expz[k] = exp(-gamma * rho_z);
-            zyy[k] = A0 * pow(rho_z, yy);
+            expz[k] = exp_fast(-gamma * rho_z);
+            zyy[k] = A0 * exp_fast(yy * log(rho_z));
             rho += stpf[k] * (zyy[k] * expz[k] * (1.0 + expz[k]) + C0);
-            const double repul_z = r / r1;
-            zb1[k] = pow(repul_z, b1); zb2[k] = pow(repul_z, b2);
-            rep += stpf[k] * (rep_coeff * (b2 / zb1[k] - b1 / zb2[k]) + delta);
+            const double lz = log(r * inv_r1);
+            izb1[k] = exp_fast(-b1 * lz); izb2[k] = exp_fast(-b2 * lz);
+            rep += stpf[k] * (rep_coeff * (b2 * izb1[k] - b1 * izb2[k]) + delta);
         }
     }
     mu0 = wave_sum(mu0); mu1 = wave_sum(mu1); mu2 = wave_sum(mu2);
@@ -168,10 +221,8 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
     const double e_ang = 0.5 * sum_mu + 0.5 * sum_lam - 1.0 / 6.0 * v_i * v_i;
     const double e_emb = c1F * sqrt(rho) + c2F * rho * rho;
     const double evdwl = 0.5 * rep + e_emb + e_ang + p.e_base;
-    if (lane == 0) {
-        if (p.eatom) p.eatom[i] += evdwl;
-        if (p.eng) atomicAdd(p.eng, evdwl);
-    }
+    if (lane == 0 && p.eatom) p.eatom[i] += evdwl;
+    e_wave += evdwl;
     const double demb = 0.5 * c1F / sqrt(rho) + 2.0 * c2F * rho;       // adp:237
 
     // ---- forces (adp:215-280)
@@ -184,24 +235,24 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
             const double rij = Lr[a], dx = Ldx[a], dy = Ldy[a], dz = Ldz[a];
             const double rho_z = rij - r0;
             const double ga_zyy = zyy[k] * gamma;
-            const double d_rho = expz[k] * (1.0 + expz[k]) * (zyy[k] * (dstpf[k] + stpf[k] * yy / rho_z) - ga_zyy) + C0 * dstpf[k] -
+            const double d_rho = expz[k] * (1.0 + expz[k]) * (zyy[k] * (dstpf[k] + stpf[k] * yy * rcp_fast(rho_z)) - ga_zyy) + C0 * dstpf[k] -
                                  ga_zyy * expz[k] * expz[k];
             const double d_embed = demb * d_rho;
-            const double repul_z = rij / r1;
-            const double drep_t = b2 * b1 / r1;
-            const double rep_t1 = rep_coeff * (b2 / zb1[k] - b1 / zb2[k]) + delta;
-            const double d_repul = dstpf[k] * rep_t1 + stpf[k] * rep_coeff * (drep_t / repul_z * (-1.0 / zb1[k] + 1.0 / zb2[k]));
+            const double inv_r = rcp_fast(rij);
+            const double drep_t = b2 * b1 * inv_r1;
+            const double rep_t1 = rep_coeff * (b2 * izb1[k] - b1 * izb2[k]) + delta;
+            const double d_repul = dstpf[k] * rep_t1 + stpf[k] * rep_coeff * (drep_t * (r1 * inv_r) * (izb2[k] - izb1[k]));
             const double adp_u = stpf[k] * (uterm[k] + d3);
             const double adp_w = 2.0 * stpf[k] * (wterm[k] + q3);
             const double d_adp_u = dstpf[k] * (uterm[k] + d3) + stpf[k] * (-d2 * uterm[k]);
             const double d_adp_w = dstpf[k] * (wterm[k] + q3) + stpf[k] * (-q2 * wterm[k]);
             const double lamb1 = d_adp_w * (l00 * dx * dx + l11 * dy * dy + l22 * dz * dz);
             const double lamb2 = d_adp_w * (l01 * dx * dy + l02 * dx * dz + l12 * dy * dz) * 2.0 + lamb1;
-            const double df1 = 0.5 * d_repul + d_embed + d_adp_u * (mu0 * dx + mu1 * dy + mu2 * dz) + lamb2;
+            const double df1 = (0.5 * d_repul + d_embed + d_adp_u * (mu0 * dx + mu1 * dy + mu2 * dz) + lamb2) * inv_r;
             const double df3 = f_v * (d_adp_w * rij + adp_w);
-            const double fx = df1 * dx / rij + adp_w * (dy * l01 + dz * l02 + dx * l00) + mu0 * adp_u + dx * df3;
-            const double fy = df1 * dy / rij + adp_w * (dy * l11 + dz * l12 + dx * l01) + mu1 * adp_u + dy * df3;
-            const double fz = df1 * dz / rij + adp_w * (dy * l12 + dz * l22 + dx * l02) + mu2 * adp_u + dz * df3;
+            const double fx = df1 * dx + adp_w * (dy * l01 + dz * l02 + dx * l00) + mu0 * adp_u + dx * df3;
+            const double fy = df1 * dy + adp_w * (dy * l11 + dz * l12 + dx * l01) + mu1 * adp_u + dy * df3;
+            const double fz = df1 * dz + adp_w * (dy * l12 + dz * l22 + dx * l02) + mu2 * adp_u + dz * df3;
             const int j = Lj[a];
             atomicAdd(&p.f[3 * (size_t)j], fx); atomicAdd(&p.f[3 * (size_t)j + 1], fy); atomicAdd(&p.f[3 * (size_t)j + 2], fz);
             fi0 -= fx; fi1 -= fy; fi2 -= fz;
@@ -235,6 +286,12 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
             }
         }
     }
+    wave_lds_sync();        // the next atom reuses the records
+    }
+    if (p.eng && lane == 0 && e_wave != 0.0) atomicAdd(p.eng, e_wave);
 }
+
+// the walk above wants a bounded grid: enough waves to fill the chip several times over, no more
+inline int anna_blocks(int inum) { return std::max(1, std::min((inum + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK, 256 * 16)); }
 
 }  // namespace annp

@@ -51,6 +51,7 @@ struct annp_hip_handle {
     int nout = 1;
     double e_base = 0.0, gp[17] = {0};
     double *d_net = nullptr;            // network image for annp_anna_adp (layer 0 in the device feature layout)
+    int net_doubles = 0;
     int ni_cap = 24;                    // Behler kernels: record capacity per atom for the next descriptor pass
     int ni_cap_last = 0;                // ... and what the last force pass ran with
     int flagact[MLP_MAXL] = {0, 0, 0, 0};
@@ -256,14 +257,15 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         AnnaArgs q{};
         q.inum = inum; q.ilist = d_ilist; q.x = d_x; q.numneigh = d_numneigh; q.first = d_first; q.neigh = d_neigh;
         q.n_cap = 64 * ANNA_NR; q.rc = h->cut; q.G = h->G.p; q.net = h->d_net;
+        q.net_doubles = h->net_doubles; q.net_in_lds = h->net_doubles <= ANNA_NET_LDS_MAX;
         q.nl = h->nl; q.nin = h->nsf_dev; q.nnod = h->nnod; q.nout = h->nout;
         for (int l = 0; l < h->nl; l++) q.act[l] = h->flagact[l];
         for (int k = 0; k < 17; k++) q.gp[k] = h->gp[k];
         q.e_base = h->e_base;
         q.f = d_f; q.eatom = d_eatom; q.eng = d_eng; q.virial = d_virial; q.vatom = d_vatom; q.errflag = h->d_flags;
-        const size_t lds2 = anna_lds_per_wave(q.n_cap) * ANNP_WAVES_PER_BLOCK;
-        if (d_virial || d_vatom) hipLaunchKernelGGL((annp_anna_adp<true>), dim3(blocks), dim3(256), lds2, s, q);
-        else hipLaunchKernelGGL((annp_anna_adp<false>), dim3(blocks), dim3(256), lds2, s, q);
+        const size_t lds2 = anna_lds_per_wave(q.n_cap) * ANNP_WAVES_PER_BLOCK + anna_lds_net(h->net_doubles);
+        if (d_virial || d_vatom) hipLaunchKernelGGL((annp_anna_adp<true>), dim3(anna_blocks(inum)), dim3(256), lds2, s, q);
+        else hipLaunchKernelGGL((annp_anna_adp<false>), dim3(anna_blocks(inum)), dim3(256), lds2, s, q);
         HIP_TRY(h, hipGetLastError());
         // more in-range neighbours than a wave holds (128) is reported at the next sync point
         HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -432,6 +434,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
             }
             img.insert(img.end(), p->bias_all[l], p->bias_all[l] + nr);
         }
+        h->net_doubles = (int)img.size();
         INIT_TRY(hipMalloc((void **)&h->d_net, sizeof(double) * img.size()));
         INIT_TRY(hipMemcpy(h->d_net, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
         h->bytes += sizeof(double) * img.size();

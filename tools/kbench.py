@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool: kernel timings (HIP events) of one force evaluation for a synthetic box.
    python tools/kbench.py fe 80      # bcc Fe, 80^3 cells
-   python tools/kbench.py ni 40 40 80  # fcc Ni 40x40x80 cells (512 000 atoms)"""
+   python tools/kbench.py ni 40 40 80  # fcc Ni 40x40x80 cells (512 000 atoms)
+   python tools/kbench.py anna 80      # bcc Fe, pair_style anna_adp (list cutoff 5.055 + 2 A)"""
 import ctypes as C
 import os
 import sys
@@ -23,7 +24,7 @@ class _NoDist:
 
 def main():
     import torch
-    from annp_testlib import A_FE, A_NI, FE_POT, NI_POT, bcc, fcc, perturb
+    from annp_testlib import A_FE, A_NI, ANNA_POT, FE_POT, NI_POT, bcc, fcc, perturb
     from meng_zhang_amd import PairANNP
     from meng_zhang_amd.domain import Domain, HaloPlan
     from meng_zhang_amd.lib import load_library
@@ -32,25 +33,29 @@ def main():
     while len(dims) < 3:
         dims.append(dims[-1])
     reps = 5
+    style, rc_list = "annp", 8.5
     if kind == "fe":
         x0, box = bcc(*dims, A_FE)
         pot, el = FE_POT, "Fe"
+    elif kind == "anna":
+        x0, box = bcc(*dims, A_FE)
+        pot, el, style, rc_list = ANNA_POT, "Fe", "anna_adp", 7.055
     else:
         x0, box = fcc(*dims, A_NI)
         pot, el = NI_POT, "Ni"
     xg = perturb(x0, 12345, 0.05)
     lib = load_library()
     dev = torch.device("cuda", 0)
-    plan = HaloPlan(x0, box, (1, 1, 1), 8.5, 1, 0)
+    plan = HaloPlan(x0, box, (1, 1, 1), rc_list, 1, 0)
     dom = Domain(plan, xg, dev, _NoDist())
-    pair = PairANNP(1, device=0)
+    pair = PairANNP(1, device=0, style=style)
     pair.settings([])
     pair.coeff(["*", "*", pot, el])
     pair.init_style()
     h = pair.handle
     st = torch.cuda.current_stream(dev).cuda_stream
     pn, pf, pg, mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
-    assert lib.annp_hip_neigh_build_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), 8.5, C.byref(pn), C.byref(pf), C.byref(pg), C.byref(mx), st) == 0
+    assert lib.annp_hip_neigh_build_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), rc_list, C.byref(pn), C.byref(pf), C.byref(pg), C.byref(mx), st) == 0
     eng = torch.zeros(1, dtype=torch.float64, device=dev)
     lib.annp_hip_set_timing(h, 1)
     for _ in range(reps + 1):
