@@ -35,6 +35,7 @@ namespace annp {
 constexpr int FE_NP = 9;      // radial Chebyshev orders the kernels are instantiated for (T_0..T_8)
 constexpr int FE_NT = 19;     // angular orders (T_0..T_18); smaller bases are embedded with zero weights (annp_hip_init)
 constexpr int FE_Q = 4;       // chunks per tournament row
+constexpr int FE_REDROW = 72; // row pitch (doubles) of the reduction scratch: rows 16 banks apart, see annp_fe_desc
 constexpr int FE_DUMP = 8;    // null / dump slots behind the records: where masked-off pair steps read and scatter
 
 struct FeArgs {
@@ -70,7 +71,7 @@ __host__ __device__ inline int fe_slots(int n_cap) { return n_cap + fe_lcap(n_ca
 __host__ __device__ inline size_t fe_desc_lds_per_wave(int n_cap)
 {
     size_t rec = (size_t)fe_slots(n_cap) * 32;      // multiple of 16: every wave's base stays b128-aligned
-    return rec < 4096 + 512 ? 4096 + 512 : rec;     // reduction scratch [8][64] + [64] results
+    return rec < 8 * FE_REDROW * 8 + 512 ? 8 * FE_REDROW * 8 + 512 : rec;     // reduction scratch [8][FE_REDROW] + [64] results
 }
 // AUXREG (n_cap <= 128): a lane owns neighbours lane and lane+64 and keeps their 1/r and fc' in registers;
 // otherwise they live in LDS.  The neighbour index always does (it is written by the compacting lane).
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
     double2 *recA = reinterpret_cast<double2 *>(wbase);
     double2 *recB = recA + fe_slots(p.n_cap);
     double *scratch = reinterpret_cast<double *>(wbase);          // reused after the pair loop: [8][64]
-    double *red = scratch + 8 * 64;                               // [64] reduced sums
+    double *red = scratch + 8 * FE_REDROW;                        // [64] reduced sums
     const int NZ = p.n_cap + fe_lcap(p.n_cap);                    // first null record
 
     const int i = p.ilist ? p.ilist[ii] : ii;
@@ -297,15 +298,17 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
             else if (m == NP + NT) v = vx;
             else if (m == NP + NT + 1) v = vy;
             else if (m == NP + NT + 2) v = vz;
-            scratch[k * 64 + lane] = v;
+            scratch[k * FE_REDROW + lane] = v;
         }
         wave_lds_sync();
         {
+            // lane (k, part) sums every 8th value of row k: the 8 lanes of a row read 8 consecutive doubles and the
+            // rows sit 16 banks apart (pitch 72), a 2-way conflict; contiguous 8-value chunks per lane were 16-way
             const int k = lane >> 3, part = lane & 7;
-            const double *src = scratch + k * 64 + part * 8;
+            const double *src = scratch + k * FE_REDROW + part;
             double sm = 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; u++) sm += src[u];
+            for (int u = 0; u < 8; u++) sm += src[8 * u];
             sm += __shfl_xor(sm, 1, 64);
             sm += __shfl_xor(sm, 2, 64);
             sm += __shfl_xor(sm, 4, 64);

@@ -31,6 +31,8 @@ namespace annp {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int MLP_MAXL = 4;   // weight layers supported by the MFMA path (ntl-1)
+constexpr int MLP_CROW = ANNP_CPAD + 1;   // row pitch of the coefficient staging buffer: an even pitch of 48 puts the 16
+                                          // atoms of a fragment column on two banks (8-way conflict on every write)
 
 struct MlpArgs {
     int inum;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
     constexpr int KSH = S::KSH, MT0 = S::MT0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *opnd = reinterpret_cast<double *>(lds_raw);                 // [S::total][64]
-    double *cbuf_all = opnd + (size_t)S::total * 64;                    // [4 waves][16][ANNP_CPAD]
+    double *cbuf_all = opnd + (size_t)S::total * 64;                    // [4 waves][16][MLP_CROW]
 
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
         for (int idx = threadIdx.x; idx < S::total * 32; idx += 256) dst[idx] = src[idx];
     }
     __syncthreads();
-    double *cbuf = cbuf_all + (size_t)wave * 16 * ANNP_CPAD;
+    double *cbuf = cbuf_all + (size_t)wave * 16 * MLP_CROW;
     ActParam ap[NL];
 #pragma unroll
     for (int l = 0; l < NL; l++) ap[l] = act_param(p.act[l], p.act_plain);
@@ -295,13 +297,13 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
             for (int s = 0; s < KSH; s++)
                 acc = mfma_f64(opnd[(size_t)(S::bwd0 + mt * KSH + s) * 64 + lane], dl[s / 4][s % 4], acc);
 #pragma unroll
-            for (int r = 0; r < 4; r++) cbuf[lr * ANNP_CPAD + 16 * mt + lq + 4 * r] = acc[r];
+            for (int r = 0; r < 4; r++) cbuf[lr * MLP_CROW + 16 * mt + lq + 4 * r] = acc[r];
         }
         wave_lds_sync();
         {
             const int nrow = min(16, p.inum - tile * 16);
             double *dst = p.coef + (size_t)tile * 16 * ANNP_CPAD;
-            for (int idx = lane; idx < nrow * ANNP_CPAD; idx += 64) dst[idx] = cbuf[idx];
+            for (int idx = lane; idx < nrow * ANNP_CPAD; idx += 64) dst[idx] = cbuf[idx + idx / ANNP_CPAD];
         }
         wave_lds_sync();
     }
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
 template <int KS0, int MT, int NL>
 inline size_t mlp_lds_bytes()
 {
-    return ((size_t)MlpSlots<KS0, MT, NL>::total * 64 + (size_t)ANNP_WAVES_PER_BLOCK * 16 * ANNP_CPAD) * sizeof(double);
+    return ((size_t)MlpSlots<KS0, MT, NL>::total * 64 + (size_t)ANNP_WAVES_PER_BLOCK * 16 * MLP_CROW) * sizeof(double);
 }
 
 }  // namespace annp
