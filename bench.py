@@ -73,13 +73,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if os.environ.get("ANNP_BENCH_SHARE_GPU") == "1":      # rehearsal only: several ranks on one card (if RCCL allows it)
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("ANNP_FORCE_DIST") == "1"      # the latter: rehearse RCCL with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("ANNP_BENCH_BACKEND") == "gloo":    # rehearsal only (one card, several ranks): halo staged through the host
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- workload -------------------------------------------------------------------
     rc_list = 8.5
@@ -87,7 +92,8 @@ def main():
     xg = perturb(x0, 12345, 0.05)
     natoms = xg.shape[0]
     plan = HaloPlan(x0, box, (1, 1, 1), rc_list, world, rank)
-    dom = Domain(plan, xg, dev, dist if world > 1 else _NoDist())
+    staged = os.environ.get("ANNP_BENCH_BACKEND") == "gloo"
+    dom = Domain(plan, xg, dev, (_HostStagedDist(dist) if staged else dist) if world > 1 else _NoDist())
     nlocal, nall = plan.nlocal, plan.nall
 
     lib = load_library()
@@ -304,6 +310,40 @@ class _NoDist:
     @staticmethod
     def batch_isend_irecv(ops):
         return []
+
+
+class _HostStagedDist:
+    """Rehearsal transport (ANNP_BENCH_BACKEND=gloo): the same P2POp / batch_isend_irecv surface Domain uses, with device
+    buffers bounced through host memory because gloo has no device point-to-point.  Never the measured configuration:
+    it exists so that the N > 1 control flow of this file can run where only one GPU is visible."""
+
+    class _Req:
+        def __init__(self, req, host, dev_t):
+            self.req, self.host, self.dev_t = req, host, dev_t
+
+        def wait(self):
+            self.req.wait()
+            if self.dev_t is not None:
+                self.dev_t.copy_(self.host)
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.isend, self.irecv = "isend", "irecv"
+
+    @staticmethod
+    def P2POp(op, tensor, peer):
+        return (op, tensor, peer)
+
+    def batch_isend_irecv(self, ops):
+        reqs = []
+        for op, tensor, peer in ops:
+            if op == "isend":
+                host = tensor.detach().cpu()
+                reqs.append(self._Req(self.dist.isend(host, peer), host, None))
+            else:
+                host = tensor.new_empty(tensor.shape, device="cpu")
+                reqs.append(self._Req(self.dist.irecv(host, peer), host, tensor))
+        return reqs
 
 
 def _sample_system(lib, h, x_all, nlocal, nall, m, rc_list):
