@@ -156,7 +156,8 @@ int annp_hip_sync(annp_hip_handle *handle);
 /* Kernel timing with HIP events recorded on the stream the kernels are launched on.
  * annp_hip_set_timing(h, 1) starts recording (and resets the sample count); every
  * evaluation then records four events.  ms4 = milliseconds of [0] descriptor pass,
- * [1] network pass, [2] force pass, [3] whole evaluation.
+ * [1] network pass, [2] force pass, [3] whole evaluation (ANNA_ADP: [1] is empty, [2] is the one
+ * kernel that holds network, ADP sums, energy and forces).
  *   annp_hip_last_timing   the most recent evaluation
  *   annp_hip_timing_stats  mean over the evaluations since enabling (the last 64 at most) */
 int annp_hip_set_timing(annp_hip_handle *handle, int enable);

@@ -73,6 +73,10 @@ struct annp_hip_handle {
     // neighbour list built on device
     NeighBuild nb;
     // host-list cache
+    // pinned, persistent staging for what host_finish brings back (a fresh pageable vector per call costs its
+    // page faults and a second copy inside the runtime: ~3 ms per 1 M atoms)
+    double *pin_f = nullptr, *pin_e = nullptr, *pin_v = nullptr;
+    size_t pin_f_cap = 0, pin_e_cap = 0, pin_v_cap = 0;
     std::vector<long long> h_first;
     std::vector<int> h_numneigh, h_neigh;
     int list_max = 0;                   // max numneigh of the uploaded list
@@ -356,6 +360,9 @@ void annp_hip_clear(annp_hip_handle *h)
     if (h->d_scalars) (void)hipFree(h->d_scalars);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->h_flags) (void)hipHostFree(h->h_flags);
+    if (h->pin_f) (void)hipHostFree(h->pin_f);
+    if (h->pin_e) (void)hipHostFree(h->pin_e);
+    if (h->pin_v) (void)hipHostFree(h->pin_v);
     if (h->h_scalars) (void)hipHostFree(h->h_scalars);
     for (hipEvent_t e : h->evring) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -717,29 +724,41 @@ int annp_hip_neigh_build_device(annp_hip_handle *h, int nlocal, int nall, const 
 }
 
 // ---- host-pointer entry points --------------------------------------------------------
+static int ensure_pinned(annp_hip_handle *h, double *&p, size_t &cap, size_t n)
+{
+    if (n <= cap) return 0;
+    if (p) { (void)hipHostFree(p); h->bytes -= cap * sizeof(double); p = nullptr; cap = 0; }
+    const size_t want = n + n / 8;
+    hipError_t e = hipHostMalloc((void **)&p, want * sizeof(double));
+    if (e != hipSuccess) { p = nullptr; return fail(h, ANNP_HIP_ENOMEM, "hipHostMalloc(%zu bytes) failed: %s", want * sizeof(double), hipGetErrorString(e)); }
+    cap = want;
+    h->bytes += cap * sizeof(double);
+    return 0;
+}
+
 static int host_finish(annp_hip_handle *h, int inum, int nall, int eflag, int vflag, int eatom_flag,
-                       double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom,
-                       std::vector<double> &hf, std::vector<double> &he)
+                       double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom)
 {
     hipStream_t s = h->stream;
-    hf.resize((size_t)nall * 3);
-    HIP_TRY(h, hipMemcpyAsync(hf.data(), h->f.p, sizeof(double) * nall * 3, hipMemcpyDeviceToHost, s));
-    if (eflag && eatom_flag && eatom) {
-        he.resize((size_t)nall);
-        HIP_TRY(h, hipMemcpyAsync(he.data(), h->eatom.p, sizeof(double) * nall, hipMemcpyDeviceToHost, s));
+    int rc;
+    if ((rc = ensure_pinned(h, h->pin_f, h->pin_f_cap, (size_t)nall * 3))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->pin_f, h->f.p, sizeof(double) * nall * 3, hipMemcpyDeviceToHost, s));
+    const bool want_e = eflag && eatom_flag && eatom;
+    if (want_e) {
+        if ((rc = ensure_pinned(h, h->pin_e, h->pin_e_cap, (size_t)nall))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->pin_e, h->eatom.p, sizeof(double) * nall, hipMemcpyDeviceToHost, s));
     }
-    std::vector<double> hv;
     if (vatom) {
-        hv.resize((size_t)nall * 6);
-        HIP_TRY(h, hipMemcpyAsync(hv.data(), h->vatom.p, sizeof(double) * nall * 6, hipMemcpyDeviceToHost, s));
+        if ((rc = ensure_pinned(h, h->pin_v, h->pin_v_cap, (size_t)nall * 6))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->pin_v, h->vatom.p, sizeof(double) * nall * 6, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(h, hipMemcpyAsync(h->h_scalars, h->d_scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     if (int rcf = check_pending_flags(h)) return rcf;
-    if (vatom) for (size_t k = 0; k < (size_t)nall * 6; k++) vatom[k] += hv[k];
-    for (size_t k = 0; k < (size_t)nall * 3; k++) f[k] += hf[k];                  // fe:199,211: += / -=
+    if (vatom) { const double *hv = h->pin_v; for (size_t k = 0; k < (size_t)nall * 6; k++) vatom[k] += hv[k]; }
+    { const double *hf = h->pin_f; for (size_t k = 0; k < (size_t)nall * 3; k++) f[k] += hf[k]; }     // fe:199,211: += / -=
     if (eflag && eng_vdwl) *eng_vdwl += h->h_scalars[0];                          // fe:185
-    if (eflag && eatom_flag && eatom) for (int k = 0; k < nall; k++) eatom[k] += he[k];   // fe:186
+    if (want_e) { const double *he = h->pin_e; for (int k = 0; k < nall; k++) eatom[k] += he[k]; }   // fe:186
     if (vflag && virial) for (int k = 0; k < 6; k++) virial[k] += h->h_scalars[1 + k];
     (void)inum;
     return 0;
@@ -804,8 +823,7 @@ int annp_hip_compute(annp_hip_handle *h, int ago, int inum, int nall, int nghost
                              h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr,
                              want_vatom ? h->vatom.p : nullptr, s);
     if (rc) return rc;
-    std::vector<double> hf, he;
-    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, want_vatom ? vatom : nullptr, hf, he);
+    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, want_vatom ? vatom : nullptr);
 }
 
 int annp_hip_compute_n(annp_hip_handle *h, int ago, int inum, int nall, int nghost,
@@ -844,8 +862,7 @@ int annp_hip_compute_n(annp_hip_handle *h, int ago, int inum, int nall, int ngho
                              h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr,
                              want_vatom ? h->vatom.p : nullptr, s);
     if (rc) return rc;
-    std::vector<double> hf, he;
-    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, want_vatom ? vatom : nullptr, hf, he);
+    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, want_vatom ? vatom : nullptr);
 }
 
 }  // extern "C"
