@@ -14,8 +14,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from annp_testlib import (A_FE, A_NI, FE_POT, KIND_FE, KIND_NI_COMPAT, KIND_NI_FIXED, LITERAL, NI_POT, System, bcc, fcc,  # noqa: E402
-                          oracle_compute, perturb, read_pot)
+from annp_testlib import (A_FE, A_NI, ANNA_POT, FE_POT, KIND_FE, KIND_NI_COMPAT, KIND_NI_FIXED, LITERAL, NI_POT, System, anna_compute,  # noqa: E402
+                          bcc, fcc, oracle_compute, perturb, read_anna, read_pot)
 
 CASES = {
     # name: (lattice, cells, a, seed, amplitude, potential, kind)
@@ -32,7 +32,25 @@ def build(case):
     return System(perturb(x, seed, amp), box), read_pot(potfile), kind
 
 
+# pair_style anna_adp: (cells, seed, amplitude, list cutoff)
+ANNA_CASES = {"anna_4x4x4": ((4, 4, 4), 2310, 0.06, 7.055), "anna_3x5x4_big_disp": ((3, 5, 4), 99, 0.2, 7.055)}
+
+
+def build_anna(case):
+    cells, seed, amp, rc_list = ANNA_CASES[case]
+    x, box = bcc(*cells, A_FE)
+    return System(perturb(x, seed, amp), box, rc_list=rc_list), read_anna(ANNA_POT)
+
+
 def main():
+    out = {}
+    for name in ANNA_CASES:
+        s, pot = build_anna(name)
+        r = anna_compute(pot, s, want_virial=True)
+        for key in ("eatom", "f", "f_all", "virial", "G", "lparams"):
+            out[name + "/" + key] = r[key]
+        print("%-22s nlocal %4d nall %5d  E %.9f  |F|max %.6f" % (name, s.nlocal, s.nall, r["energy"], np.abs(r["f"]).max()))
+    np.savez_compressed(os.path.join(HERE, "anna_golden.npz"), **out)
     out = {}
     for name in CASES:
         s, pot, kind = build(name)
