@@ -83,6 +83,10 @@ def _free_port():
     return port
 
 
+def _cells_x(world):
+    return {2: 8, 3: 10, 4: 12}[world]
+
+
 def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
@@ -91,7 +95,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from meng_zhang_amd.domain import Domain, HaloPlan
-        x0, box = bcc(8, 3, 3, A_FE)
+        x0, box = bcc(_cells_x(world), 3, 3, A_FE)
         xg = perturb(x0, 4242, 0.05)
         plan = HaloPlan(x0, box, (1, 1, 1), RC_LIST, world, rank)
         dom = Domain(plan, x0, torch.device("cpu"), dist)          # start from the ideal lattice ...
@@ -110,19 +114,22 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_gloo():
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_over_gloo(world):
+    """one process per rank, halo over the wire: with two ranks both slab faces meet the same peer, with three every
+    rank has two distinct peers (the general case of Domain.forward / reverse)"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    x0, box = bcc(8, 3, 3, A_FE)
+    x0, box = bcc(_cells_x(world), 3, 3, A_FE)
     xg = perturb(x0, 4242, 0.05)
     f_ref, e_ref = reference_forces(xg, box)
     f = np.zeros_like(xg)
