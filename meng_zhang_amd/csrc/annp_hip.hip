@@ -221,7 +221,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         if (lds1 > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "neighbour list too long for LDS (%d)", max_numneigh);
         hipLaunchKernelGGL((annp_fe_desc<FE_NP, FE_NT>), dim3(blocks), dim3(256), lds1, s, a);
         HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL(annp_max_int, dim3(std::min(1024, (inum + 255) / 256)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
+        hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
         HIP_TRY(h, hipGetLastError());
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
         // pass 2
@@ -291,7 +291,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             a.nbr = h->ni_nbr.p; a.nbr_stride = a.n_cap;
             ni_launch_desc(a, h->ni_shape, s);
             HIP_TRY(h, hipGetLastError());
-            hipLaunchKernelGGL(annp_max_int, dim3(std::min(1024, (inum + 255) / 256)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
+            hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
             HIP_TRY(h, hipGetLastError());
             HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));

@@ -39,20 +39,30 @@ inline void neigh_release(NeighBuild &nb)
     nb = NeighBuild();
 }
 
-__global__ void annp_max_int(const int *v, int n, int *out)
+// max over an int array: one atomic per block (per-wave atomics on the one result word serialise: 4096 of them cost 40 us)
+__global__ __launch_bounds__(256) void annp_max_int(const int *v, int n, int *out)
 {
+    __shared__ int part[4];
     int m = 0;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) m = max(m, v[k]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (m > 0) atomicMax(out, m);
+    }
 }
+inline int annp_max_int_blocks(int n) { return std::max(1, std::min(256, (n + 255) / 256)); }
 
-__global__ __launch_bounds__(1024) void annp_bbox(const double *x, int n, double *bbox)
+// bounding box in two steps: per-block boxes, then one block folds them
+constexpr int ANNP_BBOX_BLOCKS = 256;
+__global__ __launch_bounds__(256) void annp_bbox_partial(const double *x, int n, double *part)   // part[gridDim.x][6]
 {
-    __shared__ double slo[3][16], shi[3][16];
+    __shared__ double slo[3][4], shi[3][4];
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int k = threadIdx.x; k < n; k += blockDim.x)
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
         for (int d = 0; d < 3; d++) { const double v = x[3 * (size_t)k + d]; lo[d] = fmin(lo[d], v); hi[d] = fmax(hi[d], v); }
     for (int d = 0; d < 3; d++) {
         for (int off = 32; off > 0; off >>= 1) { lo[d] = fmin(lo[d], __shfl_xor(lo[d], off, 64)); hi[d] = fmax(hi[d], __shfl_xor(hi[d], off, 64)); }
@@ -61,9 +71,18 @@ __global__ __launch_bounds__(1024) void annp_bbox(const double *x, int n, double
     __syncthreads();
     if (threadIdx.x < 3) {
         const int d = threadIdx.x;
-        double l = 1e300, hh = -1e300;
-        for (int w = 0; w < (int)(blockDim.x >> 6); w++) { l = fmin(l, slo[d][w]); hh = fmax(hh, shi[d][w]); }
-        bbox[d] = l; bbox[3 + d] = hh;
+        part[6 * blockIdx.x + d] = fmin(fmin(slo[d][0], slo[d][1]), fmin(slo[d][2], slo[d][3]));
+        part[6 * blockIdx.x + 3 + d] = fmax(fmax(shi[d][0], shi[d][1]), fmax(shi[d][2], shi[d][3]));
+    }
+}
+__global__ __launch_bounds__(64) void annp_bbox_final(const double *part, int nparts, double *bbox)
+{
+    const int lane = threadIdx.x;
+    for (int d = 0; d < 3; d++) {
+        double lo = 1e300, hi = -1e300;
+        for (int k = lane; k < nparts; k += 64) { lo = fmin(lo, part[6 * k + d]); hi = fmax(hi, part[6 * k + 3 + d]); }
+        for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_xor(lo, off, 64)); hi = fmax(hi, __shfl_xor(hi, off, 64)); }
+        if (lane == 0) { bbox[d] = lo; bbox[3 + d] = hi; }
     }
 }
 
@@ -213,10 +232,15 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
 #define NB_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { msg = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? -3 : -4; } } while (0)
     nb.valid = false;
     if (nall <= 0 || nlocal <= 0) { nb.nlocal = nlocal; nb.nall = nall; nb.max_numneigh = 0; return 0; }
-    if (!nb.bbox) { NB_TRY(hipMalloc((void **)&nb.bbox, 6 * sizeof(double))); NB_TRY(hipMalloc((void **)&nb.dmax, 4 * sizeof(long long))); nb.bytes += 6 * sizeof(double) + 4 * sizeof(long long); }
+    if (!nb.bbox) {     // 6 doubles of result + the per-block boxes behind them
+        const size_t bb = (6 + 6 * (size_t)ANNP_BBOX_BLOCKS) * sizeof(double);
+        NB_TRY(hipMalloc((void **)&nb.bbox, bb)); NB_TRY(hipMalloc((void **)&nb.dmax, 4 * sizeof(long long))); nb.bytes += bb + 4 * sizeof(long long);
+    }
     if (nb_alloc(nb.binof, nb.cap_binof, (size_t)nall, nb.bytes, msg)) return -3;
     if (nb_alloc(nb.binitems, nb.cap_binitems, (size_t)nall, nb.bytes, msg)) return -3;
-    hipLaunchKernelGGL(annp_bbox, dim3(1), dim3(1024), 0, s, d_x, nall, nb.bbox);
+    const int bparts = std::max(1, std::min(ANNP_BBOX_BLOCKS, (nall + 255) / 256));
+    hipLaunchKernelGGL(annp_bbox_partial, dim3(bparts), dim3(256), 0, s, d_x, nall, nb.bbox + 6);
+    hipLaunchKernelGGL(annp_bbox_final, dim3(1), dim3(64), 0, s, nb.bbox + 6, bparts, nb.bbox);
     double hb[6];
     NB_TRY(hipMemcpyAsync(hb, nb.bbox, sizeof(hb), hipMemcpyDeviceToHost, s));
     NB_TRY(hipStreamSynchronize(s));
@@ -255,7 +279,7 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     hipLaunchKernelGGL(annp_scan_block_sums, dim3(nblk), dim3(1024), 0, s, nb.numneigh, nlocal, nb.blocksum);
     hipLaunchKernelGGL(annp_scan_block_offsets, dim3(1), dim3(64), 0, s, nb.blocksum, nblk, dtot);
     hipLaunchKernelGGL(annp_scan_finish, dim3(nblk), dim3(1024), 0, s, nb.numneigh, nlocal, nb.blocksum, nb.first);
-    hipLaunchKernelGGL(annp_max_int, dim3(std::min(1024, (nlocal + 255) / 256)), dim3(256), 0, s, nb.numneigh, nlocal, nb.dmax);
+    hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(nlocal)), dim3(256), 0, s, nb.numneigh, nlocal, nb.dmax);
     long long hres[2];
     NB_TRY(hipMemcpyAsync(hres, nb.dmax, sizeof(hres), hipMemcpyDeviceToHost, s));
     NB_TRY(hipStreamSynchronize(s));
