@@ -24,17 +24,18 @@ struct NeighBuild {
     // scratch
     int *binof = nullptr, *bincount = nullptr, *binstart = nullptr, *binfill = nullptr, *binitems = nullptr;
     long long *blocksum = nullptr;
+    double *xs = nullptr;           // positions in bin order: xs[k] = x[binitems[k]], read contiguously by the passes
     double *bbox = nullptr;         // device: lo[3], hi[3]
     int *dmax = nullptr;
     // element capacity of every array above (each grows on its own)
     size_t cap_numneigh = 0, cap_first = 0, cap_neigh = 0, cap_binof = 0, cap_binitems = 0;
-    size_t cap_bincount = 0, cap_binstart = 0, cap_binfill = 0, cap_blocksum = 0;
+    size_t cap_bincount = 0, cap_binstart = 0, cap_binfill = 0, cap_blocksum = 0, cap_xs = 0;
     size_t bytes = 0;
 };
 
 inline void neigh_release(NeighBuild &nb)
 {
-    void *ptrs[] = {nb.numneigh, nb.first, nb.neigh, nb.binof, nb.bincount, nb.binstart, nb.binfill, nb.binitems, nb.blocksum, nb.bbox, nb.dmax};
+    void *ptrs[] = {nb.numneigh, nb.first, nb.neigh, nb.binof, nb.bincount, nb.binstart, nb.binfill, nb.binitems, nb.blocksum, nb.bbox, nb.dmax, nb.xs};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     nb = NeighBuild();
 }
@@ -142,9 +143,19 @@ __global__ void annp_bin_sort(int nbins, const int *binstart, int *binitems)
     }
 }
 
+// positions in bin order, so that a run of bins is one contiguous stretch of coordinates: gathered through binitems
+// each candidate costs a 64-byte line for 24 useful bytes, and the two passes are bound by exactly that traffic
+__global__ void annp_bin_gather_x(const double *x, int n, const int *binitems, double *xs)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int j = binitems[k];
+    xs[3 * (size_t)k] = x[3 * (size_t)j]; xs[3 * (size_t)k + 1] = x[3 * (size_t)j + 1]; xs[3 * (size_t)k + 2] = x[3 * (size_t)j + 2];
+}
+
 // one wave per owned atom; FILL=false counts, FILL=true writes
 template <bool FILL>
-__global__ __launch_bounds__(256) void annp_neigh_pass(const double *x, int nlocal, BinGeom g, double rc2,
+__global__ __launch_bounds__(256) void annp_neigh_pass(const double *x, const double *xs, int nlocal, BinGeom g, double rc2,
                                                        const int *binof, const int *binstart, const int *binitems,
                                                        int *numneigh, const long long *first, int *neigh)
 {
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256) void annp_neigh_pass(const double *x, int nloc
                 int j = 0;
                 if (k < e) {
                     j = binitems[k];
-                    const double dx = xi - x[3 * (size_t)j], dy = yi - x[3 * (size_t)j + 1], dz = zi - x[3 * (size_t)j + 2];
+                    const double dx = xi - xs[3 * (size_t)k], dy = yi - xs[3 * (size_t)k + 1], dz = zi - xs[3 * (size_t)k + 2];
                     in = (j != i) && (dx * dx + dy * dy + dz * dz <= rc2);
                 }
                 const unsigned long long m = __ballot(in);
@@ -264,6 +275,8 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     hipLaunchKernelGGL(annp_scan_bins, dim3(1), dim3(1024), 0, s, nb.bincount, (int)nbins, nb.binstart);
     hipLaunchKernelGGL(annp_bin_fill, dim3(gb), dim3(tb), 0, s, nall, nb.binof, nb.binstart, nb.binfill, nb.binitems);
     hipLaunchKernelGGL(annp_bin_sort, dim3((int)((nbins + tb - 1) / tb)), dim3(tb), 0, s, (int)nbins, nb.binstart, nb.binitems);
+    if (nb_alloc(nb.xs, nb.cap_xs, (size_t)nall * 3, nb.bytes, msg)) return -3;
+    hipLaunchKernelGGL(annp_bin_gather_x, dim3(gb), dim3(tb), 0, s, d_x, nall, nb.binitems, nb.xs);
     // count
     if (nb_alloc(nb.numneigh, nb.cap_numneigh, (size_t)nall, nb.bytes, msg)) return -3;
     if (nb_alloc(nb.first, nb.cap_first, (size_t)nall + 1, nb.bytes, msg)) return -3;
@@ -271,7 +284,7 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     NB_TRY(hipMemsetAsync(nb.numneigh, 0, sizeof(int) * (size_t)nall, s));
     const int wb = (nlocal + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK;
     const double rc2 = cutneigh * cutneigh;
-    hipLaunchKernelGGL((annp_neigh_pass<false>), dim3(wb), dim3(256), 0, s, d_x, nlocal, g, rc2, nb.binof, nb.binstart, nb.binitems,
+    hipLaunchKernelGGL((annp_neigh_pass<false>), dim3(wb), dim3(256), 0, s, d_x, nb.xs, nlocal, g, rc2, nb.binof, nb.binstart, nb.binitems,
                        nb.numneigh, (const long long *)nullptr, (int *)nullptr);
     const int nblk = (nlocal + 1023) / 1024;
     long long *dtot = reinterpret_cast<long long *>(nb.dmax) + 1;
@@ -286,7 +299,7 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     nb.max_numneigh = (int)(hres[0] & 0xffffffffll);
     const long long total = hres[1];
     if (nb_alloc(nb.neigh, nb.cap_neigh, (size_t)std::max<long long>(total, 1), nb.bytes, msg)) return -3;
-    hipLaunchKernelGGL((annp_neigh_pass<true>), dim3(wb), dim3(256), 0, s, d_x, nlocal, g, rc2, nb.binof, nb.binstart, nb.binitems,
+    hipLaunchKernelGGL((annp_neigh_pass<true>), dim3(wb), dim3(256), 0, s, d_x, nb.xs, nlocal, g, rc2, nb.binof, nb.binstart, nb.binitems,
                        nb.numneigh, (const long long *)nb.first, nb.neigh);
     NB_TRY(hipGetLastError());
     nb.nlocal = nlocal; nb.nall = nall; nb.valid = true;
