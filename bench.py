@@ -4,6 +4,9 @@
     python bench.py --gpus N --steps K --warmup W          (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+--workload ni / anna run the same harness on BASELINE.json's config 4 (fcc Ni, 512 000 atoms) and on
+pair_style anna_adp; the default is the metric's own workload:
+
 Workload (BASELINE.json): bcc-Fe ANNP, 80x80x80 cells x 2 = 1 024 000 atoms, fully
 periodic, a = 2.8553 A, every coordinate displaced by U(-0.05, 0.05) A from a
 counter-based generator, neighbour list cutoff 6.5 + 2.0 A.  With N ranks the box is
@@ -45,6 +48,8 @@ SURVEY_FLOP_PAIR, SURVEY_FLOP_NBR, SURVEY_FLOP_MLP = 350.0, 175.0, 1600.0
 BYTES_ATOM_STEP = 9960.0                          # gathered bytes per atom-step
 PEAK_FP64_VECTOR = 78.6                           # TFLOP/s, MI355X (MI355X_MICROARCH.md: half of FP32 vector 157.3)
 PEAK_HBM = 8000.0                                 # GB/s spec
+# SURVEY.md 8d, Ni: per (j,k) pair 24 functions x 40 + 150, network 5 k
+NI_FLOP_PAIR, NI_FLOP_MLP = 24 * 40.0 + 150.0, 5000.0
 
 
 def main():
@@ -55,13 +60,17 @@ def main():
     ap.add_argument("--cells", type=int, default=80, help="bcc cells per edge (80 -> 1 024 000 atoms)")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="atoms in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dt", type=float, default=0.001, help="ps")
+    ap.add_argument("--workload", choices=["fe", "ni", "anna"], default="fe",
+                    help="fe = the BASELINE.json metric (default); ni = config 4 (fcc Ni, 40x40x80 cells = 512 000 atoms, "
+                         "cells taken as cells/2 x cells/2 x cells); anna = pair_style anna_adp on the bcc-Fe box")
     ap.add_argument("--rebuild-every", type=int, default=10,
                     help="secondary figure: the same steps with the neighbour list rebuilt on the device every N steps (0 = skip)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from annp_testlib import A_FE, FAST, FE_POT, KIND_FE, System, bcc, oracle_compute, oracle_lib, perturb, read_pot
+    from annp_testlib import (A_FE, A_NI, ANNA_POT, FAST, FE_POT, KIND_FE, KIND_NI_FIXED, NI_POT, System, anna_compute, bcc, fcc,
+                              oracle_compute, oracle_lib, perturb, read_anna, read_pot)
     from meng_zhang_amd import PairANNP
     from meng_zhang_amd.domain import Domain, HaloPlan
     from meng_zhang_amd.lib import load_library
@@ -87,8 +96,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- workload -------------------------------------------------------------------
-    rc_list = 8.5
-    x0, box = bcc(args.cells, args.cells, args.cells, A_FE)
+    wl = args.workload
+    rc_list = 7.055 if wl == "anna" else 8.5
+    if wl == "ni":
+        x0, box = fcc(args.cells // 2, args.cells // 2, args.cells, A_NI)
+    else:
+        x0, box = bcc(args.cells, args.cells, args.cells, A_FE)
     xg = perturb(x0, 12345, 0.05)
     natoms = xg.shape[0]
     plan = HaloPlan(x0, box, (1, 1, 1), rc_list, world, rank)
@@ -97,9 +110,11 @@ def main():
     nlocal, nall = plan.nlocal, plan.nall
 
     lib = load_library()
-    pair = PairANNP(ntypes=1, device=local_rank)
+    potfile, element, style, mass = {"fe": (FE_POT, "Fe", "annp", 55.847), "ni": (NI_POT, "Ni", "annp", 58.6934),
+                                     "anna": (ANNA_POT, "Fe", "anna_adp", 55.847)}[wl]
+    pair = PairANNP(ntypes=1, device=local_rank, style=style)
     pair.settings([])
-    pair.coeff(["*", "*", FE_POT, "Fe"])
+    pair.coeff(["*", "*", potfile, element])
     pair.init_style()
     h = pair.handle
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -114,7 +129,6 @@ def main():
                                           C.byref(p_neigh), C.byref(mx), stream), "neigh_build")
     eng = torch.zeros(1, dtype=torch.float64, device=dev)
     vel = torch.zeros((nlocal, 3), dtype=torch.float64, device=dev)
-    mass = 55.847
     ftm2v = 1.0 / 1.0364269e-4          # LAMMPS metal units: (eV/A)/(g/mol) -> A/ps^2
     dtf = 0.5 * args.dt * ftm2v / mass
 
@@ -191,6 +205,8 @@ def main():
     flop_desc = pairs * FLOP_PAIR_DESC + nbrs * FLOP_NBR_DESC
     flop_eval = flop_force + flop_desc + nlocal * FLOP_MLP
     flop_survey = pairs * SURVEY_FLOP_PAIR + nbrs * SURVEY_FLOP_NBR + nlocal * SURVEY_FLOP_MLP
+    if wl == "ni":          # only SURVEY's estimate exists for the G2/G4 passes: both figures are that one
+        flop_eval = flop_survey = pairs * NI_FLOP_PAIR + nlocal * NI_FLOP_MLP
     force_ms, desc_ms, mlp_ms = float(ms4[2]), float(ms4[0]), float(ms4[1])
 
     if rank != 0:
@@ -199,8 +215,9 @@ def main():
 
     value = natoms * args.steps / dt_wall
     achieved = flop_force / (force_ms * 1e-3) / 1e12
+    label = {"fe": "bcc-Fe ANNP", "ni": "fcc-Ni ANNP (BASELINE.json config 4)", "anna": "bcc-Fe ANNA-ADP (pair_style anna_adp, SURVEY 8f.4)"}[wl]
     out = {
-        "metric": "atom-steps/sec (whole node), bcc-Fe ANNP, 1/2/4/8 MI355X",
+        "metric": "atom-steps/sec (whole node), %s, 1/2/4/8 MI355X" % label,
         "value": value,
         "unit": "atom-steps/s",
         "n_gpus": world,
@@ -213,8 +230,10 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "%d-atom bcc-Fe ANNP (%d^3 cells x2, a=2.8553, +-0.05 A displacements), "
-                        "fe_annp_potential_2.ann, list cutoff 8.5 A, x-slab decomposition" % (natoms, args.cells),
+            "workload": ("%d-atom bcc-Fe ANNP (%d^3 cells x2, a=2.8553, +-0.05 A displacements), "
+                         "fe_annp_potential_2.ann, list cutoff 8.5 A, x-slab decomposition" % (natoms, args.cells)) if wl == "fe" else
+                        "%d-atom %s, %s, +-0.05 A displacements, list cutoff %.3f A, x-slab decomposition" % (
+                            natoms, label, os.path.basename(potfile), rc_list),
             "atoms": natoms, "atoms_rank0": nlocal, "ghosts_rank0": plan.nghost,
             "neighbors_in_cutoff_mean": float(n.mean()), "list_neighbors_max": int(mx.value),
             "parallelism": "spatial x%d, halo p2p" % world,
@@ -223,7 +242,7 @@ def main():
         "energy_per_atom_eV": e_total / natoms,
         "mini_md": None if md_rate is None else {
             "value": md_rate, "unit": "atom-steps/s",
-            "note": "same %d steps with the full neighbour list (cutoff 8.5 A) rebuilt on the device every %d steps" % (args.steps, args.rebuild_every)},
+            "note": "same %d steps with the full neighbour list (cutoff %.3f A) rebuilt on the device every %d steps" % (args.steps, rc_list, args.rebuild_every)},
         "kernel_ms": {"descriptor": desc_ms, "network": mlp_ms, "force": force_ms, "evaluation": float(ms4[3]), "samples": int(ns.value)},
         "roofline": {
             "kernel": "annp_fe_force<9,19>",
@@ -247,16 +266,41 @@ def main():
                     "note": "9.96 KB gathered per atom-step over the whole evaluation; the path is FP64-VALU bound, not HBM bound"},
         },
     }
+    if wl == "ni":
+        ev = flop_eval / (float(ms4[3]) * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": "annp_ni_desc + annp_mlp_mfma + annp_ni_force (whole evaluation)", "bound": "fp64_valu",
+            "achieved": ev, "peak": PEAK_FP64_VECTOR, "unit": "TFLOP/s", "frac": ev / PEAK_FP64_VECTOR, "traffic": None,
+            "algorithmic_flop_per_launch": flop_eval,
+            "flop_per_unit": {"pair": NI_FLOP_PAIR, "atom": NI_FLOP_MLP},
+            "note": "SURVEY.md 8d's estimate for the G2/G4 formulation (24 functions x 40 + 150 per in-range pair); with ~18 "
+                    "neighbours per atom the passes are issue- and LDS-bound, not HBM-bound (DESIGN.md 4.4)"}
+    elif wl == "anna":
+        dd = flop_desc / (desc_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": "annp_fe_desc<9,19> (descriptor pass of pair_style anna_adp)", "bound": "fp64_valu",
+            "achieved": dd, "peak": PEAK_FP64_VECTOR, "unit": "TFLOP/s", "frac": dd / PEAK_FP64_VECTOR, "traffic": None,
+            "algorithmic_flop_per_launch": flop_desc, "flop_per_unit": {"pair": FLOP_PAIR_DESC, "neighbour": FLOP_NBR_DESC},
+            "note": "the second kernel (network + ADP sums + forces, no pair loop) is bound by its scattered force atomics "
+                    "and memory latency, not by arithmetic (DESIGN.md 4.4b)"}
     # ---- CPU baseline (rank 0, N = 1 only) ------------------------------------------------
     if world == 1 and args.cpu_sample > 0:
         m = min(args.cpu_sample, nlocal)
         xs = dom.x.cpu().numpy()
         s = _sample_system(lib, h, xs, nlocal, nall, m, rc_list)
-        pot = read_pot(FE_POT)
         nthreads = min(oracle_lib().annp_oracle_max_threads(), _cpu_share())
-        oracle_compute(pot, s, KIND_FE, FAST, inum=min(m, 256), nthreads=nthreads)           # warm
-        t1 = time.perf_counter()
-        oracle_compute(pot, s, KIND_FE, FAST, inum=m, nthreads=nthreads)
+        if wl == "anna":
+            C.CDLL("libgomp.so.1").omp_set_num_threads(int(nthreads))       # this oracle takes OpenMP's default
+            pot = read_anna(ANNA_POT)
+            anna_compute(pot, s, inum=min(m, 256))                                               # warm
+            t1 = time.perf_counter()
+            anna_compute(pot, s, inum=m)
+        else:
+            pot = read_pot(potfile)
+            kind = KIND_FE if wl == "fe" else KIND_NI_FIXED
+            oracle_compute(pot, s, kind, FAST, inum=min(m, 256), nthreads=nthreads)              # warm
+            t1 = time.perf_counter()
+            oracle_compute(pot, s, kind, FAST, inum=m, nthreads=nthreads)
         tc = time.perf_counter() - t1
         out["cpu_baseline"] = {
             "value": m / tc, "unit": "atom-steps/s", "cores": int(nthreads), "kind": "port",
