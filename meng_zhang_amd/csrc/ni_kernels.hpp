@@ -31,6 +31,8 @@ constexpr int NI_MAXP = 8;        // radial functions supported
 constexpr int NI_MAXT = 32;       // angular functions supported
 constexpr int NI_RED = 9;         // sums per LDS reduction round (desc)
 constexpr int NI_REDROW = 17;     // padded row of 16 lane partials
+constexpr int NI_CH = 16;         // trips per chunk of the pair pre-pass: 256 pair slots per atom
+constexpr int NI_PLIST = NI_CH * NI_GL;   // in-range pair list per atom (ushort: a | b << 8)
 #ifndef NI_WAVES_PER_SIMD
 #define NI_WAVES_PER_SIMD 4     // descriptor pass: 512 / 4 = 128 VGPRs
 #endif
@@ -66,7 +68,7 @@ __host__ __device__ inline int ni_coef_stride(int nsf) { return nsf | 1; }
 __host__ __device__ inline size_t ni_lds_per_wave(int cap, bool force, int nsf)
 {
     const size_t R = (size_t)NI_GA * cap + 2;          // + two dummy records for idle lanes
-    size_t b = R * 7 * 8 + (force ? R * 3 * 8 + (size_t)NI_GA * ni_coef_stride(nsf) * 8 : 0) + R * 4 + NI_GA * 4;
+    size_t b = R * 7 * 8 + (force ? R * 3 * 8 + (size_t)NI_GA * ni_coef_stride(nsf) * 8 : 0) + R * 4 + NI_GA * 4 + (size_t)NI_GA * NI_PLIST * 2;
     const size_t scratch = (size_t)NI_GA * NI_RED * NI_REDROW * 8;
     if (!force && b < scratch) b = scratch;
     return (b + 15) / 16 * 16;
@@ -339,6 +341,7 @@ struct NiLds {
     double *coef;                                 // [NI_GA][stride] weights: radial, then angular in visit order
     int *j;                                       // [NI_GA * cap]
     int *ci;                                      // [NI_GA] atom index of each group, -1 = none
+    unsigned short *pl;                           // [NI_GA][NI_PLIST] in-range pairs of the current chunk
 };
 
 template <bool FORCE>
@@ -353,6 +356,7 @@ __device__ __forceinline__ NiLds ni_carve(unsigned char *wbase, int cap, int cst
     if (FORCE) { L.a0 = d; L.a1 = L.a0 + R; L.a2 = L.a1 + R; L.coef = L.a2 + R; d = L.coef + NI_GA * cstride; }
     L.j = reinterpret_cast<int *>(d);
     L.ci = L.j + R;
+    L.pl = reinterpret_cast<unsigned short *>(L.ci + NI_GA);
     return L;
 }
 
@@ -558,6 +562,35 @@ __device__ __forceinline__ NiPairS ni_pair(const NiLds &L, const NiConst &c, int
 // compiler-level only: values read from LDS before this point are not kept in registers across it
 __device__ __forceinline__ void ni_forget_lds() { asm volatile("" ::: "memory"); }
 
+// Pair pre-pass.  Only pairs with r_ij, r_ik AND r_jk inside the cutoff contribute (ni:729) -- 60 of the 153 pairs of
+// an fcc-Ni atom -- but which ones is scattered over the enumeration, so every trip of the full visit would carry
+// ~60 % idle lanes.  A cheap sweep over a chunk of trips (distances only) writes the in-range pairs of each atom as
+// a dense list; the expensive part (cutoff function of r_jk, exponential, 24 functions) then runs over ceil(60/16)
+// = 4 trips instead of 10.  The test is computed exactly as ni_pair computes it, so the list and the visit agree.
+// Returns this lane's atom's count for the chunk (same value in the 16 lanes of a group).
+__device__ __forceinline__ int ni_prepass(const NiLds &L, const NiConst &c, NiWalk &walk, int g, int l, int sbase, int cap,
+                                          int npl, int t0, int t1)
+{
+    const double cfl = c.K[NI_KM + 2], rc = c.K[NI_KM + 1];
+    int cnt = 0;
+    for (int t = t0; t < t1; t++) {
+        const int pp = t * NI_GL + l;
+        int a, b;
+        ni_walk_next(walk, a, b);
+        const bool live = pp < npl;
+        const int sa = live ? sbase + a : NI_GA * cap, sb = live ? sbase + b : NI_GA * cap + 1;
+        const double g0 = L.dx[sb] - L.dx[sa], g1 = L.dy[sb] - L.dy[sa], g2 = L.dz[sb] - L.dz[sa];
+        const double gsq = g0 * g0 + g1 * g1 + g2 * g2;
+        const double rgm = (gsq * fast_rsqrt_ic(gsq)) * cfl;
+        const bool ok = live && (L.r[sa] * cfl < rc) && (L.r[sb] * cfl < rc) && (rgm < rc);
+        const unsigned long long m = __ballot(ok);
+        const unsigned m16 = (unsigned)(m >> (NI_GL * g)) & 0xffffu;
+        if (ok) L.pl[g * NI_PLIST + cnt + __popc(m16 & ((1u << l) - 1u))] = (unsigned short)(a | (b << 8));
+        cnt += __popc(m16);
+    }
+    return cnt;
+}
+
 // ---------------------------------------------------------------------------------
 template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM>
 __global__ __launch_bounds__(256, NI_WAVES_PER_SIMD) void annp_ni_desc(NiArgs p)
@@ -613,19 +646,25 @@ __global__ __launch_bounds__(256, NI_WAVES_PER_SIMD) void annp_ni_desc(NiArgs p)
     const int npl = nl * (nl - 1) / 2;
     const int trips = (nmax * (nmax - 1) / 2 + NI_GL - 1) / NI_GL;
     NiWalk walk = ni_walk_init(l, nl);
-    for (int t = 0; t < trips; t++) {
-        const int pp = t * NI_GL + l;
-        int a, b;
-        ni_walk_next(walk, a, b);
-        const bool live = pp < npl;
-        const NiPairS q = ni_pair(L, kc, live ? sbase + a : NI_GA * cap, live ? sbase + b : NI_GA * cap + 1);
-        const double r2sum = q.rjm * q.rjm + q.rkm * q.rkm + q.rgm * q.rgm;
-        const double tfc = q.tfc;                                   // dead lanes and rejected pairs add zeros
-        ni_forget_lds();                                            // (keeps the table reads inside the loop)
-        if constexpr (NL > 0) ni_desc_cart<NL, NE, NZ, ZP, EM, NT>(kc, q.ct, r2sum, tfc, ga);
-        else
-            ni_visit_functions<NT, false>(tab, p.ntsf, q.ct, r2sum,
-                                          [&](int pos, double val, double) { ga[pos] = fma(val, tfc, ga[pos]); });
+    for (int t0 = 0; t0 < trips; t0 += NI_CH) {
+        const int cnt = ni_prepass(L, kc, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + NI_CH));
+        wave_lds_sync();
+        const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
+                             max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
+        for (int t2 = 0; t2 * NI_GL < cmax; t2++) {
+            const int idx = t2 * NI_GL + l;
+            const bool live = idx < cnt;
+            const int v = live ? L.pl[g * NI_PLIST + idx] : 0;
+            const NiPairS q = ni_pair(L, kc, live ? sbase + (v & 255) : NI_GA * cap, live ? sbase + (v >> 8) : NI_GA * cap + 1);
+            const double r2sum = q.rjm * q.rjm + q.rkm * q.rkm + q.rgm * q.rgm;
+            const double tfc = q.tfc;                                   // idle lanes add zeros
+            ni_forget_lds();                                            // (keeps the table reads inside the loop)
+            if constexpr (NL > 0) ni_desc_cart<NL, NE, NZ, ZP, EM, NT>(kc, q.ct, r2sum, tfc, ga);
+            else
+                ni_visit_functions<NT, false>(tab, p.ntsf, q.ct, r2sum,
+                                              [&](int pos, double val, double) { ga[pos] = fma(val, tfc, ga[pos]); });
+        }
+        wave_lds_sync();        // the list is rewritten by the next chunk
     }
     wave_lds_sync();
     // sum the 16 lane partials of every atom through LDS, NI_RED sums per round (records are dead now)
@@ -696,12 +735,16 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     const int npl = nl * (nl - 1) / 2;
     const int trips = (nmax * (nmax - 1) / 2 + NI_GL - 1) / NI_GL;
     NiWalk walk = ni_walk_init(l, nl);
-    for (int t = 0; t < trips; t++) {
-        const int pp = t * NI_GL + l;
-        int a, b;
-        ni_walk_next(walk, a, b);
-        const bool lv = pp < npl;
-        const int sa = lv ? sbase + a : NI_GA * cap, sb = lv ? sbase + b : NI_GA * cap + 1;
+    for (int t0 = 0; t0 < trips; t0 += NI_CH) {
+    const int cnt = ni_prepass(L, kc, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + NI_CH));
+    wave_lds_sync();
+    const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
+                         max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
+    for (int t2 = 0; t2 * NI_GL < cmax; t2++) {
+        const int idx = t2 * NI_GL + l;
+        const bool lv = idx < cnt;
+        const int pv = lv ? L.pl[g * NI_PLIST + idx] : 0;
+        const int sa = lv ? sbase + (pv & 255) : NI_GA * cap, sb = lv ? sbase + (pv >> 8) : NI_GA * cap + 1;
         const NiPairS q = ni_pair(L, kc, sa, sb);
         const double r2sum = q.rjm * q.rjm + q.rkm * q.rkm + q.rgm * q.rgm;
         // everything below only matters for pairs inside the cutoffs; keeping the visit inside the branch also keeps
@@ -742,7 +785,8 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
             atomicAdd(&L.a0[sb], fk[0]); atomicAdd(&L.a1[sb], fk[1]); atomicAdd(&L.a2[sb], fk[2]);
         }
     }
-    wave_lds_sync();
+    wave_lds_sync();            // the list is rewritten by the next chunk
+    }
     double fi0 = 0.0, fi1 = 0.0, fi2 = 0.0;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
     for (int a = l; a < nmax; a += NI_GL) {
