@@ -97,3 +97,22 @@ def test_anna_too_many_neighbours_is_reported(pot):
             run(p, s)
     finally:
         p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,density", [(21, 0.01), (22, 0.04), (23, 0.08), (24, 0.11)])
+def test_anna_random_clusters(pot, seed, density):
+    """disordered, non-periodic point sets: in-range counts from 0 to ~60, short distances (steep repulsive branch)"""
+    from test_gpu_parity import _random_cluster
+    x = _random_cluster(seed, density, 20.0, 1.9)
+    s = System(x, np.array([0, 0, 0, 20.0, 20.0, 20.0]), periodic=(0, 0, 0), rc_list=7.0)
+    o = anna_compute(pot, s, want_virial=True)
+    p = make_anna()
+    try:
+        r = run(p, s, vflag=1)
+    finally:
+        p.close()
+    scale = max(1.0, np.abs(o["f"]).max())
+    assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6 * max(1.0, np.abs(o["eatom"] + 4473.0).max())
+    assert np.abs(r["f"] - o["f"]).max() < 1e-8 * scale
+    assert np.allclose(r["virial"], o["virial"], rtol=1e-8, atol=1e-6 * scale)

@@ -217,6 +217,36 @@ def test_fe_random_clusters(fe_pair, fe_pot, seed, density):
     assert np.allclose(r["virial"], o["virial"], rtol=1e-9, atol=1e-6 * scale)
 
 
+def _random_cluster(seed, density, side, dmin):
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0.0, side, size=(int(density * side ** 3), 3))
+    while True:
+        pairs = cKDTree(x).query_pairs(dmin, output_type="ndarray")
+        if pairs.shape[0] == 0:
+            return x
+        x = np.delete(x, np.unique(pairs[:, 1]), axis=0)
+
+
+@pytest.mark.parametrize("compat", [False, True])
+@pytest.mark.parametrize("seed,density", [(11, 0.01), (12, 0.04), (13, 0.09), (14, 0.14)])
+def test_ni_random_clusters(ni_pot, seed, density, compat):
+    """Disordered point sets for the Behler kernels: in-range counts from 0 to ~35 in the same wave, atom counts of
+    any residue mod 4, pair lists from empty to several trips."""
+    x = _random_cluster(seed, density, 22.0, 1.7)
+    s = System(x, np.array([0, 0, 0, 22.0, 22.0, 22.0]), periodic=(0, 0, 0), rc_list=6.5)
+    o = oracle_compute(ni_pot, s, KIND_NI_COMPAT if compat else KIND_NI_FIXED, FAST, want_virial=True)
+    p = make_pair(NI_POT, "Ni", ni_compat=compat)
+    try:
+        r = run(p, s, vflag=1)
+    finally:
+        p.close()
+    scale = max(1.0, np.abs(o["f"]).max())
+    assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6 * max(1.0, np.abs(o["eatom"]).max())
+    assert np.abs(r["f"] - o["f"]).max() < 1e-8 * scale
+    assert np.allclose(r["virial"], o["virial"], rtol=1e-8, atol=1e-6 * scale)
+
+
 def test_special_bits_in_neighbour_indices_are_masked(fe_pair, fe_pot):
     """LAMMPS stores special-bond flags in the top bits of a neighbour index; the pair style masks
     them with NEIGHMASK (fe_v2/src/pair_annp.cpp:136)."""
