@@ -384,8 +384,8 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     wave_lds_sync();
     const int H = n >> 1;
     const int L = (H + FE_Q - 1) / FE_Q;
-    // accumulators start at zero, except C which starts at -R r so that the radial term rides along:
-    //   Fn_a = (-V_a + C_a e_a)/r_a - S_a fc'_a e_a   with   C_a = sum_b alpha cos - R_a r_a
+    // accumulators start at zero; slot 4 holds -R r (radial term), the pair loop only adds to slots 0..3:
+    //   Fn_a = (-V_a + C_a e_a)/r_a - S_a fc'_a e_a   with   C_a = e_a . V_a - R_a r_a
     for (int k = lane; k < 5 * (n + L); k += 64) acc[k] = 0.0;
     if (lane < FE_DUMP) {
         recA[NZ + lane] = make_double2(0.0, 0.0);
@@ -461,7 +461,8 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
         const int smax = act ? (t1 - t0) : -1;
         const int ar = act ? it.a : dump;             // idle lanes: null record (fc_a = 0 -> they scatter zeros)
         const double2 A0 = recA[ar], A1 = recB[ar];
-        double va0 = 0.0, va1 = 0.0, va2 = 0.0, sa = 0.0, ca = 0.0;
+        const double fa0 = A1.y * A0.x, fa1 = A1.y * A0.y, fa2 = A1.y * A1.x;      // fc_a e_a, constant over the run
+        double va0 = 0.0, va1 = 0.0, va2 = 0.0, sa = 0.0;
         int b = it.a + t0;
         if (b >= n) b -= n;
         if (!act) b = dump;
@@ -482,20 +483,20 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
                 P = fma(P, c, ce[mm]);
                 if (mm < NT - 2) Pd = fma(Pd, c, cd[mm]);
             }
-            const double w = A1.y * B1.y;          // fc_a fc_b
-            const double al = Pd * w;
-            const double alc = al * c;
-            va0 = fma(al, B0.x, va0); va1 = fma(al, B0.y, va1); va2 = fma(al, B1.x, va2);
+            // alpha = dP/dz fc_a fc_b.  Every contribution to a target's V lacks exactly that target's own fc
+            // (a-side: fc_a, b-side: fc_b), so the accumulators hold V' = sum dP/dz fc_partner e_partner and
+            // finish() multiplies by the target's fc once.  C = sum alpha cos(theta) is not accumulated at all:
+            // cos = e_a . e_b, so C_a = e_a . V_a.
+            const double be = Pd * B1.y;           // dP/dz fc_b
+            va0 = fma(be, B0.x, va0); va1 = fma(be, B0.y, va1); va2 = fma(be, B1.x, va2);
             sa = fma(P, B1.y, sa);
-            ca += alc;
 #if ANNP_VARIANT != 3
-            atomicAdd(q + 0, al * A0.x);
-            atomicAdd(q + 1, al * A0.y);
-            atomicAdd(q + 2, al * A1.x);
+            atomicAdd(q + 0, Pd * fa0);            // dP/dz fc_a e_a
+            atomicAdd(q + 1, Pd * fa1);
+            atomicAdd(q + 2, Pd * fa2);
             atomicAdd(q + 3, P * A1.y);
-            atomicAdd(q + 4, alc);
 #else
-            asm volatile("" ::"v"(al * A0.x), "v"(al * A0.y), "v"(al * A1.x), "v"(P * A1.y), "v"(q));
+            asm volatile("" ::"v"(Pd * fa0), "v"(Pd * fa1), "v"(Pd * fa2), "v"(P * A1.y), "v"(q));
 #endif
         };
 
@@ -534,7 +535,6 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
             atomicAdd(q + 1, va1);
             atomicAdd(q + 2, va2);
             atomicAdd(q + 3, sa);
-            atomicAdd(q + 4, ca);
         }
         it.next(n);
     }
@@ -549,10 +549,13 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     auto finish = [&](int a, double rinv, double dfc) {
         const double2 E0 = recA[a], E1 = recB[a];
         const double *q = acc + 5 * a;
-        const double t = fma(q[4], rinv, -q[3] * dfc);
-        const double g0 = fma(t, E0.x, -q[0] * rinv);
-        const double g1 = fma(t, E0.y, -q[1] * rinv);
-        const double g2 = fma(t, E1.x, -q[2] * rinv);
+        // V_a = fc_a V'_a;  C_a = sum_b alpha_ab cos(theta_ab) = e_a . V_a, plus the radial -R r parked in slot 4
+        const double V0 = E1.y * q[0], V1 = E1.y * q[1], V2 = E1.y * q[2];
+        const double cq = fma(E0.x, V0, fma(E0.y, V1, fma(E1.x, V2, q[4])));
+        const double t = fma(cq, rinv, -q[3] * dfc);
+        const double g0 = fma(t, E0.x, -V0 * rinv);
+        const double g1 = fma(t, E0.y, -V1 * rinv);
+        const double g2 = fma(t, E1.x, -V2 * rinv);
         const int j = auxJ[a];
 #if ANNP_VARIANT != 4
         atomicAdd(&p.f[3 * (size_t)j], -g0);
