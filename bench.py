@@ -40,7 +40,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # Per-unit algorithmic work (fp64, FMA = 2 flop), derived line by line in DESIGN.md 4.5.
 # (a) what the implemented formulation needs -- the roofline numerator:
 FLOP_PAIR_DESC, FLOP_NBR_DESC = 76.0, 110.0       # pass 1: cos 5, weights 3, T_2..T_18 recurrence + accumulate 68
-FLOP_PAIR_FORCE, FLOP_NBR_FORCE = 92.0, 150.0     # pass 3: cos 5, Horner P 36 + dP 34, weights 3, a-side 9, b-side 5
+FLOP_PAIR_FORCE, FLOP_NBR_FORCE = 88.0, 158.0     # pass 3: cos 5, Horner P 36 + dP 34, dP fc_b 1, a-side 8, b-side 4
 FLOP_MLP = 2500.0
 # (b) SURVEY.md 8d's budget for the reference formulation (T and T' recurrences for every function in both
 #     passes): 350 flop per pair + 175 per neighbour + 1.6 k = 2.20 MFLOP per atom-step at n = 112
