@@ -21,6 +21,7 @@ struct NeighBuild {
     int max_numneigh = 0;
     int nlocal = 0, nall = 0;
     bool valid = false;
+    int pitch = 0;                  // row pitch learned from the last build (0 = none yet): next build tries one pass
     // scratch
     int *binof = nullptr, *bincount = nullptr, *binstart = nullptr, *binfill = nullptr, *binitems = nullptr;
     long long *blocksum = nullptr;
@@ -157,8 +158,9 @@ __global__ void annp_bin_gather_x(const double *x, int n, const int *binitems, d
 template <bool FILL>
 __global__ __launch_bounds__(256) void annp_neigh_pass(const double *x, const double *xs, int nlocal, BinGeom g, double rc2,
                                                        const int *binof, const int *binstart, const int *binitems,
-                                                       int *numneigh, const long long *first, int *neigh)
+                                                       int *numneigh, const long long *first, int *neigh, int pitch)
 {
+    // pitch > 0 (FILL only): rows are pitch entries apart; entries beyond the pitch are counted, not written
     const int lane = lane_id();
     const int i = uniform(blockIdx.x * ANNP_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     if (i >= nlocal) return;
@@ -166,7 +168,8 @@ __global__ __launch_bounds__(256) void annp_neigh_pass(const double *x, const do
     const int b = binof[i];
     const int c0 = b % g.nb[0], c1 = (b / g.nb[0]) % g.nb[1], c2 = b / (g.nb[0] * g.nb[1]);
     int cnt = 0;
-    int *out = FILL ? neigh + first[i] : nullptr;
+    int *out = FILL ? neigh + (pitch > 0 ? (long long)i * pitch : first[i]) : nullptr;
+    const int room = (FILL && pitch > 0) ? pitch : 0x7fffffff;
     for (int z = c2 - 1; z <= c2 + 1; z++) {
         if (z < 0 || z >= g.nb[2]) continue;
         for (int y = c1 - 1; y <= c1 + 1; y++) {
@@ -184,12 +187,18 @@ __global__ __launch_bounds__(256) void annp_neigh_pass(const double *x, const do
                     in = (j != i) && (dx * dx + dy * dy + dz * dz <= rc2);
                 }
                 const unsigned long long m = __ballot(in);
-                if (FILL && in) out[cnt + __popcll(m & ((1ull << lane) - 1ull))] = j;
+                if (FILL && in) { const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull)); if (pos < room) out[pos] = j; }
                 cnt += __popcll(m);
             }
         }
     }
-    if (!FILL && lane == 0) numneigh[i] = cnt;
+    if ((!FILL || pitch > 0) && lane == 0) numneigh[i] = cnt;
+}
+
+__global__ void annp_first_pitched(long long *first, int n, int pitch)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k <= n) first[k] = (long long)k * pitch;
 }
 
 // exclusive scan of numneigh -> first (int64), three small kernels
@@ -284,8 +293,27 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     NB_TRY(hipMemsetAsync(nb.numneigh, 0, sizeof(int) * (size_t)nall, s));
     const int wb = (nlocal + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK;
     const double rc2 = cutneigh * cutneigh;
+    auto learn_pitch = [&]() { nb.pitch = (nb.max_numneigh + nb.max_numneigh / 16 + 4 + 7) / 8 * 8; };
+    // One pass when the previous build left a row pitch: the distance tests are the whole cost and the exact layout
+    // needs them twice (count, then fill).  Rows that outgrow the pitch only show in the count; then fall through.
+    if (nb.pitch > 0 && (long long)nlocal * nb.pitch < (1ll << 33)) {
+        if (nb_alloc(nb.neigh, nb.cap_neigh, (size_t)nlocal * nb.pitch, nb.bytes, msg)) return -3;
+        NB_TRY(hipMemsetAsync(nb.dmax, 0, 4 * sizeof(long long), s));
+        hipLaunchKernelGGL(annp_first_pitched, dim3((nall + 1 + 255) / 256), dim3(256), 0, s, nb.first, nall, nb.pitch);
+        hipLaunchKernelGGL((annp_neigh_pass<true>), dim3(wb), dim3(256), 0, s, d_x, nb.xs, nlocal, g, rc2, nb.binof, nb.binstart, nb.binitems,
+                           nb.numneigh, (const long long *)nb.first, nb.neigh, nb.pitch);
+        hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(nlocal)), dim3(256), 0, s, nb.numneigh, nlocal, nb.dmax);
+        long long h1[1];
+        NB_TRY(hipMemcpyAsync(h1, nb.dmax, sizeof(h1), hipMemcpyDeviceToHost, s));
+        NB_TRY(hipStreamSynchronize(s));
+        nb.max_numneigh = (int)(h1[0] & 0xffffffffll);
+        const bool fits = nb.max_numneigh <= nb.pitch;
+        learn_pitch();
+        if (fits) { nb.nlocal = nlocal; nb.nall = nall; nb.valid = true; return 0; }
+        NB_TRY(hipMemsetAsync(nb.numneigh, 0, sizeof(int) * (size_t)nall, s));
+    }
     hipLaunchKernelGGL((annp_neigh_pass<false>), dim3(wb), dim3(256), 0, s, d_x, nb.xs, nlocal, g, rc2, nb.binof, nb.binstart, nb.binitems,
-                       nb.numneigh, (const long long *)nullptr, (int *)nullptr);
+                       nb.numneigh, (const long long *)nullptr, (int *)nullptr, 0);
     const int nblk = (nlocal + 1023) / 1024;
     long long *dtot = reinterpret_cast<long long *>(nb.dmax) + 1;
     NB_TRY(hipMemsetAsync(nb.dmax, 0, 4 * sizeof(long long), s));
@@ -300,8 +328,9 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     const long long total = hres[1];
     if (nb_alloc(nb.neigh, nb.cap_neigh, (size_t)std::max<long long>(total, 1), nb.bytes, msg)) return -3;
     hipLaunchKernelGGL((annp_neigh_pass<true>), dim3(wb), dim3(256), 0, s, d_x, nb.xs, nlocal, g, rc2, nb.binof, nb.binstart, nb.binitems,
-                       nb.numneigh, (const long long *)nb.first, nb.neigh);
+                       nb.numneigh, (const long long *)nb.first, nb.neigh, 0);
     NB_TRY(hipGetLastError());
+    learn_pitch();
     nb.nlocal = nlocal; nb.nall = nall; nb.valid = true;
     return 0;
 #undef NB_TRY
