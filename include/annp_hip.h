@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define ANNP_HIP_ABI_VERSION 2
+#define ANNP_HIP_ABI_VERSION 3
 
 #define ANNP_HIP_OK 0
 #define ANNP_HIP_EARG (-1)
@@ -133,7 +133,18 @@ int annp_hip_compute_n(annp_hip_handle *handle, int ago, int inum, int nall, int
  *   d_f [nall*3] accumulated;  d_eatom [nall] accumulated (nullable)
  *   d_eng: 1 double accumulated (nullable);  d_virial: 6 doubles accumulated (nullable)
  *   d_vatom: [nall*6] accumulated (nullable)
- *   stream: hipStream_t (NULL = default stream).  Asynchronous: returns after enqueue. */
+ *   stream: hipStream_t (NULL = default stream).
+ * Asynchronous: every kernel and copy is enqueued on `stream` and the call returns without waiting for
+ * the device (the calling thread's current device is left as it was).  The LDS record capacity of the
+ * force pass comes from the in-cutoff maximum of the PREVIOUS evaluation on the handle, read back
+ * without blocking; Chebyshev: an atom that has more neighbours than that is queued on the device and
+ * evaluated by a fix-up launch on the same stream, so the result is complete whatever the
+ * configuration does between two calls.  Two exceptions wait for the device once: the first
+ * evaluation on a handle, and (Behler only) the one after a capacity error.
+ * Device-side capacity errors (Behler: more in-range neighbours than the previous maximum + 1/8;
+ * anna_adp: more than 128; any: a list row longer than max_numneigh) skip the affected atoms and are
+ * reported as ANNP_HIP_ENEIGHCAP by the NEXT call on the handle or by annp_hip_sync, however many
+ * evaluations were enqueued in between (the error word stays set on the device until it was seen). */
 int annp_hip_compute_device(annp_hip_handle *handle, int inum, int nall,
                             const double *d_x, const int *d_type, const int *d_ilist,
                             const int *d_numneigh, const long long *d_first, const int *d_neigh,
@@ -152,6 +163,11 @@ int annp_hip_neigh_build_device(annp_hip_handle *handle, int nlocal, int nall, c
 /* Blocks until the handle's enqueued work is done and reports deferred device-side
  * errors (e.g. ANNP_HIP_ENEIGHCAP). */
 int annp_hip_sync(annp_hip_handle *handle);
+
+/* Facts about the most recent evaluation (waits for its flag words only):
+ *   info4[0] largest in-cutoff neighbour count   info4[1] atoms that went through the fix-up launch
+ *   info4[2] record capacity its force pass ran with   info4[3] capacity the next evaluation will use */
+int annp_hip_eval_info(annp_hip_handle *handle, int *info4);
 
 /* Kernel timing with HIP events recorded on the stream the kernels are launched on.
  * annp_hip_set_timing(h, 1) starts recording (and resets the sample count); every

@@ -34,14 +34,10 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // (the last gridDim % 8 blocks keep their place).
 __device__ __forceinline__ int xcd_block()
 {
-#if defined(ANNP_VARIANT) && ANNP_VARIANT == 5
-    return blockIdx.x;
-#else
     const int b = blockIdx.x;
     const int q = gridDim.x >> 3;
     if (b >= (q << 3)) return b;
     return (b & 7) * q + (b >> 3);
-#endif
 }
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -52,8 +52,10 @@ struct annp_hip_handle {
     double e_base = 0.0, gp[17] = {0};
     double *d_net = nullptr;            // network image for annp_anna_adp (layer 0 in the device feature layout)
     int net_doubles = 0;
-    int ni_cap = 24;                    // Behler kernels: record capacity per atom for the next descriptor pass
-    int ni_cap_last = 0;                // ... and what the last force pass ran with
+    int ni_cap = 24;                    // Behler kernels: record capacity per atom for the next evaluation
+    bool ni_primed = false;             // ... has been sized from a completed evaluation (else the next one sizes it synchronously)
+    int fe_cap = 0;                     // Chebyshev force pass: record capacity for the next evaluation (0 = not sized yet)
+    int cap_last = 0;                   // capacity the last force pass ran with
     int flagact[MLP_MAXL] = {0, 0, 0, 0};
     double e_scale = 0, e_shift = 0, e_atom = 0, cut = 0, cutsq = 0;
     double *d_norm = nullptr;           // nmul | nsub | nden, ANNP_GPAD each
@@ -64,11 +66,16 @@ struct annp_hip_handle {
     std::vector<double> sym_rad, sym_ang;
     // work buffers
     DevBuf<double> G, coef, x, f, eatom, vatom;
-    DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr;
+    DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ovf;
     DevBuf<long long> first;
     double *d_scalars = nullptr;        // [0] energy, [1..6] virial
-    int *d_flags = nullptr;             // [0] capacity-overflow max n, [1] max in-cutoff n
-    int *h_flags = nullptr;             // pinned mirror
+    int *d_flags = nullptr;             // [0] capacity error: max n of the atoms that were skipped (stays set until the host has
+                                        //     seen it), [1] max in-cutoff n, [2] length of the fix-up queue; [1], [2] per evaluation
+    int *h_flags = nullptr;             // pinned mirror, copied back behind every evaluation
+    hipEvent_t ev_flags = nullptr;      // ... that copy has landed
+    int sticky_rc = 0;                  // error found in a landed copy, returned by the next call on the handle
+    bool reset_err = false;             // d_flags[0] was seen non-zero: clear it before the next evaluation
+    int info[4] = {0, 0, 0, 0};         // annp_hip_eval_info
     double *h_scalars = nullptr;        // pinned mirror
     // neighbour list built on device
     NeighBuild nb;
@@ -88,7 +95,7 @@ struct annp_hip_handle {
     std::vector<hipEvent_t> evring;       // kRing x 4 events, created on first enable
     hipEvent_t *ev = nullptr;             // the four events of the evaluation being enqueued
     long long ev_count = 0;               // evaluations recorded since timing was enabled
-    bool flags_pending = false;         // h_flags holds an un-inspected copy of d_flags (Behler path: no mid-step sync)
+    bool flags_pending = false;         // a copy of d_flags into h_flags is in flight or not yet looked at
     bool mlp_attr_done = false;
 };
 
@@ -183,17 +190,117 @@ std::vector<double> mlp_image(const annp_hip_handle *h, const double *const *W, 
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Record capacities for the next evaluation from the in-cutoff maximum of the last one.
+// Chebyshev force pass: an atom above the capacity is not lost, it goes through the fix-up launch, so the slack is
+// small; 128 is kept as long as the maximum allows it (up to there a lane holds 1/r and fc' in registers).
+int fe_next_cap(int mx)
+{
+    int c = std::max(16, round_up(mx + 2, 16));
+    if (mx <= 128 && c > 128) c = 128;
+    return c;
+}
+// Behler kernels: nothing stands behind an overflow (it is reported and the evaluation has to be re-issued), so the
+// slack is generous: an eighth of the count, at least 2.
+int ni_next_cap(int mx) { return std::max(16, round_up(mx + std::max(2, mx / 8), 8)); }
+
+// Look at the flag words an evaluation copied back.  Updates the capacities for the next evaluation and turns a
+// device-side capacity error into sticky_rc.
+void digest_flags(annp_hip_handle *h)
+{
+    const int over = h->h_flags[0], mx = h->h_flags[1], nfix = h->h_flags[2];
+    h->info[0] = mx; h->info[1] = nfix; h->info[2] = h->cap_last;
+    if (h->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
+        h->fe_cap = fe_next_cap(mx);
+        h->info[3] = h->fe_cap;
+        if (over > 0)
+            h->sticky_rc = fail(h, ANNP_HIP_ENEIGHCAP, "an atom has %d in-cutoff neighbours, more than the list-row capacity the "
+                                "evaluation was given (max_numneigh) or than LDS holds; it was skipped", over);
+    } else if (h->descriptor == ANNP_HIP_DESC_BEHLER) {
+        if (over > 0) {
+            h->ni_cap = round_up(over + 2, 8);
+            h->ni_primed = false;
+            h->sticky_rc = fail(h, ANNP_HIP_ENEIGHCAP, "%d neighbours inside the descriptor cutoff exceed the record capacity %d of "
+                                "that evaluation; the affected atoms were skipped: re-issue it (the capacity has been raised)",
+                                over, h->cap_last);
+        } else {
+            h->ni_cap = ni_next_cap(mx);
+        }
+        h->info[3] = h->ni_cap;
+    } else {
+        h->info[3] = h->cap_last;
+        if (over > 0)
+            h->sticky_rc = fail(h, ANNP_HIP_ENEIGHCAP, "%d neighbours inside the descriptor cutoff exceed the kernel capacity %d; "
+                                "the affected atoms were skipped", over, h->cap_last);
+    }
+    if (over > 0) h->reset_err = true;
+}
+
+// wait = false: only if the copy has landed already (never blocks); wait = true: block until it has.
+// Returns a pending error once.
+int poll_flags(annp_hip_handle *h, bool wait)
+{
+    if (h->flags_pending) {
+        hipError_t e = wait ? hipEventSynchronize(h->ev_flags) : hipEventQuery(h->ev_flags);
+        if (e == hipSuccess) {
+            h->flags_pending = false;
+            digest_flags(h);
+        } else if (e != hipErrorNotReady) {
+            return fail(h, ANNP_HIP_EDEVICE, "flag read-back failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (h->sticky_rc) {
+        const int rc = h->sticky_rc;
+        h->sticky_rc = 0;
+        return rc;
+    }
+    return 0;
+}
+
+// the calling thread's current device is put back when an entry point returns
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) { err = hipSetDevice(dev); switched = (err == hipSuccess) && prev >= 0; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define DEVICE_GUARD(h)                                                                              \
+    DeviceGuard guard_((h)->device);                                                                 \
+    if (guard_.err != hipSuccess) return fail(h, ANNP_HIP_EDEVICE, "hipSetDevice(%d) failed: %s", (h)->device, hipGetErrorString(guard_.err))
+
+template <bool VIR>
+void launch_fe_force(const FeArgs &a, int blocks, hipStream_t s)
+{
+    if (fe_force_auxreg(a.n_cap))
+        hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, VIR, true>), dim3(blocks), dim3(256), fe_force_lds_per_wave(a.n_cap, true) * ANNP_WAVES_PER_BLOCK, s, a);
+    else
+        hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, VIR, false>), dim3(blocks), dim3(256), fe_force_lds_per_wave(a.n_cap, false) * ANNP_WAVES_PER_BLOCK, s, a);
+}
+
 // ---- one evaluation on device-resident data ----------------------------------------
-int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_x, const int *d_ilist,
+// Nothing here waits for the device in the steady state: capacities come from the previous evaluation's flag
+// words (whenever their copy has landed), this evaluation's flag words are copied back behind its last kernel.
+// Only the first evaluation on a handle (and the one after a Behler capacity error) sizes itself synchronously.
+int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_x, const int *d_type, const int *d_ilist,
                         const int *d_numneigh, const long long *d_first, const int *d_neigh, int max_numneigh,
                         double *d_f, double *d_eatom, double *d_eng, double *d_virial, double *d_vatom, hipStream_t s)
 {
-    if (inum <= 0) return 0;
     int rc;
+    if ((rc = poll_flags(h, false))) return rc;      // an error of an earlier evaluation, reported once
+    if (inum <= 0) return 0;
     if ((rc = ensure(h, h->G, (size_t)inum * ANNP_GPAD))) return rc;
     if ((rc = ensure(h, h->coef, (size_t)inum * ANNP_CPAD))) return rc;
     if ((rc = ensure(h, h->ncount, (size_t)inum))) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, 2 * sizeof(int), s));
+    if (h->reset_err) {
+        HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, 3 * sizeof(int), s));
+        h->reset_err = false;
+    } else {
+        HIP_TRY(h, hipMemsetAsync(h->d_flags + 1, 0, 2 * sizeof(int), s));
+    }
     if (h->timing) {
         h->ev = h->evring.data() + 4 * (size_t)(h->ev_count % annp_hip_handle::kRing);
         HIP_TRY(h, hipEventRecord(h->ev[0], s));
@@ -228,23 +335,40 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         m.act_plain = 0; m.energy_raw = 0;
         if ((rc = run_mlp(h, m, s))) return rc;
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
-        // pass 3: size the LDS records by the in-cutoff maximum just measured
-        HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipStreamSynchronize(s));
-        if (h->h_flags[0] > 0)
-            return fail(h, ANNP_HIP_ENEIGHCAP, "in-cutoff neighbours %d exceed capacity %d", h->h_flags[0], a.n_cap);
-        a.n_cap = std::max(16, round_up(h->h_flags[1], 16));
-        size_t lds3 = fe_force_lds_per_wave(a.n_cap) * ANNP_WAVES_PER_BLOCK;
-        if (lds3 > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "too many in-cutoff neighbours for LDS (%d)", h->h_flags[1]);
-        const bool vir = d_virial || d_vatom;
-        if (fe_force_auxreg(a.n_cap)) {
-            if (vir) hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, true, true>), dim3(blocks), dim3(256), lds3, s, a);
-            else hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, false, true>), dim3(blocks), dim3(256), lds3, s, a);
+        // pass 3: LDS records sized by the in-cutoff maximum of the previous evaluation; an atom that has more
+        // is queued by the kernel and taken by the fix-up launch behind it, which has room for a whole list row
+        int cap3;
+        if (h->fe_cap == 0) {       // first evaluation on this handle: read the maximum just measured, once
+            HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+            if (h->h_flags[0] > 0) {
+                h->reset_err = true;
+                return fail(h, ANNP_HIP_ENEIGHCAP, "in-cutoff neighbours %d exceed capacity %d", h->h_flags[0], a.n_cap);
+            }
+            cap3 = std::max(16, round_up(h->h_flags[1], 16));
+            h->fe_cap = fe_next_cap(h->h_flags[1]);
         } else {
-            if (vir) hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, true, false>), dim3(blocks), dim3(256), lds3, s, a);
-            else hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, false, false>), dim3(blocks), dim3(256), lds3, s, a);
+            cap3 = std::min(h->fe_cap, cap_list);
         }
+        const bool vir = d_virial || d_vatom;
+        if ((rc = ensure(h, h->ovf, (size_t)inum))) return rc;
+        a.n_cap = cap3;
+        const size_t lds_fix = fe_force_lds_per_wave(cap_list, false);      // the fix-up runs one wave per workgroup
+        const bool fixup = cap3 < cap_list && lds_fix <= 160 * 1024;
+        a.ovf_count = h->d_flags + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
+        if (fe_force_lds_per_wave(cap3) * ANNP_WAVES_PER_BLOCK > 160 * 1024)
+            return fail(h, ANNP_HIP_ENEIGHCAP, "too many in-cutoff neighbours for LDS (%d)", cap3);
+        if (vir) launch_fe_force<true>(a, blocks, s); else launch_fe_force<false>(a, blocks, s);
         HIP_TRY(h, hipGetLastError());
+        if (fixup) {
+            FeArgs b = a;
+            b.n_cap = cap_list;
+            const int fblocks = std::min(inum, 1024);
+            if (vir) hipLaunchKernelGGL((annp_fe_force_fixup<FE_NP, FE_NT, true>), dim3(fblocks), dim3(64), lds_fix, s, b);
+            else hipLaunchKernelGGL((annp_fe_force_fixup<FE_NP, FE_NT, false>), dim3(fblocks), dim3(64), lds_fix, s, b);
+            HIP_TRY(h, hipGetLastError());
+        }
+        h->cap_last = cap3;
     } else if (h->descriptor == ANNP_HIP_DESC_ANNA_ADP) {
         // pass 1: the same Chebyshev descriptor kernel, raw sums (adp:584-612 has no normalisation)
         FeArgs a{};
@@ -271,10 +395,9 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         if (d_virial || d_vatom) hipLaunchKernelGGL((annp_anna_adp<true>), dim3(anna_blocks(inum)), dim3(256), lds2, s, q);
         else hipLaunchKernelGGL((annp_anna_adp<false>), dim3(anna_blocks(inum)), dim3(256), lds2, s, q);
         HIP_TRY(h, hipGetLastError());
-        // more in-range neighbours than a wave holds (128) is reported at the next sync point
-        HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-        h->flags_pending = true;
-        h->ni_cap_last = q.n_cap;
+        // more in-range neighbours than a wave holds (128): the error word stays set on the device until the host
+        // has seen it, so it is reported by the next call or annp_hip_sync however many evaluations are enqueued
+        h->cap_last = q.n_cap;
     } else {
         NiArgs a{};
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
@@ -283,9 +406,31 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.vatom = d_vatom; a.ncount = h->ncount.p; a.errflag = h->d_flags;
         if (a.npsf > NI_MAXP || a.ntsf > NI_MAXT)
             return fail(h, ANNP_HIP_ESHAPE, "Behler kernels support npsf<=%d ntsf<=%d", NI_MAXP, NI_MAXT);
-        // pass 1 with the capacity that sufficed last time; the in-range maximum comes back with the overflow flag
         const int cap_max = ni_max_cap(true, h->nsf);
-        for (int attempt = 0;; attempt++) {
+        int cap_force;
+        if (!h->ni_primed) {
+            // first evaluation (or the one after a capacity error): size the records synchronously, retry once
+            for (int attempt = 0;; attempt++) {
+                a.n_cap = std::min(h->ni_cap, cap_max);
+                if ((rc = ensure(h, h->ni_nbr, (size_t)inum * a.n_cap))) return rc;
+                a.nbr = h->ni_nbr.p; a.nbr_stride = a.n_cap;
+                ni_launch_desc(a, h->ni_shape, s);
+                HIP_TRY(h, hipGetLastError());
+                hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
+                HIP_TRY(h, hipGetLastError());
+                HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+                HIP_TRY(h, hipStreamSynchronize(s));
+                if (h->h_flags[0] <= 0) break;
+                HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, 3 * sizeof(int), s));
+                if (h->h_flags[0] > cap_max || attempt > 0)
+                    return fail(h, ANNP_HIP_ENEIGHCAP, "%d neighbours inside the descriptor cutoff exceed the kernel capacity %d",
+                                h->h_flags[0], cap_max);
+                h->ni_cap = round_up(h->h_flags[0], 8);           // some atom overflowed: redo the pass with room for it
+            }
+            h->ni_cap = ni_next_cap(h->h_flags[1]);
+            h->ni_primed = true;
+            cap_force = std::max(8, round_up(h->h_flags[1], 8));
+        } else {
             a.n_cap = std::min(h->ni_cap, cap_max);
             if ((rc = ensure(h, h->ni_nbr, (size_t)inum * a.n_cap))) return rc;
             a.nbr = h->ni_nbr.p; a.nbr_stride = a.n_cap;
@@ -293,42 +438,23 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             HIP_TRY(h, hipGetLastError());
             hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
             HIP_TRY(h, hipGetLastError());
-            HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-            HIP_TRY(h, hipStreamSynchronize(s));
-            if (h->h_flags[0] <= 0) break;
-            if (h->h_flags[0] > cap_max || attempt > 0)
-                return fail(h, ANNP_HIP_ENEIGHCAP, "%d neighbours inside the descriptor cutoff exceed the kernel capacity %d",
-                            h->h_flags[0], cap_max);
-            h->ni_cap = round_up(h->h_flags[0], 8);           // some atom overflowed: redo the pass with room for it
-            HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, 2 * sizeof(int), s));
+            cap_force = a.n_cap;
         }
-        h->ni_cap = std::max(16, round_up(h->h_flags[1] + 2, 8));   // a little slack for the next call
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
         m.act_plain = 1; m.energy_raw = 1;
         if ((rc = run_mlp(h, m, s))) return rc;
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
-        a.n_cap = std::max(8, round_up(h->h_flags[1], 8));
-        h->ni_cap_last = a.n_cap;
+        a.n_cap = cap_force;
+        h->cap_last = cap_force;
         ni_launch_force(a, h->ni_shape, d_virial != nullptr || d_vatom != nullptr, s);
         HIP_TRY(h, hipGetLastError());
-        // positions cannot change between the passes, so the force pass cannot overflow; the flag is still read
-        // back at the next sync point as a guard
-        HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-        h->flags_pending = true;
     }
+    // flag words of this evaluation, for whoever looks next (poll_flags)
+    HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipEventRecord(h->ev_flags, s));
+    h->flags_pending = true;
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[3], s)); h->ev_count++; }
-    (void)nall;
-    return 0;
-}
-
-// after the stream has been synchronised: turn a pending capacity report into an error
-int check_pending_flags(annp_hip_handle *h)
-{
-    if (!h->flags_pending) return 0;
-    h->flags_pending = false;
-    if (h->h_flags[0] > 0)
-        return fail(h, ANNP_HIP_ENEIGHCAP, "%d neighbours inside the descriptor cutoff exceed the kernel capacity %d; "
-                    "the affected atoms were skipped", h->h_flags[0], h->ni_cap_last);
+    (void)nall; (void)d_type;
     return 0;
 }
 
@@ -346,20 +472,21 @@ double annp_hip_bytes(const annp_hip_handle *h) { return h ? (double)h->bytes : 
 void annp_hip_clear(annp_hip_handle *h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    DeviceGuard guard_(h->device);
+    (void)hipDeviceSynchronize();           // evaluations may still be running on the caller's streams
     if (h->d_norm) (void)hipFree(h->d_norm);
     if (h->d_sym) (void)hipFree(h->d_sym);
     if (h->d_isym) (void)hipFree(h->d_isym);
     if (h->d_mlp_img) (void)hipFree(h->d_mlp_img);
     if (h->d_net) (void)hipFree(h->d_net);
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom); release(h, h->vatom);
-    release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr);
+    release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr); release(h, h->ovf);
     release(h, h->first);
     neigh_release(h->nb);
     if (h->d_scalars) (void)hipFree(h->d_scalars);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->h_flags) (void)hipHostFree(h->h_flags);
+    if (h->ev_flags) (void)hipEventDestroy(h->ev_flags);
     if (h->pin_f) (void)hipHostFree(h->pin_f);
     if (h->pin_e) (void)hipHostFree(h->pin_e);
     if (h->pin_v) (void)hipHostFree(h->pin_v);
@@ -415,8 +542,10 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
             return bail(e_ == hipErrorOutOfMemory ? ANNP_HIP_ENOMEM : ANNP_HIP_EDEVICE);                 \
         }                                                                                                \
     } while (0)
-    INIT_TRY(hipSetDevice(device));
+    DeviceGuard guard_(device);
+    INIT_TRY(guard_.err);
     INIT_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    INIT_TRY(hipEventCreateWithFlags(&h->ev_flags, hipEventDisableTiming));
     h->descriptor = p->descriptor; h->ntypes = p->ntypes; h->ntl = p->ntl; h->nhl = p->nhl; h->nnod = p->nnod;
     h->nsf = p->nsf; h->npsf = p->npsf; h->ntsf = p->ntsf; h->nl = nl; h->ni_compat = p->ni_compat;
     h->e_scale = p->e_scale; h->e_shift = p->e_shift; h->e_atom = p->e_atom; h->cut = p->cut;
@@ -594,6 +723,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     }
     INIT_TRY(hipMalloc((void **)&h->d_scalars, 8 * sizeof(double)));
     INIT_TRY(hipMalloc((void **)&h->d_flags, 4 * sizeof(int)));
+    INIT_TRY(hipMemset(h->d_flags, 0, 4 * sizeof(int)));
     INIT_TRY(hipHostMalloc((void **)&h->h_flags, 4 * sizeof(int)));
     INIT_TRY(hipHostMalloc((void **)&h->h_scalars, 8 * sizeof(double)));
     h->bytes += 8 * sizeof(double) + 4 * sizeof(int);
@@ -605,6 +735,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_fixup<FE_NP, FE_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_fixup<FE_NP, FE_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(ni_set_lds_attributes());
         INIT_TRY(hipFuncSetAttribute((const void *)annp_anna_adp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_anna_adp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
@@ -624,7 +756,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
 int annp_hip_set_timing(annp_hip_handle *h, int enable)
 {
     if (!h) return ANNP_HIP_EARG;
-    HIP_TRY(h, hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     if (enable && h->evring.empty()) {
         h->evring.assign((size_t)annp_hip_handle::kRing * 4, nullptr);
         for (hipEvent_t &e : h->evring) HIP_TRY(h, hipEventCreate(&e));
@@ -651,7 +783,7 @@ int annp_hip_last_timing(annp_hip_handle *h, double *ms4)
 {
     if (!h || !ms4) return ANNP_HIP_EARG;
     if (h->ev_count == 0) return fail(h, ANNP_HIP_EARG, "no timed evaluation recorded");
-    HIP_TRY(h, hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     return timing_slot(h, h->ev_count - 1, ms4);
 }
 
@@ -659,7 +791,7 @@ int annp_hip_timing_stats(annp_hip_handle *h, double *ms4_mean, int *nsamples)
 {
     if (!h || !ms4_mean) return ANNP_HIP_EARG;
     if (h->ev_count == 0) return fail(h, ANNP_HIP_EARG, "no timed evaluation recorded");
-    HIP_TRY(h, hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     const long long n = std::min<long long>(h->ev_count, annp_hip_handle::kRing);
     double acc[4] = {0, 0, 0, 0};
     for (long long k = h->ev_count - n; k < h->ev_count; k++) {
@@ -676,7 +808,7 @@ int annp_hip_timing_stats(annp_hip_handle *h, double *ms4_mean, int *nsamples)
 int annp_hip_last_counts(annp_hip_handle *h, int *counts, int inum)
 {
     if (!h || !counts || inum < 0 || (size_t)inum > h->ncount.cap) return h ? fail(h, ANNP_HIP_EARG, "last_counts: bad argument") : ANNP_HIP_EARG;
-    HIP_TRY(h, hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipMemcpy(counts, h->ncount.p, sizeof(int) * (size_t)inum, hipMemcpyDeviceToHost));
     return 0;
@@ -685,9 +817,22 @@ int annp_hip_last_counts(annp_hip_handle *h, int *counts, int inum)
 int annp_hip_sync(annp_hip_handle *h)
 {
     if (!h) return ANNP_HIP_EARG;
-    HIP_TRY(h, hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     HIP_TRY(h, hipDeviceSynchronize());
-    return check_pending_flags(h);
+    return poll_flags(h, true);
+}
+
+int annp_hip_eval_info(annp_hip_handle *h, int *info4)
+{
+    if (!h || !info4) return ANNP_HIP_EARG;
+    DEVICE_GUARD(h);
+    if (h->flags_pending) {     // the error, if any, stays for the next call or annp_hip_sync to report
+        HIP_TRY(h, hipEventSynchronize(h->ev_flags));
+        h->flags_pending = false;
+        digest_flags(h);
+    }
+    for (int k = 0; k < 4; k++) info4[k] = h->info[k];
+    return 0;
 }
 
 int annp_hip_compute_device(annp_hip_handle *h, int inum, int nall,
@@ -699,9 +844,8 @@ int annp_hip_compute_device(annp_hip_handle *h, int inum, int nall,
     if (!h) return ANNP_HIP_EARG;
     if (inum < 0 || nall < inum || !d_x || !d_f || (inum > 0 && (!d_numneigh || !d_first || !d_neigh)))
         return fail(h, ANNP_HIP_EARG, "annp_hip_compute_device: bad argument");
-    (void)d_type;   // single-element potentials: the type never enters the arithmetic
-    HIP_TRY(h, hipSetDevice(h->device));
-    return compute_device_impl(h, inum, nall, d_x, d_ilist, d_numneigh, d_first, d_neigh, max_numneigh,
+    DEVICE_GUARD(h);
+    return compute_device_impl(h, inum, nall, d_x, d_type, d_ilist, d_numneigh, d_first, d_neigh, max_numneigh,
                                d_f, d_eatom, d_eng, d_virial, d_vatom, (hipStream_t)stream);
 }
 
@@ -710,7 +854,7 @@ int annp_hip_neigh_build_device(annp_hip_handle *h, int nlocal, int nall, const 
                                 int *max_numneigh, void *stream)
 {
     if (!h || !d_x || nlocal < 0 || nall < nlocal || cutneigh <= 0) return h ? fail(h, ANNP_HIP_EARG, "neigh_build: bad argument") : ANNP_HIP_EARG;
-    HIP_TRY(h, hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     std::string msg;
     size_t before = h->nb.bytes;
     int rc = neigh_build(h->nb, nlocal, nall, d_x, cutneigh, (hipStream_t)stream, msg);
@@ -754,7 +898,7 @@ static int host_finish(annp_hip_handle *h, int inum, int nall, int eflag, int vf
     }
     HIP_TRY(h, hipMemcpyAsync(h->h_scalars, h->d_scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
-    if (int rcf = check_pending_flags(h)) return rcf;
+    if (int rcf = poll_flags(h, true)) return rcf;
     if (vatom) { const double *hv = h->pin_v; for (size_t k = 0; k < (size_t)nall * 6; k++) vatom[k] += hv[k]; }
     { const double *hf = h->pin_f; for (size_t k = 0; k < (size_t)nall * 3; k++) f[k] += hf[k]; }     // fe:199,211: += / -=
     if (eflag && eng_vdwl) *eng_vdwl += h->h_scalars[0];                          // fe:185
@@ -762,6 +906,34 @@ static int host_finish(annp_hip_handle *h, int inum, int nall, int eflag, int vf
     if (vflag && virial) for (int k = 0; k < 6; k++) virial[k] += h->h_scalars[1 + k];
     (void)inum;
     return 0;
+}
+
+// Positions are on the device (h->x); run one evaluation on the handle's stream and bring the results back.
+// A Behler capacity overflow is not an error here: the call is synchronous anyway, so it runs the evaluation
+// again with the raised capacity.
+static int host_evaluate(annp_hip_handle *h, int inum, int nall, const int *host_type, const int *d_ilist,
+                         const int *d_numneigh, const long long *d_first, const int *d_neigh, int max_numneigh,
+                         int eflag, int vflag, int eatom_flag,
+                         double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom)
+{
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = ensure(h, h->f, (size_t)nall * 3)) || (rc = ensure(h, h->eatom, (size_t)nall))) return rc;
+    if (vatom && (rc = ensure(h, h->vatom, (size_t)nall * 6))) return rc;
+    (void)host_type;
+    const bool want_eatom = eflag && eatom_flag && eatom;
+    for (int attempt = 0;; attempt++) {
+        HIP_TRY(h, hipMemsetAsync(h->f.p, 0, sizeof(double) * (size_t)nall * 3, s));
+        HIP_TRY(h, hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), s));
+        if (want_eatom) HIP_TRY(h, hipMemsetAsync(h->eatom.p, 0, sizeof(double) * (size_t)nall, s));
+        if (vatom) HIP_TRY(h, hipMemsetAsync(h->vatom.p, 0, sizeof(double) * (size_t)nall * 6, s));
+        rc = compute_device_impl(h, inum, nall, h->x.p, nullptr, d_ilist, d_numneigh, d_first, d_neigh, max_numneigh,
+                                 h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr,
+                                 vatom ? h->vatom.p : nullptr, s);
+        if (!rc) rc = host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, vatom);
+        if (rc == ANNP_HIP_ENEIGHCAP && attempt == 0 && h->descriptor == ANNP_HIP_DESC_BEHLER && !h->ni_primed) continue;
+        return rc;
+    }
 }
 
 int annp_hip_compute(annp_hip_handle *h, int ago, int inum, int nall, int nghost,
@@ -775,7 +947,7 @@ int annp_hip_compute(annp_hip_handle *h, int ago, int inum, int nall, int nghost
         return fail(h, ANNP_HIP_EARG, "annp_hip_compute: bad argument");
     const bool want_vatom = vatom_flag && vatom;
     (void)host_type;
-    HIP_TRY(h, hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     hipStream_t s = h->stream;
     int rc;
     // neighbour list: re-packed to CSR and uploaded when LAMMPS rebuilt it (ago == 0)
@@ -808,22 +980,10 @@ int annp_hip_compute(annp_hip_handle *h, int ago, int inum, int nall, int nghost
         h->list_max = mx;
         h->list_valid = true;
     }
-    if ((rc = ensure(h, h->x, (size_t)nall * 3)) || (rc = ensure(h, h->f, (size_t)nall * 3)) || (rc = ensure(h, h->eatom, (size_t)nall)))
-        return rc;
+    if ((rc = ensure(h, h->x, (size_t)nall * 3))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->x.p, host_x, sizeof(double) * (size_t)nall * 3, hipMemcpyHostToDevice, s));
-    HIP_TRY(h, hipMemsetAsync(h->f.p, 0, sizeof(double) * (size_t)nall * 3, s));
-    HIP_TRY(h, hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), s));
-    const bool want_eatom = eflag && eatom_flag && eatom;
-    if (want_eatom) HIP_TRY(h, hipMemsetAsync(h->eatom.p, 0, sizeof(double) * (size_t)nall, s));
-    if (want_vatom) {
-        if ((rc = ensure(h, h->vatom, (size_t)nall * 6))) return rc;
-        HIP_TRY(h, hipMemsetAsync(h->vatom.p, 0, sizeof(double) * (size_t)nall * 6, s));
-    }
-    rc = compute_device_impl(h, inum, nall, h->x.p, h->ilist.p, h->numneigh.p, h->first.p, h->neigh.p, h->list_max,
-                             h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr,
-                             want_vatom ? h->vatom.p : nullptr, s);
-    if (rc) return rc;
-    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, want_vatom ? vatom : nullptr);
+    return host_evaluate(h, inum, nall, host_type, h->ilist.p, h->numneigh.p, h->first.p, h->neigh.p, h->list_max,
+                         eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, want_vatom ? vatom : nullptr);
 }
 
 int annp_hip_compute_n(annp_hip_handle *h, int ago, int inum, int nall, int nghost,
@@ -837,11 +997,10 @@ int annp_hip_compute_n(annp_hip_handle *h, int ago, int inum, int nall, int ngho
         return fail(h, ANNP_HIP_EARG, "annp_hip_compute_n: bad argument");
     const bool want_vatom = vatom_flag && vatom;
     (void)host_type; (void)sublo; (void)subhi;
-    HIP_TRY(h, hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     hipStream_t s = h->stream;
     int rc;
-    if ((rc = ensure(h, h->x, (size_t)nall * 3)) || (rc = ensure(h, h->f, (size_t)nall * 3)) || (rc = ensure(h, h->eatom, (size_t)nall)))
-        return rc;
+    if ((rc = ensure(h, h->x, (size_t)nall * 3))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->x.p, host_x, sizeof(double) * (size_t)nall * 3, hipMemcpyHostToDevice, s));
     if (ago == 0 || !h->nb.valid || h->nb.nlocal != inum || h->nb.nall != nall) {
         std::string msg;
@@ -850,19 +1009,8 @@ int annp_hip_compute_n(annp_hip_handle *h, int ago, int inum, int nall, int ngho
         h->bytes += h->nb.bytes - before;
         if (rc) return fail(h, rc, "%s", msg.c_str());
     }
-    HIP_TRY(h, hipMemsetAsync(h->f.p, 0, sizeof(double) * (size_t)nall * 3, s));
-    HIP_TRY(h, hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), s));
-    const bool want_eatom = eflag && eatom_flag && eatom;
-    if (want_eatom) HIP_TRY(h, hipMemsetAsync(h->eatom.p, 0, sizeof(double) * (size_t)nall, s));
-    if (want_vatom) {
-        if ((rc = ensure(h, h->vatom, (size_t)nall * 6))) return rc;
-        HIP_TRY(h, hipMemsetAsync(h->vatom.p, 0, sizeof(double) * (size_t)nall * 6, s));
-    }
-    rc = compute_device_impl(h, inum, nall, h->x.p, nullptr, h->nb.numneigh, h->nb.first, h->nb.neigh, h->nb.max_numneigh,
-                             h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr,
-                             want_vatom ? h->vatom.p : nullptr, s);
-    if (rc) return rc;
-    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, want_vatom ? vatom : nullptr);
+    return host_evaluate(h, inum, nall, host_type, nullptr, h->nb.numneigh, h->nb.first, h->nb.neigh, h->nb.max_numneigh,
+                         eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, want_vatom ? vatom : nullptr);
 }
 
 }  // extern "C"

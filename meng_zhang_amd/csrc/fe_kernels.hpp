@@ -26,10 +26,6 @@
 #pragma once
 #include "annp_common.hpp"
 
-#ifndef ANNP_VARIANT
-#define ANNP_VARIANT 0
-#endif
-
 namespace annp {
 
 constexpr int FE_NP = 9;      // radial Chebyshev orders the kernels are instantiated for (T_0..T_8)
@@ -55,7 +51,12 @@ struct FeArgs {
     double *virial;            // nullable, 6 doubles accumulated
     double *vatom;             // nullable, [nall][6] accumulated (needs the VIRIAL kernel variant)
     int *ncount;               // nullable [inum]: in-cutoff neighbour count
-    int *errflag;              // device int: max n seen when n > n_cap
+    int *errflag;              // device int: max n seen when n > n_cap and nothing can take the atom over
+    // force pass only: atoms whose in-cutoff count exceeds n_cap are queued for annp_fe_force_fixup, which
+    // runs them with the list-length capacity on the same stream (nullable: report through errflag instead)
+    int *ovf_count;            // device int, zeroed per evaluation
+    int *ovf_list;             // [ovf_cap] entries ii
+    int ovf_cap;
 };
 
 // LDS layout of one wave.  A record is two 16-byte halves (e_x,e_y) and (e_z,fc), kept in two
@@ -76,11 +77,12 @@ __host__ __device__ inline size_t fe_desc_lds_per_wave(int n_cap)
 // AUXREG (n_cap <= 128): a lane owns neighbours lane and lane+64 and keeps their 1/r and fc' in registers;
 // otherwise they live in LDS.  The neighbour index always does (it is written by the compacting lane).
 __host__ __device__ inline bool fe_force_auxreg(int n_cap) { return n_cap <= 128; }
-__host__ __device__ inline size_t fe_force_lds_per_wave(int n_cap)
+__host__ __device__ inline size_t fe_force_lds_per_wave(int n_cap, bool auxreg)
 {
-    const size_t b = (size_t)fe_slots(n_cap) * (32 + 40) + (size_t)n_cap * (fe_force_auxreg(n_cap) ? 4 : 16 + 4);
+    const size_t b = (size_t)fe_slots(n_cap) * (32 + 40) + (size_t)n_cap * (auxreg ? 4 : 16 + 4);
     return (b + 15) & ~(size_t)15;                  // every wave's base stays b128-aligned
 }
+__host__ __device__ inline size_t fe_force_lds_per_wave(int n_cap) { return fe_force_lds_per_wave(n_cap, fe_force_auxreg(n_cap)); }
 
 // ---- stage A, first sweep: candidates -> compacted raw entries (dx,dy | dz,r^2) [+ index]
 template <bool WITH_J>
@@ -350,16 +352,10 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
 //   (copies behind n have their own accumulators, folded back at the end).
 // ---------------------------------------------------------------------------------
 template <int NP, int NT, bool VIRIAL, bool AUXREG>
-__global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
+__device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, const int lane, unsigned char *wbase)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = lane_id();
-    const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
-    if (ii >= p.inum) return;
     const int nslot = fe_slots(p.n_cap);
     const int NZ = p.n_cap + fe_lcap(p.n_cap);
-    unsigned char *wbase = lds_raw + (size_t)wave * fe_force_lds_per_wave(p.n_cap);
     double2 *recA = reinterpret_cast<double2 *>(wbase);
     double2 *recB = recA + nslot;
     // 5 accumulators per slot (stride 40 B: the 16 lanes of an LDS pass land on 16 distinct even
@@ -377,8 +373,12 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     const double *cf = p.coef + (size_t)ii * ANNP_CPAD;
 
     const int n = fe_compact<true>(p, i, lane, recA, recB, auxJ);
-    if (n > p.n_cap) {
-        if (lane == 0) atomicMax(p.errflag, n);
+    if (n > p.n_cap) {          // does not fit this launch's records: hand the atom to the fix-up launch
+        if (lane == 0) {
+            const int k = p.ovf_list ? atomicAdd(p.ovf_count, 1) : p.ovf_cap;
+            if (k < p.ovf_cap) p.ovf_list[k] = ii;
+            else atomicMax(p.errflag, n);
+        }
         return;
     }
     wave_lds_sync();
@@ -490,14 +490,10 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
             const double be = Pd * B1.y;           // dP/dz fc_b
             va0 = fma(be, B0.x, va0); va1 = fma(be, B0.y, va1); va2 = fma(be, B1.x, va2);
             sa = fma(P, B1.y, sa);
-#if ANNP_VARIANT != 3
             atomicAdd(q + 0, Pd * fa0);            // dP/dz fc_a e_a
             atomicAdd(q + 1, Pd * fa1);
             atomicAdd(q + 2, Pd * fa2);
             atomicAdd(q + 3, P * A1.y);
-#else
-            asm volatile("" ::"v"(Pd * fa0), "v"(Pd * fa1), "v"(Pd * fa2), "v"(P * A1.y), "v"(q));
-#endif
         };
 
         int s = 0;
@@ -557,13 +553,9 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
         const double g1 = fma(t, E0.y, -V1 * rinv);
         const double g2 = fma(t, E1.x, -V2 * rinv);
         const int j = auxJ[a];
-#if ANNP_VARIANT != 4
         atomicAdd(&p.f[3 * (size_t)j], -g0);
         atomicAdd(&p.f[3 * (size_t)j + 1], -g1);
         atomicAdd(&p.f[3 * (size_t)j + 2], -g2);
-#else
-        asm volatile("" ::"v"(j));
-#endif
         fi0 += g0; fi1 += g1; fi2 += g2;
         if (VIRIAL) {   // ev_tally_xyz(i,j,...,fx=-Fj, del = xi-xj = r e)   (fe:201-209)
             const double r = 1.0 / rinv;
@@ -606,6 +598,38 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
                 atomicAdd(vi + 3, 0.5 * v3); atomicAdd(vi + 4, 0.5 * v4); atomicAdd(vi + 5, 0.5 * v5);
             }
         }
+    }
+}
+
+// one wave per atom of the launch
+template <int NP, int NT, bool VIRIAL, bool AUXREG>
+__global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const int wave = uniform(threadIdx.x >> 6);
+    const int ii = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
+    if (ii >= p.inum) return;
+    fe_force_atom<NP, NT, VIRIAL, AUXREG>(p, ii, lane, lds_raw + (size_t)wave * fe_force_lds_per_wave(p.n_cap, AUXREG));
+}
+
+// Fix-up launch: the atoms the main launch queued (their in-cutoff count exceeded the capacity its LDS records were
+// sized for, which comes from the previous evaluation) are evaluated here with p.n_cap = the list-row capacity, which
+// no atom can exceed.  Fixed small grid, every wave walks the queue; with an empty queue (the steady state) the
+// launch costs a few microseconds and the host never has to look at the count.
+template <int NP, int NT, bool VIRIAL>
+__global__ __launch_bounds__(256) void annp_fe_force_fixup(FeArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const int wave = uniform(threadIdx.x >> 6);
+    const int count = uniform(min(*p.ovf_count, p.ovf_cap));
+    unsigned char *wbase = lds_raw + (size_t)wave * fe_force_lds_per_wave(p.n_cap, false);
+    FeArgs q = p;
+    q.ovf_list = nullptr; q.ovf_cap = 0;          // nothing behind this launch: a second overflow is an error
+    for (int k = blockIdx.x * ANNP_WAVES_PER_BLOCK + wave; k < count; k += gridDim.x * ANNP_WAVES_PER_BLOCK) {
+        fe_force_atom<NP, NT, VIRIAL, false>(q, uniform(p.ovf_list[k]), lane, wbase);
+        wave_lds_sync();
     }
 }
 

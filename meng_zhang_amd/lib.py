@@ -8,7 +8,7 @@ _LIB = None
 # symbols include/annp_hip.h declares
 ABI_SYMBOLS = [
     "annp_hip_init", "annp_hip_compute", "annp_hip_compute_n", "annp_hip_compute_device",
-    "annp_hip_neigh_build_device", "annp_hip_sync", "annp_hip_set_timing", "annp_hip_last_timing",
+    "annp_hip_neigh_build_device", "annp_hip_sync", "annp_hip_eval_info", "annp_hip_set_timing", "annp_hip_last_timing",
     "annp_hip_timing_stats", "annp_hip_last_counts",
     "annp_hip_clear", "annp_hip_bytes", "annp_hip_last_error", "annp_hip_abi_version",
 ]
@@ -21,8 +21,7 @@ PAIR_SYMBOLS = [
 
 
 def library_path():
-    # ANNP_HIP_LIBRARY: developer switch for A/B-ing kernel variants (tools/build_variants.sh)
-    return os.environ.get("ANNP_HIP_LIBRARY") or os.path.join(_HERE, "libannp_hip.so")
+    return os.path.join(_HERE, "libannp_hip.so")
 
 
 def load_library():
@@ -47,6 +46,7 @@ def load_library():
     lib.annp_hip_clear.argtypes = [vp]
     lib.annp_hip_clear.restype = None
     lib.annp_hip_sync.argtypes = [vp]
+    lib.annp_hip_eval_info.argtypes = [vp, ip]
     lib.annp_hip_set_timing.argtypes = [vp, C.c_int]
     lib.annp_hip_last_timing.argtypes = [vp, dp]
     lib.annp_hip_timing_stats.argtypes = [vp, dp, ip]

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported(lib):
         assert getattr(lib, name) is not None, name
     from meng_zhang_amd.lib import ABI_SYMBOLS
     assert sorted(ABI_SYMBOLS) == declared
-    assert lib.annp_hip_abi_version() == 2      # 2: annp_hip_params grew the anna_adp fields
+    assert lib.annp_hip_abi_version() == 3      # 3: annp_hip_eval_info, per-element network images
 
 
 def test_pair_symbols_exported(lib):
