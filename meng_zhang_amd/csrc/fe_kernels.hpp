@@ -627,7 +627,8 @@ __global__ __launch_bounds__(256) void annp_fe_force_fixup(FeArgs p)
     unsigned char *wbase = lds_raw + (size_t)wave * fe_force_lds_per_wave(p.n_cap, false);
     FeArgs q = p;
     q.ovf_list = nullptr; q.ovf_cap = 0;          // nothing behind this launch: a second overflow is an error
-    for (int k = blockIdx.x * ANNP_WAVES_PER_BLOCK + wave; k < count; k += gridDim.x * ANNP_WAVES_PER_BLOCK) {
+    const int wpb = blockDim.x >> 6;              // launched with one wave per workgroup: the whole LDS for one list row
+    for (int k = blockIdx.x * wpb + wave; k < count; k += gridDim.x * wpb) {
         fe_force_atom<NP, NT, VIRIAL, false>(q, uniform(p.ovf_list[k]), lane, wbase);
         wave_lds_sync();
     }

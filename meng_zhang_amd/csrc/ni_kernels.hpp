@@ -613,7 +613,9 @@ __global__ __launch_bounds__(256, NI_WAVES_PER_SIMD) void annp_ni_desc(NiArgs p)
     int nl;
     const int nmax = ni_stage<false>(p, ii0, L, T, lane, nl);
     const int ncl = __shfl(nl, NI_GL * (lane & (NI_GA - 1)), 64);     // count of atom (lane & 3), for lanes 0..3
-    if (p.ncount && lane < NI_GA && ii0 + lane < p.inum) p.ncount[ii0 + lane] = min(ncl, cap);
+    // a group whose records overflowed is skipped by both passes: its count is left at 0 so that the force pass, which
+    // runs without the host having looked at the error word, finds nothing to do for it (its list rows are not written)
+    if (p.ncount && lane < NI_GA && ii0 + lane < p.inum) p.ncount[ii0 + lane] = nmax > cap ? 0 : ncl;
     if (nmax > cap) {
         if (lane == 0) atomicMax(p.errflag, nmax);
         for (int idx = lane; idx < NI_GA * ANNP_GPAD; idx += 64)
