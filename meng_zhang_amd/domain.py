@@ -1,178 +1,336 @@
 """Spatial decomposition of one periodic box over the GPUs of a node.
 
-What LAMMPS core does around ``Pair::compute`` for the reference (``processors N 1 1``
-+ ``Comm::forward_comm`` / ``reverse_comm`` with ``newton on``),
-restated for one process per GPU with ``torch.distributed`` (backend ``nccl`` = RCCL over
-xGMI on ROCm, ``gloo`` on CPU in the tests):
+What LAMMPS core does around ``Pair::compute`` for the reference (``processors N 1 1``;
+``Comm::exchange`` + ``Comm::borders`` at every reneighbouring, ``Comm::forward_comm`` /
+``reverse_comm`` with ``newton on`` every step), restated for one process
+per GPU with ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on ROCm, ``gloo`` on CPU
+in the tests):
 
-* the box is cut into ``world`` slabs along x; a rank owns the atoms whose home
-  coordinate falls into its slab and carries *ghost* copies of every atom image that
-  lies within ``rc_halo`` of the slab (periodic images in y and z, neighbours' atoms
-  and periodic images in x);
-* ``forward()``  -- owners send current positions, ghosts receive them (+ image shift);
-* ``reverse()``  -- ghosts send the forces they accumulated back, owners add them.
+* the box is cut into ``world`` slabs along x; a rank owns the atoms inside its slab and
+  carries *ghost* copies of every atom image within ``rc_halo`` (= list cutoff) of it;
+* ``replan()``   -- at every neighbour-list rebuild: atoms are wrapped into the box, atoms that
+  left the slab migrate to the neighbouring rank (``exchange``), and the ghost lists are
+  re-derived from the current positions (``borders``): first across the two slab faces over
+  the wire (counts first, then the atoms), then the periodic images in y and z of everything
+  held so far as local copies -- so edges and corners come out right without diagonal messages;
+* ``forward()``  -- owners' current positions -> ghosts (+ image shift);
+* ``reverse()``  -- forces accumulated on ghosts -> owners.
 
-Both directions are one group of point-to-point sends/receives between slab
-neighbours (``batch_isend_irecv`` = ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd):
-xGMI is point-to-point, a slab has two neighbours, so each exchange uses two links
-and moves only the boundary atoms.  No collective touches the data path; only the
-scalar energy (and virial) is all-reduced.
+Both per-step directions are one group of point-to-point sends/receives between slab
+neighbours (``batch_isend_irecv`` = ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd): xGMI is
+point-to-point, a slab has two neighbours, so an exchange uses two links and moves only the
+boundary atoms, received straight into the ghost rows of ``x``.  No collective touches the
+data path; collectives carry a handful of integers at a replan (message sizes) and scalars
+(energy, largest displacement).  Nothing in the per-step path waits on the host.
 
-The plan (who sends what to whom) is computed once from the initial configuration,
-identically on every rank, so no communication is needed to set it up.  Arithmetic is
-not done here: the force engine is passed in (the HIP library in the product; the
-tests may pass any callable with the same signature to check the decomposition).
+Arithmetic is not done here: the force engine is passed the arrays (the HIP library in the
+product; the tests pass the CPU oracle to check the decomposition itself).
 """
 import numpy as np
 
-_SHIFTS = [(sx, sy, sz) for sx in (-1, 0, 1) for sy in (-1, 0, 1) for sz in (-1, 0, 1)]
+
+class NoTransport:
+    """single rank: no peers"""
+    world, rank = 1, 0
+
+    def route(self, msgs):
+        assert not msgs
+
+    def allgather(self, t):
+        return t.reshape(1, -1).cpu()
+
+    def allreduce_max(self, v):
+        return float(v)
+
+    def allreduce_sum_(self, t):
+        return t
 
 
-def slab_of(x_home, box, world):
-    """Rank that owns each atom: equal-width slabs along x."""
-    lx = box[3] - box[0]
-    r = np.floor((x_home[:, 0] - box[0]) / lx * world).astype(np.int64)
-    return np.clip(r, 0, world - 1)
+class TorchTransport:
+    """torch.distributed (nccl = RCCL on the GPUs, gloo on CPU)"""
 
+    def __init__(self, dist):
+        self.dist = dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
 
-def _halo_block(x_src, box, periodic, rc, lo, hi, owner_is_self):
-    """Images of x_src (atoms of one owner rank) that fall into the halo of the slab
-    [lo, hi) x box_y x box_z, in (shift, local index) order.
-    Returns (local indices, shift vectors)."""
-    L = np.array([box[3] - box[0], box[4] - box[1], box[5] - box[2]])
-    idx_all, sh_all = [], []
-    for s in _SHIFTS:
-        if any(s[d] != 0 and not periodic[d] for d in range(3)):
-            continue
-        if owner_is_self and s == (0, 0, 0):
-            continue
-        p = x_src + np.array(s, dtype=np.float64) * L
-        m = (p[:, 0] >= lo - rc) & (p[:, 0] < hi + rc)
-        m &= (p[:, 1] >= box[1] - rc) & (p[:, 1] < box[4] + rc)
-        m &= (p[:, 2] >= box[2] - rc) & (p[:, 2] < box[5] + rc)
-        if not owner_is_self and s == (0, 0, 0):
-            pass    # another rank's atoms inside my halo region
-        # an image that lies inside my own slab (possible only for s != 0 of far atoms) is a real ghost too
-        ids = np.nonzero(m)[0]
-        if ids.size:
-            idx_all.append(ids)
-            sh_all.append(np.tile(np.array(s, dtype=np.float64) * L, (ids.size, 1)))
-    if not idx_all:
-        return np.zeros(0, dtype=np.int64), np.zeros((0, 3))
-    return np.concatenate(idx_all), np.vstack(sh_all)
+    def route(self, msgs):
+        """msgs: list of ('send' | 'recv', tensor, peer); one ncclGroup of point-to-point transfers"""
+        d = self.dist
+        ops = [d.P2POp(d.isend if kind == "send" else d.irecv, t, peer) for kind, t, peer in msgs]
+        for r in (d.batch_isend_irecv(ops) if ops else []):
+            r.wait()
 
+    def allgather(self, t):
+        out = [t.new_empty(t.shape) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return self.dist_stack(out)
 
-class HaloPlan:
-    """Ownership and exchange lists for one rank (pure numpy; same on CPU and GPU runs)."""
-
-    def __init__(self, x_global, box, periodic, rc_halo, world, rank):
-        box = np.asarray(box, dtype=np.float64)
-        self.world, self.rank, self.box, self.rc = world, rank, box, rc_halo
-        owner = slab_of(x_global, box, world)
-        lx = box[3] - box[0]
-        if lx / world < rc_halo and world > 1:
-            raise ValueError("slab thinner than the halo: %g < %g" % (lx / world, rc_halo))
-        self.own_ids = [np.nonzero(owner == r)[0] for r in range(world)]       # global ids per rank, local order
-        self.nlocal = int(self.own_ids[rank].size)
-
-        def slab(r):
-            return box[0] + lx * r / world, box[0] + lx * (r + 1) / world
-
-        # ghosts of THIS rank, grouped by owner rank q
-        lo, hi = slab(rank)
-        self.recv_counts = np.zeros(world, dtype=np.int64)
-        g_local, g_shift, g_owner = [], [], []
-        for q in range(world):
-            idx, sh = _halo_block(x_global[self.own_ids[q]], box, periodic, rc_halo, lo, hi, q == rank)
-            self.recv_counts[q] = idx.size
-            g_local.append(idx); g_shift.append(sh); g_owner.append(np.full(idx.size, q, dtype=np.int64))
-        self.ghost_owner = np.concatenate(g_owner)
-        self.ghost_owner_local = np.concatenate(g_local)       # index in the owner's local order
-        self.ghost_shift = np.vstack(g_shift)
-        self.nghost = int(self.ghost_owner.size)
-        self.nall = self.nlocal + self.nghost
-        # what THIS rank sends to every other rank r (= r's ghost block owned by me), in r's order
-        self.send_idx = []
-        for r in range(world):
-            if r == rank:
-                self.send_idx.append(self.ghost_owner_local[self.ghost_owner == rank])
-                continue
-            lo_r, hi_r = slab(r)
-            idx, _ = _halo_block(x_global[self.own_ids[rank]], box, periodic, rc_halo, lo_r, hi_r, False)
-            self.send_idx.append(idx)
-        self.send_counts = np.array([s.size for s in self.send_idx], dtype=np.int64)
-        self.recv_offsets = np.concatenate([[0], np.cumsum(self.recv_counts)])
-
-    def local_positions(self, x_global):
-        """[owned | ghosts] positions for this rank from a global configuration."""
-        xo = x_global[self.own_ids[self.rank]]
-        xg = np.empty((self.nghost, 3))
-        for q in range(self.world):
-            a, b = self.recv_offsets[q], self.recv_offsets[q + 1]
-            xg[a:b] = x_global[self.own_ids[q]][self.ghost_owner_local[a:b]] + self.ghost_shift[a:b]
-        return np.vstack([xo, xg])
-
-
-class Domain:
-    """Device (or CPU) state of one rank + the two halo exchanges."""
-
-    def __init__(self, plan, x_global, device, dist=None):
+    @staticmethod
+    def dist_stack(ts):
         import torch
-        self.torch, self.dist, self.plan, self.device = torch, dist, plan, device
-        p = plan
-        self.x = torch.from_numpy(p.local_positions(x_global)).to(device).contiguous()
+        return torch.stack(ts).cpu()
+
+    def allreduce_max(self, v):
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX)
+        return float(v)
+
+    def allreduce_sum_(self, t):
+        self.dist.all_reduce(t)
+        return t
+
+
+def slab_bounds(box, world, rank):
+    lx = box[3] - box[0]
+    return box[0] + lx * rank / world, box[0] + lx * (rank + 1) / world
+
+
+class SlabDomain:
+    """Atoms of one rank: ``x`` / ``f`` are ``[nall, 3]`` tensors, owned atoms first, then the ghosts received from
+    the slab neighbours, then the local periodic images.  ``ids`` (global atom id) and every tensor in ``extra``
+    (e.g. velocities) belong to the owned atoms and migrate with them."""
+
+    def __init__(self, box, periodic, rc_halo, device, transport=None, x_own=None, ids=None, extra=None):
+        import torch
+        self.torch = torch
+        self.tp = transport if transport is not None else NoTransport()
+        self.world, self.rank = self.tp.world, self.tp.rank
+        self.box = np.asarray(box, dtype=np.float64)
+        self.periodic = tuple(bool(p) for p in periodic)
+        self.rc = float(rc_halo)
+        self.device = device
+        L = self.box[3:] - self.box[:3]
+        if self.world > 1 and L[0] / self.world < self.rc:
+            raise ValueError("slab thinner than the halo: %g < %g" % (L[0] / self.world, self.rc))
+        self.lo, self.hi = slab_bounds(self.box, self.world, self.rank)
+        w = self.world
+        self.left = (self.rank - 1) % w if (self.rank > 0 or self.periodic[0]) else None
+        self.right = (self.rank + 1) % w if (self.rank < w - 1 or self.periodic[0]) else None
+        if w == 1:
+            self.left = self.right = None
+        x_own = torch.as_tensor(x_own, dtype=torch.float64, device=device).reshape(-1, 3).contiguous()
+        self.nlocal = int(x_own.shape[0])
+        self.x = x_own.clone()
         self.f = torch.zeros_like(self.x)
-        self.shift = torch.from_numpy(p.ghost_shift).to(device)
-        self.send_idx = [torch.from_numpy(s.astype(np.int64)).to(device) for s in p.send_idx]
-        self.peers = [q for q in range(p.world) if q != p.rank and (p.send_counts[q] or p.recv_counts[q])]
-        # staging buffers (contiguous per peer)
-        self.sbuf = {q: torch.empty((int(p.send_counts[q]), 3), dtype=torch.float64, device=device) for q in self.peers}
-        self.rbuf = {q: torch.empty((int(p.recv_counts[q]), 3), dtype=torch.float64, device=device) for q in self.peers}
-        self.bytes_per_exchange = sum(int(p.send_counts[q]) for q in self.peers) * 24
+        self.ids = (torch.arange(self.nlocal, dtype=torch.int64, device=device) if ids is None
+                    else torch.as_tensor(ids, dtype=torch.int64, device=device).clone())
+        self.extra = {k: torch.as_tensor(v, dtype=torch.float64, device=device).reshape(self.nlocal, -1).clone()
+                      for k, v in (extra or {}).items()}
+        self.nghost = self.nall = 0
+        self.n_replans = 0
+        self.migrated_last = 0
+        self.replan()
 
-    # ---- Comm::forward_comm: positions owners -> ghosts
-    def forward(self):
-        t, p = self.torch, self.plan
-        n = p.nlocal
+    @classmethod
+    def from_global(cls, x_global, box, periodic, rc_halo, device, transport=None, extra=None):
+        """Every rank holds the same global configuration (synthetic inputs) and keeps the atoms of its slab."""
+        tp = transport if transport is not None else NoTransport()
+        box = np.asarray(box, dtype=np.float64)
+        L = box[3:] - box[:3]
+        xw = np.array(x_global, dtype=np.float64, copy=True)
+        for d in range(3):
+            if periodic[d]:
+                xw[:, d] -= np.floor((xw[:, d] - box[d]) / L[d]) * L[d]
+        owner = np.clip(np.floor((xw[:, 0] - box[0]) / L[0] * tp.world).astype(np.int64), 0, tp.world - 1)
+        mine = np.nonzero(owner == tp.rank)[0]
+        ex = {k: np.asarray(v)[mine] for k, v in (extra or {}).items()}
+        return cls(box, periodic, rc_halo, device, tp, x_global[mine], mine, ex)
+
+    # ------------------------------------------------------------------ wire helpers
+    def _route(self, send, n_l, n_r, recv, m_r, m_l):
+        """send rows [to-left | to-right] -> neighbours; recv rows [from-right | from-left] <- neighbours.
+        With two ranks both faces meet the same peer: one message each way carries both parts."""
+        msgs = []
+        if self.left is not None and self.left == self.right:
+            if n_l + n_r:
+                msgs.append(("send", send[: n_l + n_r], self.left))
+            if m_r + m_l:
+                msgs.append(("recv", recv[: m_r + m_l], self.left))
+        else:
+            if self.left is not None and n_l:
+                msgs.append(("send", send[:n_l], self.left))
+            if self.right is not None and n_r:
+                msgs.append(("send", send[n_l:n_l + n_r], self.right))
+            if self.right is not None and m_r:
+                msgs.append(("recv", recv[:m_r], self.right))
+            if self.left is not None and m_l:
+                msgs.append(("recv", recv[m_r:m_r + m_l], self.left))
+        return msgs
+
+    def _route_back(self, ghost_rows, m_r, m_l, back, n_l, n_r):
+        """the mirror image: rows [from-right | from-left] go back where they came from, arriving as [to-left | to-right]"""
+        msgs = []
+        if self.left is not None and self.left == self.right:
+            if m_r + m_l:
+                msgs.append(("send", ghost_rows[: m_r + m_l], self.left))
+            if n_l + n_r:
+                msgs.append(("recv", back[: n_l + n_r], self.left))
+        else:
+            if self.right is not None and m_r:
+                msgs.append(("send", ghost_rows[:m_r], self.right))
+            if self.left is not None and m_l:
+                msgs.append(("send", ghost_rows[m_r:m_r + m_l], self.left))
+            if self.left is not None and n_l:
+                msgs.append(("recv", back[:n_l], self.left))
+            if self.right is not None and n_r:
+                msgs.append(("recv", back[n_l:n_l + n_r], self.right))
+        return msgs
+
+    def _peer_counts(self, n_l, n_r):
+        """what my neighbours will send me, given what everyone sends: (from right = its to-left, from left = its to-right)"""
+        t = self.torch
+        mine = t.tensor([n_l, n_r], dtype=t.int64, device=self.device)
+        allc = self.tp.allgather(mine).numpy().reshape(self.world, 2)
+        m_r = int(allc[self.right][0]) if self.right is not None else 0
+        m_l = int(allc[self.left][1]) if self.left is not None else 0
+        return m_r, m_l
+
+    # ------------------------------------------------------------------ Comm::exchange
+    def _exchange(self):
+        t = self.torch
+        n = self.nlocal
+        x = self.x[:n]
+        L = self.box[3:] - self.box[:3]
+        for d in range(3):
+            if self.periodic[d]:
+                x[:, d] -= t.floor((x[:, d] - self.box[d]) / L[d]) * L[d]
+        self.migrated_last = 0
+        if self.world == 1:
+            return
+        dest = t.clamp(t.floor((x[:, 0] - self.box[0]) / L[0] * self.world).to(t.int64), 0, self.world - 1)
+        rel = (dest - self.rank) % self.world
+        stay = t.nonzero(rel == 0).flatten()
+        go_r = t.nonzero(rel == 1).flatten() if self.right is not None else stay[:0]
+        go_l = t.nonzero(rel == self.world - 1).flatten() if (self.left is not None and self.world > 2) else stay[:0]
+        if int(stay.numel() + go_r.numel() + go_l.numel()) != n:
+            raise RuntimeError("an atom moved further than the neighbouring slab between two rebuilds")
+        cols = [x, self.ids.to(t.float64).reshape(n, 1)] + [self.extra[k] for k in sorted(self.extra)]
+        pay = t.cat(cols, dim=1)
+        width = pay.shape[1]
+        n_l, n_r = int(go_l.numel()), int(go_r.numel())
+        m_r, m_l = self._peer_counts(n_l, n_r)
+        send = pay[t.cat([go_l, go_r])].contiguous()
+        recv = pay.new_empty((m_r + m_l, width))
+        self.tp.route(self._route(send, n_l, n_r, recv, m_r, m_l))
+        new = t.cat([pay[stay], recv], dim=0)
+        self.migrated_last = n_l + n_r
+        self.nlocal = int(new.shape[0])
+        self._own_x = new[:, :3].contiguous()
+        self.ids = new[:, 3].round().to(t.int64)
+        c = 4
+        for k in sorted(self.extra):
+            wk = self.extra[k].shape[1]
+            self.extra[k] = new[:, c:c + wk].contiguous()
+            c += wk
+        self.x = self._own_x
+
+    # ------------------------------------------------------------------ Comm::borders
+    def _borders(self):
+        t = self.torch
+        dev = self.device
+        n = self.nlocal
         xo = self.x[:n]
-        ops = []
-        for q in self.peers:
-            if p.send_counts[q]:
-                t.index_select(xo, 0, self.send_idx[q], out=self.sbuf[q])
-                ops.append(self.dist.P2POp(self.dist.isend, self.sbuf[q], q))
-            if p.recv_counts[q]:
-                ops.append(self.dist.P2POp(self.dist.irecv, self.rbuf[q], q))
-        reqs = self.dist.batch_isend_irecv(ops) if ops else []
-        # images of my own atoms need no wire
-        a, b = int(p.recv_offsets[p.rank]), int(p.recv_offsets[p.rank + 1])
-        if b > a:
-            self.x[n + a:n + b] = xo.index_select(0, self.send_idx[p.rank]) + self.shift[a:b]
-        for r in reqs:
-            r.wait()
-        for q in self.peers:
-            a, b = int(p.recv_offsets[q]), int(p.recv_offsets[q + 1])
-            if b > a:
-                self.x[n + a:n + b] = self.rbuf[q] + self.shift[a:b]
+        L = self.box[3:] - self.box[:3]
+        # (1) across the slab faces
+        if self.world > 1:
+            sel_l = t.nonzero(xo[:, 0] < self.lo + self.rc).flatten() if self.left is not None else t.zeros(0, dtype=t.int64, device=dev)
+            sel_r = t.nonzero(xo[:, 0] >= self.hi - self.rc).flatten() if self.right is not None else t.zeros(0, dtype=t.int64, device=dev)
+            n_l, n_r = int(sel_l.numel()), int(sel_r.numel())
+            m_r, m_l = self._peer_counts(n_l, n_r)
+            self.send_idx = t.cat([sel_l, sel_r])
+            sh = t.zeros((n_l + n_r, 3), dtype=t.float64, device=dev)
+            if self.rank == 0:                       # my left neighbour sits at the far end of the box
+                sh[:n_l, 0] = L[0]
+            if self.rank == self.world - 1:
+                sh[n_l:, 0] = -L[0]
+            self.send_shift = sh
+        else:
+            n_l = n_r = m_r = m_l = 0
+            self.send_idx = t.zeros(0, dtype=t.int64, device=dev)
+            self.send_shift = t.zeros((0, 3), dtype=t.float64, device=dev)
+        self.n_l, self.n_r, self.m_r, self.m_l = n_l, n_r, m_r, m_l
+        nxg = m_r + m_l
+        prim = t.empty((n + nxg, 3), dtype=t.float64, device=dev)
+        prim[:n] = xo
+        self.sendbuf = t.empty((n_l + n_r, 3), dtype=t.float64, device=dev)
+        if self.world > 1:
+            t.index_select(xo, 0, self.send_idx, out=self.sendbuf)
+            self.sendbuf += self.send_shift
+            self.tp.route(self._route(self.sendbuf, n_l, n_r, prim[n:], m_r, m_l))
+        # (2) periodic images, one dimension after the other, of everything held so far
+        root = t.arange(n + nxg, dtype=t.int64, device=dev)
+        shift = t.zeros((n + nxg, 3), dtype=t.float64, device=dev)
+        pos = prim
+        dims = (0, 1, 2) if self.world == 1 else (1, 2)
+        for d in dims:
+            if not self.periodic[d]:
+                continue
+            new_root, new_shift, new_pos = [], [], []
+            for mask, s in ((pos[:, d] < self.box[d] + self.rc, L[d]), (pos[:, d] >= self.box[3 + d] - self.rc, -L[d])):
+                idx = t.nonzero(mask).flatten()
+                if idx.numel() == 0:
+                    continue
+                sv = shift[idx].clone()
+                sv[:, d] += s
+                pv = pos[idx].clone()
+                pv[:, d] += s
+                new_root.append(root[idx]); new_shift.append(sv); new_pos.append(pv)
+            if new_root:
+                root = t.cat([root] + new_root)
+                shift = t.cat([shift] + new_shift)
+                pos = t.cat([pos] + new_pos)
+        np0 = n + nxg
+        self.img_root = root[np0:].contiguous()
+        self.img_shift = shift[np0:].contiguous()
+        self.nxg = nxg
+        self.nimg = int(self.img_root.numel())
+        self.nghost = nxg + self.nimg
+        self.nall = n + self.nghost
+        self.x = pos.contiguous()                    # [owned | wire ghosts | images], already current
+        self.f = t.zeros_like(self.x)
+        self.backbuf = t.empty((n_l + n_r, 3), dtype=t.float64, device=dev)
+        self.x_plan = self.x[:n].clone()
+        # message lists of the per-step exchanges (tensors are views into x / f: valid until the next replan)
+        self._fwd = self._route(self.sendbuf, n_l, n_r, self.x[n:n + nxg], m_r, m_l)
+        self._rev = self._route_back(self.f[n:n + nxg], m_r, m_l, self.backbuf, n_l, n_r)
+        self.bytes_per_exchange = (n_l + n_r) * 24
 
-    # ---- Comm::reverse_comm: ghost forces -> owners (newton_pair on, fe_v2/src/pair_annp.cpp:199)
+    def replan(self):
+        """Comm::exchange + Comm::borders: call whenever the neighbour list is rebuilt."""
+        self._exchange()
+        self._borders()
+        self.n_replans += 1
+
+    # ------------------------------------------------------------------ per step
+    def forward(self):
+        """Comm::forward_comm: positions owners -> ghosts"""
+        t = self.torch
+        n = self.nlocal
+        if self._fwd:
+            t.index_select(self.x[:n], 0, self.send_idx, out=self.sendbuf)
+            self.sendbuf += self.send_shift
+            self.tp.route(self._fwd)
+        if self.nimg:
+            np0 = n + self.nxg
+            t.index_select(self.x[:np0], 0, self.img_root, out=self.x[np0:])      # roots are owned atoms or wire ghosts
+            self.x[np0:] += self.img_shift
+
     def reverse(self):
-        p = self.plan
-        n = p.nlocal
-        ops = []
-        for q in self.peers:
-            a, b = int(p.recv_offsets[q]), int(p.recv_offsets[q + 1])
-            if b > a:     # what I received positions for, I return forces for
-                self.rbuf[q].copy_(self.f[n + a:n + b])
-                ops.append(self.dist.P2POp(self.dist.isend, self.rbuf[q], q))
-            if p.send_counts[q]:
-                ops.append(self.dist.P2POp(self.dist.irecv, self.sbuf[q], q))
-        reqs = self.dist.batch_isend_irecv(ops) if ops else []
-        fo = self.f[:n]
-        a, b = int(p.recv_offsets[p.rank]), int(p.recv_offsets[p.rank + 1])
-        if b > a:
-            fo.index_add_(0, self.send_idx[p.rank], self.f[n + a:n + b])
-        for r in reqs:
-            r.wait()
-        for q in self.peers:
-            if p.send_counts[q]:
-                fo.index_add_(0, self.send_idx[q], self.sbuf[q])
+        """Comm::reverse_comm: ghost forces -> owners (newton_pair on, fe_v2/src/pair_annp.cpp:199)"""
+        n = self.nlocal
+        if self.nimg:       # images first: their roots may be wire ghosts, whose total then travels
+            self.f[: n + self.nxg].index_add_(0, self.img_root, self.f[n + self.nxg:])
+        if self._rev:
+            self.tp.route(self._rev)
+            self.f.index_add_(0, self.send_idx, self.backbuf)
+
+    def max_displacement(self):
+        """largest distance an owned atom has moved since the last replan, over all ranks
+        (LAMMPS `neigh_modify check yes`: rebuild when it exceeds half the skin)"""
+        t = self.torch
+        d2 = ((self.x[: self.nlocal] - self.x_plan) ** 2).sum(1).max() if self.nlocal else t.zeros((), dtype=t.float64, device=self.device)
+        return float(np.sqrt(self.tp.allreduce_max(d2.reshape(1).clone())))
+
+    # ------------------------------------------------------------------ helpers for drivers / tests
+    def gather_owned(self, values):
+        """(ids, rows) of a per-owned-atom tensor as numpy, for assembling global arrays in tests"""
+        return self.ids.cpu().numpy(), values[: self.nlocal].detach().cpu().numpy()

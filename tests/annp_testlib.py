@@ -335,3 +335,71 @@ def write_ann(path, npsf=9, ntsf=19, nnod=10, ntl=4, acts=("tanh", "tanh", "line
     with open(path, "w", newline="") as fh:
         fh.write("\r\n".join(L) + "\r\n")
     return path
+
+
+# ---------------------------------------------------------------- in-process ranks (tests of the decomposition)
+class ThreadFabric:
+    """Wires `world` ranks that run as threads of one process: FIFO mailboxes per (source, destination) pair and a
+    barrier for the small collectives.  Same surface as meng_zhang_amd.domain.TorchTransport."""
+
+    def __init__(self, world):
+        import queue
+        import threading
+        self.world = world
+        self.box = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def transport(self, rank):
+        return ThreadTransport(self, rank)
+
+    def run(self, fn):
+        """fn(rank, transport) on every rank, each in its own thread; returns the list of results, re-raises the first error"""
+        import threading
+        out, err = [None] * self.world, []
+
+        def body(r):
+            try:
+                out[r] = fn(r, self.transport(r))
+            except BaseException as e:          # noqa: BLE001  (reported to the caller below)
+                err.append(e)
+                self.barrier.abort()
+        th = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+
+
+class ThreadTransport:
+    def __init__(self, fabric, rank):
+        self.fab, self.rank, self.world = fabric, rank, fabric.world
+
+    def route(self, msgs):
+        for kind, t, peer in msgs:
+            if kind == "send":
+                self.fab.box[(self.rank, peer)].put(t.detach().clone())
+        for kind, t, peer in msgs:
+            if kind == "recv":
+                t.copy_(self.fab.box[(peer, self.rank)].get(timeout=120))
+
+    def _collect(self, t):
+        import torch
+        self.fab.slots[self.rank] = t.detach().clone()
+        self.fab.barrier.wait(timeout=120)
+        out = torch.stack([s.to(t.device) for s in self.fab.slots])
+        self.fab.barrier.wait(timeout=120)
+        return out
+
+    def allgather(self, t):
+        return self._collect(t).cpu()
+
+    def allreduce_max(self, v):
+        return float(self._collect(v).max())
+
+    def allreduce_sum_(self, t):
+        t.copy_(self._collect(t).sum(0))
+        return t

@@ -1,19 +1,19 @@
 """Spatial decomposition + halo exchange (meng_zhang_amd/domain.py) on CPU.
 
-The decomposition must not change the physics: forces of a box cut into slabs, after
-the reverse halo exchange, equal the single-domain forces.  Here the force engine is the
-CPU oracle (test infrastructure) so the N>1 path is covered without a GPU:
-world_size 2 over gloo, plus a single-process check of the plan for 1, 2, 3 ranks.
+The decomposition must not change the physics: forces of a box cut into slabs, after the reverse halo exchange,
+equal the single-domain forces -- also after atoms have drifted across slab faces and box boundaries and the plan
+has been re-derived (Comm::exchange + Comm::borders).  The force engine here is the CPU oracle (test infrastructure),
+so the N > 1 path is covered without a GPU: ranks as threads of one process for 1..8 slabs, and one process per rank
+over gloo for world_size 2 and 3.
 """
 import os
 import socket
-import sys
 
 import numpy as np
 import pytest
 
-from annp_testlib import (A_FE, FAST, FE_POT, KIND_FE, System, _dp, _ip, _lp, bcc, oracle_compute, oracle_lib, perturb,
-                          read_pot)
+from annp_testlib import (A_FE, FAST, FE_POT, KIND_FE, System, ThreadFabric, _dp, _ip, _lp, bcc, oracle_compute, oracle_lib,
+                          perturb, read_pot, uniform_counter)
 
 RC_LIST = 8.5
 
@@ -45,34 +45,86 @@ def reference_forces(xg, box):
     return r["f"], r["energy"]
 
 
+def oracle_step(dom, pot, nthreads=0):
+    """one force evaluation on a rank's atoms with the CPU oracle + reverse halo; returns the rank's energy"""
+    import torch
+    s = local_system(dom.x.cpu().numpy(), dom.nlocal)
+    out = oracle_compute(pot, s, KIND_FE, FAST, nthreads=nthreads)
+    dom.f.copy_(torch.from_numpy(out["f_all"]))
+    dom.reverse()
+    return out["energy"]
+
+
+def drift(xg, box, seed, amp):
+    """move every atom by up to +-amp in each direction (far beyond half the skin for amp ~ 1.5 A), no wrapping:
+    atoms end up outside their slab and outside the box"""
+    u = uniform_counter(xg.size, seed).reshape(xg.shape)
+    return xg + (2.0 * u - 1.0) * amp
+
+
+def cells_x(world):
+    return {1: 8, 2: 8, 3: 10, 4: 12, 8: 24}[world]
+
+
+def test_single_rank_ghosts_match_the_harness():
+    """world = 1: the periodic images (x, then y of everything so far, then z) are exactly the ghost shell the
+    LAMMPS-like harness builds, and forward() keeps them attached to their owners"""
+    import torch
+    from meng_zhang_amd.domain import SlabDomain
+    x0, box = bcc(6, 5, 4, A_FE)
+    xg = perturb(x0, 7, 0.05)
+    xg -= np.floor((xg - box[:3]) / (box[3:] - box[:3])) * (box[3:] - box[:3])      # inside the box, as after Comm::exchange
+    dom = SlabDomain.from_global(xg, box, (1, 1, 1), RC_LIST, torch.device("cpu"))
+    s = System(xg, box)
+    assert dom.nlocal == xg.shape[0] and dom.nghost == s.nghost
+    key = lambda a: np.lexsort(np.round(a, 9).T)           # noqa: E731
+    g_dom, g_ref = dom.x[dom.nlocal:].numpy(), s.x[s.nlocal:]
+    assert np.abs(g_dom[key(g_dom)] - g_ref[key(g_ref)]).max() < 1e-12
+    dom.x[: dom.nlocal] += 0.01
+    dom.forward()
+    g2 = dom.x[dom.nlocal:].numpy()
+    assert np.abs(g2[key(g_dom)] - 0.01 - g_ref[key(g_ref)]).max() < 1e-12
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
-def test_plan_reproduces_single_domain(world):
-    """All ranks emulated in one process: ghosts of every rank + owner-side force return.  (8 slabs of 3 cells are
-    8.57 A thick: just above the 8.5 A list cutoff, the thinnest a one-neighbour halo allows.)"""
-    from meng_zhang_amd.domain import HaloPlan
-    x0, box = bcc({1: 8, 2: 8, 3: 10, 4: 12, 8: 24}[world], 3, 3, A_FE)
+def test_slabs_reproduce_single_domain(world):
+    """Ranks as threads: ghosts of every rank over the (in-process) wire + owner-side force return.  (8 slabs of 3
+    cells are 8.57 A thick: just above the 8.5 A list cutoff, the thinnest a one-neighbour halo allows.)  Then every
+    atom drifts by up to 1.2 A per direction -- across slab faces and out of the box -- and the plan is re-derived."""
+    import torch
+    from meng_zhang_amd.domain import SlabDomain
+    x0, box = bcc(cells_x(world), 3, 3, A_FE)
     xg = perturb(x0, 4242, 0.05)
+    xd = drift(xg, box, 99, 1.2)
     f_ref, e_ref = reference_forces(xg, box)
+    f_ref2, e_ref2 = reference_forces(xd, box)
     pot = read_pot(FE_POT)
-    plans = [HaloPlan(x0, box, (1, 1, 1), RC_LIST, world, r) for r in range(world)]
-    assert sum(p.nlocal for p in plans) == xg.shape[0]
-    f = np.zeros_like(xg)
-    e = 0.0
-    for r, p in enumerate(plans):
-        # what rank r would send must be exactly what its peers expect
-        for q, pq in enumerate(plans):
-            assert p.send_counts[q] == pq.recv_counts[r]
-        xl = p.local_positions(xg)
-        s = local_system(xl, p.nlocal)
-        out = oracle_compute(pot, s, KIND_FE, FAST)
-        e += out["energy"]
-        fl = out["f_all"]
-        np.add.at(f, p.own_ids[r], fl[: p.nlocal])
-        # reverse comm: ghost forces to owners
-        np.add.at(f, np.concatenate([plans[q].own_ids[q][p.ghost_owner_local[p.ghost_owner == q]] for q in range(world)])
-                  if p.nghost else np.zeros(0, dtype=np.int64), fl[p.nlocal:])
-    assert abs(e - e_ref) < 1e-8
-    assert np.abs(f - f_ref).max() < 1e-11
+
+    def rank_program(rank, tp):
+        dom = SlabDomain.from_global(x0, box, (1, 1, 1), RC_LIST, torch.device("cpu"), tp)
+        ids = dom.ids.numpy()
+        dom.x[: dom.nlocal] = torch.from_numpy(xg[ids])     # owned atoms move a little ...
+        dom.forward()                                       # ... their ghosts must follow
+        e1 = oracle_step(dom, pot, nthreads=1)
+        r1 = (ids.copy(), dom.f[: dom.nlocal].numpy().copy())
+        moved = dom.max_displacement()
+        # a big move, then exchange + borders
+        dom.x[: dom.nlocal] = torch.from_numpy(xd[ids])
+        assert dom.max_displacement() > 1.0
+        dom.replan()
+        e2 = oracle_step(dom, pot, nthreads=1)
+        return e1, r1, e2, dom.gather_owned(dom.f), dom.migrated_last, moved
+
+    res = ThreadFabric(world).run(rank_program)
+    f1, f2 = np.full_like(xg, np.nan), np.full_like(xg, np.nan)
+    for e1, (ids1, fl1), e2, (ids2, fl2), _, moved in res:
+        f1[ids1] = fl1
+        f2[ids2] = fl2
+        assert 0.0 < moved < 0.1
+    assert abs(sum(r[0] for r in res) - e_ref) < 1e-8 and np.abs(f1 - f_ref).max() < 1e-11
+    assert abs(sum(r[2] for r in res) - e_ref2) < 1e-7 and np.abs(f2 - f_ref2).max() < 1e-9 * max(1.0, np.abs(f_ref2).max())
+    if world > 1:
+        assert sum(r[4] for r in res) > 0           # atoms did change owner
 
 
 def _free_port():
@@ -83,10 +135,6 @@ def _free_port():
     return port
 
 
-def _cells_x(world):
-    return {2: 8, 3: 10, 4: 12}[world]
-
-
 def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
@@ -94,30 +142,33 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from meng_zhang_amd.domain import Domain, HaloPlan
-        x0, box = bcc(_cells_x(world), 3, 3, A_FE)
+        from meng_zhang_amd.domain import SlabDomain, TorchTransport
+        x0, box = bcc(cells_x(world), 3, 3, A_FE)
         xg = perturb(x0, 4242, 0.05)
-        plan = HaloPlan(x0, box, (1, 1, 1), RC_LIST, world, rank)
-        dom = Domain(plan, x0, torch.device("cpu"), dist)          # start from the ideal lattice ...
-        own = torch.from_numpy(xg[plan.own_ids[rank]])
-        dom.x[: plan.nlocal] = own                                 # ... move the owned atoms ...
-        dom.forward()                                              # ... ghosts must follow through the wire
-        assert np.abs(dom.x.numpy() - plan.local_positions(xg)).max() < 1e-12
-        s = local_system(dom.x.numpy(), plan.nlocal)
-        out = oracle_compute(read_pot(FE_POT), s, KIND_FE, FAST, nthreads=2)
-        dom.f.copy_(torch.from_numpy(out["f_all"]))
-        dom.reverse()
-        e = torch.tensor([out["energy"]], dtype=torch.float64)
-        dist.all_reduce(e)
-        q.put((rank, plan.own_ids[rank], dom.f[: plan.nlocal].numpy().copy(), float(e.item())))
+        xd = drift(xg, box, 99, 1.2)
+        vel = uniform_counter(xg.size, 5).reshape(xg.shape)
+        pot = read_pot(FE_POT)
+        dom = SlabDomain.from_global(x0, box, (1, 1, 1), RC_LIST, torch.device("cpu"), TorchTransport(dist), extra={"v": vel})
+        ids = dom.ids.numpy()
+        dom.x[: dom.nlocal] = torch.from_numpy(xg[ids])
+        dom.forward()
+        e1 = torch.tensor([oracle_step(dom, pot, nthreads=2)], dtype=torch.float64)
+        dist.all_reduce(e1)
+        r1 = (ids.copy(), dom.f[: dom.nlocal].numpy().copy())
+        dom.x[: dom.nlocal] = torch.from_numpy(xd[ids])
+        dom.replan()
+        assert np.array_equal(dom.extra["v"].numpy(), vel[dom.ids.numpy()])      # velocities travelled with their atoms
+        e2 = torch.tensor([oracle_step(dom, pot, nthreads=2)], dtype=torch.float64)
+        dist.all_reduce(e2)
+        q.put((rank, r1, float(e1.item()), dom.gather_owned(dom.f), float(e2.item()), dom.migrated_last))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_ranks_over_gloo(world):
-    """one process per rank, halo over the wire: with two ranks both slab faces meet the same peer, with three every
-    rank has two distinct peers (the general case of Domain.forward / reverse)"""
+    """one process per rank, halo over the wire: with two ranks both slab faces meet the same peer (one message
+    carries both parts), with three every rank has two distinct peers; atoms and their velocities migrate"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -129,11 +180,16 @@ def test_ranks_over_gloo(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    x0, box = bcc(_cells_x(world), 3, 3, A_FE)
+    x0, box = bcc(cells_x(world), 3, 3, A_FE)
     xg = perturb(x0, 4242, 0.05)
+    xd = drift(xg, box, 99, 1.2)
     f_ref, e_ref = reference_forces(xg, box)
-    f = np.zeros_like(xg)
-    for rank, ids, fl, e in res:
-        f[ids] = fl
-        assert abs(e - e_ref) < 1e-8
-    assert np.abs(f - f_ref).max() < 1e-11
+    f_ref2, e_ref2 = reference_forces(xd, box)
+    f1, f2 = np.full_like(xg, np.nan), np.full_like(xg, np.nan)
+    for rank, (ids1, fl1), e1, (ids2, fl2), e2, _ in res:
+        f1[ids1] = fl1
+        f2[ids2] = fl2
+        assert abs(e1 - e_ref) < 1e-8 and abs(e2 - e_ref2) < 1e-7
+    assert np.abs(f1 - f_ref).max() < 1e-11
+    assert np.abs(f2 - f_ref2).max() < 1e-9 * max(1.0, np.abs(f_ref2).max())
+    assert sum(r[5] for r in res) > 0

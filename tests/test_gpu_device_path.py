@@ -12,23 +12,14 @@ pytestmark = pytest.mark.gpu
 RC_LIST = 8.5
 
 
-class _NoDist:
-    P2POp = None
-
-    @staticmethod
-    def batch_isend_irecv(ops):
-        return []
-
-
 def device_eval(potfile, elem, x0, xg, box, want_virial=False):
     import torch
     from meng_zhang_amd import PairANNP
-    from meng_zhang_amd.domain import Domain, HaloPlan
+    from meng_zhang_amd.domain import SlabDomain
     from meng_zhang_amd.lib import load_library
     lib = load_library()
     dev = torch.device("cuda", 0)
-    plan = HaloPlan(x0, box, (1, 1, 1), RC_LIST, 1, 0)
-    dom = Domain(plan, x0, dev, _NoDist())
+    dom = plan = SlabDomain.from_global(x0, box, (1, 1, 1), RC_LIST, dev)
     dom.x[: plan.nlocal] = torch.from_numpy(xg).to(dev)      # owned atoms move ...
     dom.forward()                                            # ... their periodic images follow
     pair = PairANNP(1, device=0)
@@ -87,43 +78,54 @@ def test_ni_device_path_512k(ni_pot):
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_virtual_ranks_on_one_device(fe_pot, world):
-    """the slab decomposition run with N virtual ranks, one after the other, on one
-    device with the HIP path as the force engine; ghost forces returned to their owners must
-    reproduce the single-domain forces (order of summation aside)."""
+    """the slab decomposition with N ranks as threads of this process sharing the one device, each with
+    its own handle and the HIP path as the force engine, halo over the in-process wire; ghost forces returned to their
+    owners must reproduce the single-domain forces (order of summation aside) -- before and after atoms have drifted
+    across slab faces and the plan was re-derived (exchange + borders + device list rebuild)."""
     import torch
+    from annp_testlib import ThreadFabric, uniform_counter
     from meng_zhang_amd import PairANNP
-    from meng_zhang_amd.domain import HaloPlan
+    from meng_zhang_amd.domain import SlabDomain
     from meng_zhang_amd.lib import load_library
     lib = load_library()
     dev = torch.device("cuda", 0)
     x0, box = bcc(16, 5, 5, A_FE)                      # 45.7 A along x: slabs of 22.8 / 11.4 A >= 8.5 A halo
     xg = perturb(x0, 99, 0.05)
-    plans = [HaloPlan(x0, box, (1, 1, 1), RC_LIST, world, r) for r in range(world)]
-    pair = PairANNP(1, device=0)
-    pair.settings([])
-    pair.coeff(["*", "*", FE_POT, "Fe"])
-    pair.init_style()
-    h = pair.handle
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    f = np.zeros_like(xg)
-    etot = 0.0
-    for r, p in enumerate(plans):
-        x = torch.from_numpy(p.local_positions(xg)).to(dev).contiguous()
-        fl = torch.zeros_like(x)
-        eng = torch.zeros(1, dtype=torch.float64, device=dev)
-        pn, pf, pg, mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
-        assert lib.annp_hip_neigh_build_device(h, p.nlocal, p.nall, x.data_ptr(), RC_LIST, C.byref(pn), C.byref(pf),
-                                               C.byref(pg), C.byref(mx), stream) == 0
-        assert lib.annp_hip_compute_device(h, p.nlocal, p.nall, x.data_ptr(), None, None, pn, pf, pg, mx.value,
-                                           fl.data_ptr(), None, eng.data_ptr(), None, None, stream) == 0
-        assert lib.annp_hip_sync(h) == 0
-        fl = fl.cpu().numpy()
-        etot += float(eng.item())
-        np.add.at(f, p.own_ids[r], fl[: p.nlocal])
-        gid = np.concatenate([plans[q].own_ids[q][p.ghost_owner_local[p.ghost_owner == q]] for q in range(world)])
-        np.add.at(f, gid, fl[p.nlocal:])
-    pair.close()
-    s = System(xg, box)
-    o = oracle_compute(fe_pot, s, KIND_FE, FAST)
-    assert abs(etot - o["energy"]) < 1e-6 * s.nlocal
-    assert np.abs(f - o["f"]).max() < 1e-9
+    xd = xg + (2.0 * uniform_counter(xg.size, 17).reshape(xg.shape) - 1.0) * 0.9
+
+    def rank_program(rank, tp):
+        dom = SlabDomain.from_global(xg, box, (1, 1, 1), RC_LIST, dev, tp)
+        pair = PairANNP(1, device=0)
+        pair.settings([])
+        pair.coeff(["*", "*", FE_POT, "Fe"])
+        pair.init_style()
+        h = pair.handle
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        out = []
+        for x_new in (None, xd):
+            if x_new is not None:
+                dom.x[: dom.nlocal] = torch.from_numpy(x_new[dom.ids.cpu().numpy()]).to(dev)
+                dom.replan()
+            eng = torch.zeros(1, dtype=torch.float64, device=dev)
+            pn, pf, pg, mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+            assert lib.annp_hip_neigh_build_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), RC_LIST, C.byref(pn), C.byref(pf),
+                                                   C.byref(pg), C.byref(mx), stream) == 0
+            assert lib.annp_hip_compute_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value,
+                                               dom.f.data_ptr(), None, eng.data_ptr(), None, None, stream) == 0
+            assert lib.annp_hip_sync(h) == 0
+            dom.reverse()
+            torch.cuda.synchronize(dev)
+            out.append((float(eng.item()),) + dom.gather_owned(dom.f))
+        pair.close()
+        return out, dom.migrated_last
+
+    res = ThreadFabric(world).run(rank_program)
+    assert sum(m for _, m in res) > 0
+    for k, xk in enumerate((xg, xd)):
+        s = System(xk, box)
+        o = oracle_compute(fe_pot, s, KIND_FE, FAST)
+        f = np.full_like(xk, np.nan)
+        for out, _ in res:
+            f[out[k][1]] = out[k][2]
+        assert abs(sum(out[k][0] for out, _ in res) - o["energy"]) < 1e-6 * s.nlocal
+        assert np.abs(f - o["f"]).max() < 1e-9 * max(1.0, np.abs(o["f"]).max())

@@ -11,26 +11,18 @@ pytestmark = pytest.mark.gpu
 RC_LIST = 8.5
 
 
-class _NoDist:
-    P2POp = None
-
-    @staticmethod
-    def batch_isend_irecv(ops):
-        return []
-
-
 @pytest.fixture(scope="module")
 def big():
     import torch
     from meng_zhang_amd import PairANNP
-    from meng_zhang_amd.domain import Domain, HaloPlan
+    from meng_zhang_amd.domain import SlabDomain
     from meng_zhang_amd.lib import load_library
     lib = load_library()
     dev = torch.device("cuda", 0)
     x0, box = bcc(80, 80, 80, A_FE)
     xg = perturb(x0, 12345, 0.05)
-    plan = HaloPlan(x0, box, (1, 1, 1), RC_LIST, 1, 0)
-    dom = Domain(plan, xg, dev, _NoDist())
+    dom = SlabDomain.from_global(xg, box, (1, 1, 1), RC_LIST, dev)
+    plan = dom                       # nlocal / nall / nghost live on the domain itself
     pair = PairANNP(1, device=0)
     pair.settings([])
     pair.coeff(["*", "*", FE_POT, "Fe"])

@@ -14,19 +14,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-class _NoDist:
-    P2POp = None
-
-    @staticmethod
-    def batch_isend_irecv(ops):
-        return []
-
-
 def main():
     import torch
     from annp_testlib import A_FE, A_NI, ANNA_POT, FE_POT, NI_POT, bcc, fcc, perturb
     from meng_zhang_amd import PairANNP
-    from meng_zhang_amd.domain import Domain, HaloPlan
+    from meng_zhang_amd.domain import SlabDomain
     from meng_zhang_amd.lib import load_library
     kind = sys.argv[1]
     dims = [int(v) for v in sys.argv[2:5]]
@@ -46,8 +38,7 @@ def main():
     xg = perturb(x0, 12345, 0.05)
     lib = load_library()
     dev = torch.device("cuda", 0)
-    plan = HaloPlan(x0, box, (1, 1, 1), rc_list, 1, 0)
-    dom = Domain(plan, xg, dev, _NoDist())
+    dom = plan = SlabDomain.from_global(xg, box, (1, 1, 1), rc_list, dev)
     pair = PairANNP(1, device=0, style=style)
     pair.settings([])
     pair.coeff(["*", "*", pot, el])
