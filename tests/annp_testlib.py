@@ -340,7 +340,10 @@ def write_ann(path, npsf=9, ntsf=19, nnod=10, ntl=4, acts=("tanh", "tanh", "line
 # ---------------------------------------------------------------- in-process ranks (tests of the decomposition)
 class ThreadFabric:
     """Wires `world` ranks that run as threads of one process: FIFO mailboxes per (source, destination) pair and a
-    barrier for the small collectives.  Same surface as meng_zhang_amd.domain.TorchTransport."""
+    barrier for the small collectives.  Same surface as meng_zhang_amd.domain.TorchTransport.
+    The ranks take turns: a thread runs only while it holds the baton and hands it over whenever it waits for a
+    message or at a barrier, so no two ranks are ever inside the HIP runtime (or torch) at the same time -- the
+    interleaving of a real multi-process run at its communication points, without its concurrency."""
 
     def __init__(self, world):
         import queue
@@ -349,9 +352,18 @@ class ThreadFabric:
         self.box = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
+        self.baton = threading.Lock()
 
     def transport(self, rank):
         return ThreadTransport(self, rank)
+
+    def waiting(self, blocking_call):
+        """run a call that may block on another rank, without the baton"""
+        self.baton.release()
+        try:
+            return blocking_call()
+        finally:
+            self.baton.acquire()
 
     def run(self, fn):
         """fn(rank, transport) on every rank, each in its own thread; returns the list of results, re-raises the first error"""
@@ -359,11 +371,14 @@ class ThreadFabric:
         out, err = [None] * self.world, []
 
         def body(r):
+            self.baton.acquire()
             try:
                 out[r] = fn(r, self.transport(r))
             except BaseException as e:          # noqa: BLE001  (reported to the caller below)
                 err.append(e)
                 self.barrier.abort()
+            finally:
+                self.baton.release()
         th = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
         for t in th:
             t.start()
@@ -384,14 +399,15 @@ class ThreadTransport:
                 self.fab.box[(self.rank, peer)].put(t.detach().clone())
         for kind, t, peer in msgs:
             if kind == "recv":
-                t.copy_(self.fab.box[(peer, self.rank)].get(timeout=120))
+                q = self.fab.box[(peer, self.rank)]
+                t.copy_(self.fab.waiting(lambda: q.get(timeout=300)))
 
     def _collect(self, t):
         import torch
         self.fab.slots[self.rank] = t.detach().clone()
-        self.fab.barrier.wait(timeout=120)
+        self.fab.waiting(lambda: self.fab.barrier.wait(timeout=300))
         out = torch.stack([s.to(t.device) for s in self.fab.slots])
-        self.fab.barrier.wait(timeout=120)
+        self.fab.waiting(lambda: self.fab.barrier.wait(timeout=300))
         return out
 
     def allgather(self, t):
