@@ -285,6 +285,57 @@ def load_fe_st():
     return x, np.array([xlo, ylo, zlo, xhi, yhi, zhi])
 
 
+# ---------------------------------------------------------------- the reference's own minimisation log
+# annp-gpu-lammps/fe_v2/performance test.zip -> log_relaxing_{new,old}.lammps: `min_style cg` (LAMMPS defaults: quadratic
+# line search, dmax = 0.1), "Iterations, force evaluations = 1 2".  Values printed by the reference's mixed-precision
+# GPU builds (fe_v2 = "new", fe = "old") for fe_st.dat:
+CG_LOG = {
+    "new": dict(e0=-684876292.365723, e1=-684876369.462402, fnorm0=39.623051, fnorm1=19.978295, fmax0=0.93490135,
+                fmax1=0.52800152, alpha=0.10696316, max_move=0.056476709, press0=-40423.638, press1=-39424.375),
+    "old": dict(e0=-684876292.28418, e1=-684876369.487793, fnorm0=39.623117, fnorm1=19.978156, fmax0=0.93490485,
+                fmax1=0.52800456, alpha=0.10696276, max_move=0.056476823, press0=-40426.438, press1=-39426.375),
+}
+CG_VOLUME, NKTV2P = 1773495.9, 1.6021765e6      # log thermo column "Volume"; LAMMPS metal units
+
+
+def cg_first_iteration(evaluate, x0):
+    """What LAMMPS' MinCG does in its first iteration with the quadratic line search (src/min_linesearch.cpp,
+    linemin_quadratic; LAMMPS is not vendored in the reference, the algorithm is its published one): search direction
+    h = F(x0); trial step alpha_max = dmax / max|h| with dmax = 0.1 A; secant projection
+    alpha0 = alpha_max - alpha_max fh / (fh - fh0) with fh = F(x0 + alpha_max h).h, taken when the energy is locally
+    quadratic (relerr <= 0.1) and 0 < alpha0 < alpha_max -- two force evaluations after the initial one, as the log
+    reports.  evaluate(x) -> dict(energy, f, virial).  Returns the three evaluations and the two step lengths."""
+    r0 = evaluate(x0)
+    h = r0["f"].copy()
+    fh0 = float((h * h).sum())
+    alpha_max = 0.1 / float(np.abs(h).max())
+    r1 = evaluate(x0 + alpha_max * h)
+    fh = float((r1["f"] * h).sum())
+    relerr = abs(1.0 - (0.5 * alpha_max * (fh + fh0) + r1["energy"]) / r0["energy"])
+    alpha0 = alpha_max - alpha_max * fh / (fh - fh0)
+    assert relerr <= 0.1 and 0.0 < alpha0 < alpha_max          # the branch LAMMPS took (3 evaluations in all)
+    r2 = evaluate(x0 + alpha0 * h)
+    return r0, r1, r2, alpha_max, alpha0
+
+
+def check_cg_log(r0, r2, alpha_max):
+    """final state of that iteration against both logs; tolerances = what the reference's own float arithmetic allows
+    (its two builds differ from each other by 7e-6 in |F|, 3e-6 in Fmax, 5e-5 in P and 0.1 eV in the energy drop)"""
+    fn, fm = float(np.linalg.norm(r2["f"])), float(np.abs(r2["f"]).max())
+    press = r2["virial"][:3].sum() / (3 * CG_VOLUME) * NKTV2P
+    de = r2["energy"] - r0["energy"]
+    for tag, L in CG_LOG.items():
+        assert abs(alpha_max - L["alpha"]) / L["alpha"] < 5e-5, tag            # observed 2.0e-5 / 2.4e-5
+        assert abs(fn - L["fnorm1"]) / L["fnorm1"] < 2e-5, tag                 # observed 3.7e-6 / 1.1e-5
+        assert abs(fm - L["fmax1"]) < 5e-5, tag                                # observed 1.7e-5 / 1.4e-5
+        assert abs(alpha_max * fm - L["max_move"]) < 1e-5, tag                 # observed 2.9e-6
+        assert abs(press - L["press1"]) / abs(L["press1"]) < 1e-4, tag         # observed 5.3e-5 / 2.4e-6
+        # The energy drop is the weak one: the reference builds evaluate E_i in float (ulp of 4479.87 = 4.9e-4 eV) and
+        # their systematic per-atom offset moves with the configuration: 2.2e-5 eV/atom at step 0, 4.6e-5 at step 1.
+        assert abs(de - (L["e1"] - L["e0"])) < 2.5e-5 * 152880, tag            # observed 3.7 eV of -77.1
+    return dict(fnorm=fn, fmax=fm, press=press, de=de)
+
+
 # ---------------------------------------------------------------- synthetic potential files
 def write_ann(path, npsf=9, ntsf=19, nnod=10, ntl=4, acts=("tanh", "tanh", "linear"), cut=6.5, seed=1, element="Fe",
               behler=None):

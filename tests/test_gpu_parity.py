@@ -6,8 +6,8 @@ Tolerances are BASELINE.json's: per-atom energies within 1e-6 eV, forces within
 import numpy as np
 import pytest
 
-from annp_testlib import (A_FE, A_NI, FAST, FE_POT, KIND_FE, KIND_NI_COMPAT, KIND_NI_FIXED, NI_POT, System, bcc, fcc,
-                          load_fe_st, oracle_compute, oracle_vatom, perturb)
+from annp_testlib import (A_FE, A_NI, FAST, FE_POT, KIND_FE, KIND_NI_COMPAT, KIND_NI_FIXED, NI_POT, System, bcc,
+                          cg_first_iteration, check_cg_log, fcc, load_fe_st, oracle_compute, oracle_vatom, perturb)
 
 pytestmark = pytest.mark.gpu
 
@@ -192,6 +192,22 @@ def test_fe_published_log_kat(fe_pair):
     assert abs(np.abs(r["f"]).max() - 0.93490135) < 5e-5
     p = r["virial"][:3].sum() / (3 * 1773495.9) * 1.6021765e6
     assert abs(p - (-40423.638)) / 40423.638 < 2e-4
+
+
+def test_fe_published_log_first_cg_iteration(fe_pair):
+    """Same reference-held numbers as tests/test_oracle_pins.py::test_fe_published_log_first_cg_iteration, with the HIP
+    path as the force engine: three evaluations of fe_st.dat (152 880 atoms, free surfaces in x and z)."""
+    x, box = load_fe_st()
+    s = System(x, box, periodic=(0, 1, 0))
+
+    def evaluate(xn):
+        s.refresh_ghosts(xn)
+        fe_pair.eatom = None
+        return run(fe_pair, s, vflag=1)
+
+    r0, r1, r2, alpha_max, alpha0 = cg_first_iteration(evaluate, x)
+    got = check_cg_log(r0, r2, alpha_max)
+    assert abs(alpha0 - 0.0969087) < 1e-6 and abs(got["fnorm"] - 19.97837) < 1e-4      # = the oracle's values
 
 
 @pytest.mark.parametrize("which", ["fe", "ni"])

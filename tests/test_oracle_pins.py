@@ -6,14 +6,19 @@ The reference ships no tests.  What pins results for this path:
       and log_relaxing_old.lammps:120-122): step-0 E_pair, force 2-norm, max force
      component and pressure of fe_st.dat (152 880 atoms), printed by the reference's
      mixed-precision GPU build;
-  2. the perfect-lattice energies of SURVEY.md Appendix B, recorded from the
-     reference CPU translation units in fp64.
+  2. the same logs' state after the first conjugate-gradient iteration (final force norm, largest force component,
+     step length, pressure at thermo step 1, energy drop): the step is taken along the step-0 forces, so every one of
+     the 458 640 force components enters, and the forces are evaluated again at the displaced configuration;
+  3. the perfect-lattice energies of SURVEY.md Appendix B, recorded from the
+     reference CPU translation units in fp64 (reproduced, but obtained through stand-in headers: they pin nothing
+     by themselves).
+Ni and anna_adp: the reference holds no fixture, log or golden value for them -- parity unpinned.
 """
 import numpy as np
 import pytest
 
 from annp_testlib import (A_FE, A_NI, FAST, KIND_FE, KIND_NI_COMPAT, KIND_NI_FIXED, LITERAL,
-                          System, bcc, fcc, load_fe_st, oracle_compute, oracle_vatom, perturb)
+                          System, bcc, cg_first_iteration, check_cg_log, fcc, load_fe_st, oracle_compute, oracle_vatom, perturb)
 
 # SURVEY.md Appendix B
 FE_KAT = [(2.80, -4479.873964205), (2.8553, -4479.881765560), (2.90, -4479.854951283)]
@@ -65,6 +70,23 @@ def test_fe_published_log_kat(fe_pot):
     # pairwise tally == F.r over owned+ghost atoms (virial_fdotr_compute)
     fdotr = (s.x * r["f_all"]).sum(0)
     assert np.allclose(fdotr, r["virial"][:3], rtol=1e-9)
+
+
+def test_fe_published_log_first_cg_iteration(fe_pot):
+    """The logs' "Minimization stats" after one CG iteration of fe_st.dat, reproduced with the oracle as the force
+    engine of LAMMPS' published line search (annp_testlib.cg_first_iteration)."""
+    x, box = load_fe_st()
+    s = System(x, box, periodic=(0, 1, 0))
+
+    def evaluate(xn):
+        s.refresh_ghosts(xn)                # max atom move 0.1 A << skin / 2: LAMMPS keeps the list as well
+        return oracle_compute(fe_pot, s, KIND_FE, FAST, want_virial=True)
+
+    r0, r1, r2, alpha_max, alpha0 = cg_first_iteration(evaluate, x)
+    got = check_cg_log(r0, r2, alpha_max)
+    assert 0.09 < alpha0 < 0.10                                  # observed 0.0969087
+    # naive reading of the log ("x1 = x0 + 0.10696316 F0") is NOT the logged state: |F| would be 21.90, not 19.98
+    assert abs(np.linalg.norm(r1["f"]) - 21.9007) < 1e-3 and abs(got["fnorm"] - 19.97837) < 1e-4
 
 
 def test_fe_fast_matches_literal(fe_pot):
