@@ -66,7 +66,11 @@ typedef struct annp_hip_handle annp_hip_handle;
 typedef struct annp_hip_params {
     int struct_bytes;       /* sizeof(annp_hip_params), ABI check                      */
     int descriptor;         /* ANNP_HIP_DESC_*                                          */
-    int ntypes;             /* LAMMPS atom->ntypes                                      */
+    int ntypes;             /* LAMMPS atom->ntypes (<= 30)                              */
+    int nelements;          /* elements in the potential file (params[0].nelements; 0 is read as 1):
+                               weight_all / bias_all carry one network per element, atom i is evaluated
+                               with the network of element map[type[i]] (fe_v2/src/pair_annp.cpp:767-768);
+                               the descriptor itself is species-blind (fe_v2:633-695)       */
     int ntl, nhl, nnod;     /* total layers, hidden layers, nodes per hidden layer      */
     int nsf, npsf, ntsf;    /* symmetry functions: all, radial, angular                 */
     int flagsym;            /* as parsed (informational; `descriptor` decides)          */
@@ -81,11 +85,15 @@ typedef struct annp_hip_params {
     const double *sfnor_scal; /* [nsf] CHEBYSHEV: 1/sqrt(cov-avg^2) (pair_annp_gpu.cpp:207-216)
                                        BEHLER: sf_max - sf_min (ni pair_annp_gpu.cpp:231-235) */
     const double *sfnor_avg;  /* [nsf] CHEBYSHEV: sfnor_avg;  BEHLER: sf_min               */
-    const double *cutsq;      /* [(ntypes+1)*(ntypes+1)] LAMMPS cutsq, row-major            */
-    const int *map;           /* [ntypes+1] LAMMPS type -> element, -1 = not mapped         */
-    const double *const *weight_all; /* [ntl-1] pointers, layer l row-major [nrow][ncol]:
-                                        (nnod x nsf), (nnod x nnod)..., (1 x nnod); element 0 */
-    const double *const *bias_all;   /* [ntl-1] pointers, [nnod] ... [1]                     */
+    const double *cutsq;      /* [(ntypes+1)*(ntypes+1)] LAMMPS cutsq, row-major.  init_one returns cutmax for every
+                                 pair of mapped types (fe_v2:323-327), so the entries are cutmax^2 or 0 (a type that
+                                 is not mapped: such atoms are neither neighbours nor centres, fe_v2:144);
+                                 anything else is refused (-9)                               */
+    const int *map;           /* [ntypes+1] LAMMPS type -> element, -1 = not mapped (NULL: every type -> 0) */
+    const double *const *weight_all; /* [nelements*(ntl-1)] pointers, entry e*(ntl-1)+l = element e, layer l,
+                                        row-major [nrow][ncol]: (nnod x nsf), (nnod x nnod)..., (1 x nnod)
+                                        (the double*** weight_all[e][l] of annp_gpu_init)     */
+    const double *const *bias_all;   /* [nelements*(ntl-1)] pointers, [nnod] ... [1]         */
     const double *cofsymrad;  /* BEHLER: [npsf*3] eta, Rs, Rc(Bohr); else NULL              */
     const double *cofsymang;  /* BEHLER: [ntsf*4] eta, lambda, zeta, Rc(Bohr); else NULL    */
     /* ANNA_ADP only (the arguments anna_adp_gpu_init adds, bcc_fe/src/pair_anna_adp_gpu.cpp:31-41) */
@@ -128,7 +136,8 @@ int annp_hip_compute_n(annp_hip_handle *handle, int ago, int inum, int nall, int
                        double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom);
 
 /* Device-resident evaluation: every pointer is a device pointer on the handle's GPU.
- *   d_x [nall*3], d_type [nall] (nullable = all type 1), d_ilist [inum] (nullable = 0..inum-1)
+ *   d_x [nall*3], d_type [nall] (LAMMPS types 1..ntypes; nullable when every type maps to the same
+ *   element, required otherwise), d_ilist [inum] (nullable = 0..inum-1)
  *   neighbours of atom i: d_neigh[d_first[i] .. d_first[i]+d_numneigh[i])
  *   d_f [nall*3] accumulated;  d_eatom [nall] accumulated (nullable)
  *   d_eng: 1 double accumulated (nullable);  d_virial: 6 doubles accumulated (nullable)

@@ -59,7 +59,12 @@ struct annp_hip_handle {
     int flagact[MLP_MAXL] = {0, 0, 0, 0};
     double e_scale = 0, e_shift = 0, e_atom = 0, cut = 0, cutsq = 0;
     double *d_norm = nullptr;           // nmul | nsub | nden, ANNP_GPAD each
-    double *d_mlp_img = nullptr;        // network pass: MFMA operand image (weights, biases, coefmat), mlp_build_image
+    double *d_mlp_img = nullptr;        // network pass: MFMA operand images (weights, biases, coefmat), one per element, mlp_build_image
+    size_t img_stride = 0;              // doubles per element image
+    int nelem = 1;
+    bool multi = false;                 // several elements or an unmapped type: the kernels need atom types
+    unsigned active = ~0u;              // bit t: type t is mapped to an element
+    int *d_map = nullptr;               // device copy of map[0..ntypes]
     double *d_sym = nullptr;            // BEHLER: function tables (ni_kernels.hpp, "per-function tables")
     int *d_isym = nullptr;
     NiShape ni_shape = {0, 0, 0};       // {lambda} x {eta} x {zeta} product shape of the angular set (0 = none)
@@ -170,6 +175,18 @@ int run_mlp(annp_hip_handle *h, const MlpArgs &a, hipStream_t s)
     ANNP_MLP_SHAPES(X)
 #undef X
     return fail(h, ANNP_HIP_ESHAPE, "no network kernel for nsf=%d nnod=%d layers=%d", h->nsf, h->nnod, h->nl);
+}
+
+// the network pass: one launch per element of the potential, each with that element's operand image
+int run_mlp_elements(annp_hip_handle *h, MlpArgs m, hipStream_t s)
+{
+    const double *base = m.img;
+    for (int e = 0; e < h->nelem; e++) {
+        m.img = base + (size_t)e * h->img_stride;
+        m.elem = e;
+        if (int rc = run_mlp(h, m, s)) return rc;
+    }
+    return 0;
 }
 
 // operand image of the network pass for this handle's shape (empty when the shape is not compiled)
@@ -309,7 +326,11 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     const int blocks = (inum + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK;
     const int cap_list = std::max(16, round_up(max_numneigh, 16));
 
+    if (h->multi && !d_type)
+        return fail(h, ANNP_HIP_EARG, "this potential distinguishes atom types (several elements or an unmapped type): d_type is required");
+    const int *types = h->multi ? d_type : nullptr;
     MlpArgs m{};
+    m.type = types; m.map = h->d_map; m.elem = 0;
     m.inum = inum; m.ilist = d_ilist; m.nsf = h->nsf_dev; m.nnod = h->nnod; m.nl = h->nl;
     for (int l = 0; l < h->nl; l++) m.act[l] = h->flagact[l];
     m.nmul = h->d_norm; m.nsub = h->d_norm + ANNP_GPAD; m.nden = h->d_norm + 2 * ANNP_GPAD; m.img = h->d_mlp_img;
@@ -320,6 +341,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         FeArgs a{};
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
         a.cutsq = h->cutsq; a.rc_list = std::sqrt(h->cutsq); a.rc_par = h->cut;
+        a.type = types; a.active = h->active;
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.vatom = d_vatom; a.ncount = h->ncount.p;
         a.errflag = h->d_flags;
         // pass 1: capacity = list length (upper bound of the in-cutoff count)
@@ -333,7 +355,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
         // pass 2
         m.act_plain = 0; m.energy_raw = 0;
-        if ((rc = run_mlp(h, m, s))) return rc;
+        if ((rc = run_mlp_elements(h, m, s))) return rc;
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
         // pass 3: LDS records sized by the in-cutoff maximum of the previous evaluation; an atom that has more
         // is queued by the kernel and taken by the fix-up launch behind it, which has room for a whole list row
@@ -402,6 +424,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         NiArgs a{};
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
         a.npsf = h->npsf; a.ntsf = h->ntsf; a.sym = h->d_sym; a.isym = h->d_isym; a.compat = h->ni_compat;
+        a.type = types; a.active = h->active;
         a.rc_rad = h->sym_rad[2]; a.rc_ang = h->sym_ang[3];
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.vatom = d_vatom; a.ncount = h->ncount.p; a.errflag = h->d_flags;
         if (a.npsf > NI_MAXP || a.ntsf > NI_MAXT)
@@ -442,7 +465,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         }
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
         m.act_plain = 1; m.energy_raw = 1;
-        if ((rc = run_mlp(h, m, s))) return rc;
+        if ((rc = run_mlp_elements(h, m, s))) return rc;
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
         a.n_cap = cap_force;
         h->cap_last = cap_force;
@@ -478,6 +501,7 @@ void annp_hip_clear(annp_hip_handle *h)
     if (h->d_sym) (void)hipFree(h->d_sym);
     if (h->d_isym) (void)hipFree(h->d_isym);
     if (h->d_mlp_img) (void)hipFree(h->d_mlp_img);
+    if (h->d_map) (void)hipFree(h->d_map);
     if (h->d_net) (void)hipFree(h->d_net);
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom); release(h, h->vatom);
     release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr); release(h, h->ovf);
@@ -518,9 +542,30 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         return fail(nullptr, ANNP_HIP_ESHAPE, "Chebyshev kernels hold up to %d radial and %d angular orders (got %d %d)", FE_NP, FE_NT, p->npsf, p->ntsf);
     if (p->descriptor == ANNP_HIP_DESC_BEHLER && (!p->cofsymrad || !p->cofsymang))
         return fail(nullptr, ANNP_HIP_EARG, "Behler descriptor needs cofsymrad/cofsymang");
-    if (p->map) {
-        for (int t = 1; t <= p->ntypes; t++)
-            if (p->map[t] != 0) return fail(nullptr, ANNP_HIP_ESHAPE, "every atom type must map to the potential's single element");
+    const int ne = std::max(1, p->nelements);
+    const int ntypes = std::max(1, p->ntypes);
+    if (ntypes > 30) return fail(nullptr, ANNP_HIP_ESHAPE, "more than 30 atom types");
+    unsigned active = 0u;
+    bool multi = ne > 1;
+    for (int t = 1; t <= ntypes; t++) {
+        const int e = p->map ? p->map[t] : 0;
+        if (e >= ne) return fail(nullptr, ANNP_HIP_EARG, "map[%d] = %d but the potential has %d element(s)", t, e, ne);
+        if (e >= 0) active |= 1u << t; else multi = true;
+    }
+    if (!active) return fail(nullptr, ANNP_HIP_EARG, "no atom type is mapped to an element");
+    if (anna && multi) return fail(nullptr, ANNP_HIP_ESHAPE, "pair_style anna_adp: single-element potentials only");
+    // cutsq: cutmax^2 for every pair of mapped types, as init_one produces it (fe_v2/src/pair_annp.cpp:323-327)
+    double cutsq_all = p->cut * p->cut;
+    if (p->cutsq) {
+        cutsq_all = -1.0;
+        for (int a = 1; a <= ntypes; a++)
+            for (int b = 1; b <= ntypes; b++) {
+                if (!((active >> a) & 1u) || !((active >> b) & 1u)) continue;
+                const double c = p->cutsq[(size_t)(p->ntypes + 1) * a + b];
+                if (cutsq_all < 0.0) cutsq_all = c;
+                if (c != cutsq_all || !(c > 0.0))
+                    return fail(nullptr, ANNP_HIP_ESHAPE, "cutsq[%d][%d] = %g differs from cutsq of the other mapped pairs (%g)", a, b, c, cutsq_all);
+            }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, ANNP_HIP_EDEVICE, "no HIP device visible");
@@ -549,7 +594,15 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     h->descriptor = p->descriptor; h->ntypes = p->ntypes; h->ntl = p->ntl; h->nhl = p->nhl; h->nnod = p->nnod;
     h->nsf = p->nsf; h->npsf = p->npsf; h->ntsf = p->ntsf; h->nl = nl; h->ni_compat = p->ni_compat;
     h->e_scale = p->e_scale; h->e_shift = p->e_shift; h->e_atom = p->e_atom; h->cut = p->cut;
-    h->cutsq = p->cutsq ? p->cutsq[(p->ntypes + 1) * 1 + 1] : p->cut * p->cut;
+    h->cutsq = cutsq_all;
+    h->nelem = ne; h->multi = multi; h->active = active;
+    if (multi) {
+        std::vector<int> mp((size_t)ntypes + 1, -1);
+        for (int t = 1; t <= ntypes; t++) mp[t] = p->map ? p->map[t] : 0;
+        INIT_TRY(hipMalloc((void **)&h->d_map, sizeof(int) * mp.size()));
+        INIT_TRY(hipMemcpy(h->d_map, mp.data(), sizeof(int) * mp.size(), hipMemcpyHostToDevice));
+        h->bytes += sizeof(int) * mp.size();
+    }
     for (int l = 0; l < nl; l++) h->flagact[l] = p->flagact[l];
 
     if (anna) {
@@ -605,11 +658,6 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         INIT_TRY(hipMalloc((void **)&h->d_norm, sizeof(double) * t.size()));
         INIT_TRY(hipMemcpy(h->d_norm, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
         h->bytes += sizeof(double) * t.size();
-        // first-layer weights in the device layout
-        std::vector<double> w0((size_t)nnod * nsf, 0.0);
-        for (int i = 0; i < nnod; i++)
-            for (int k = 0; k < p->nsf; k++) w0[(size_t)i * nsf + slot[k]] = p->weight_all[0][(size_t)i * p->nsf + k];
-
         // T: rows of coef as linear forms of c_k = cmul_k dE/dGhat_k
         std::vector<long double> T((size_t)ANNP_CPAD * nsf, 0.0L);
         if (cheb) {
@@ -633,21 +681,34 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         } else {
             for (int k = 0; k < nsf; k++) T[(size_t)k * nsf + k] = 1.0L;
         }
-        // coefmat[o][i] = sum_k T[o][k] cmul_k W_0[i][k]
-        std::vector<double> cm((size_t)ANNP_CPAD * nnod, 0.0);
-        for (int o = 0; o < ANNP_CPAD; o++)
-            for (int i = 0; i < nnod; i++) {
-                long double acc = 0.0L;
-                for (int k = 0; k < nsf; k++) acc += T[(size_t)o * nsf + k] * (long double)cmul[k] * (long double)w0[(size_t)i * nsf + k];
-                cm[(size_t)o * nnod + i] = (double)acc;
-            }
-        std::vector<const double *> Wl(p->weight_all, p->weight_all + nl);
-        Wl[0] = w0.data();
-        const std::vector<double> img = mlp_image(h, Wl.data(), p->bias_all, cm.data());
-        if (img.empty()) { fail(h, 0, "no network kernel for nsf=%d nnod=%d layers=%d", h->nsf, h->nnod, h->nl); return bail(ANNP_HIP_ESHAPE); }
-        INIT_TRY(hipMalloc((void **)&h->d_mlp_img, sizeof(double) * img.size()));
-        INIT_TRY(hipMemcpy(h->d_mlp_img, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
-        h->bytes += sizeof(double) * img.size();
+        // one operand image per element: its weights (layer 0 in the device layout), biases and coefmat
+        std::vector<double> img_all;
+        for (int e = 0; e < ne; e++) {
+            const double *const *We = p->weight_all + (size_t)e * nl;
+            const double *const *Be = p->bias_all + (size_t)e * nl;
+            for (int l = 0; l < nl; l++)
+                if (!We[l] || !Be[l]) { fail(h, 0, "weight_all / bias_all: element %d layer %d is NULL", e, l); return bail(ANNP_HIP_EARG); }
+            std::vector<double> w0((size_t)nnod * nsf, 0.0);
+            for (int i = 0; i < nnod; i++)
+                for (int k = 0; k < p->nsf; k++) w0[(size_t)i * nsf + slot[k]] = We[0][(size_t)i * p->nsf + k];
+            // coefmat[o][i] = sum_k T[o][k] cmul_k W_0[i][k]
+            std::vector<double> cm((size_t)ANNP_CPAD * nnod, 0.0);
+            for (int o = 0; o < ANNP_CPAD; o++)
+                for (int i = 0; i < nnod; i++) {
+                    long double acc = 0.0L;
+                    for (int k = 0; k < nsf; k++) acc += T[(size_t)o * nsf + k] * (long double)cmul[k] * (long double)w0[(size_t)i * nsf + k];
+                    cm[(size_t)o * nnod + i] = (double)acc;
+                }
+            std::vector<const double *> Wl(We, We + nl);
+            Wl[0] = w0.data();
+            const std::vector<double> img = mlp_image(h, Wl.data(), Be, cm.data());
+            if (img.empty()) { fail(h, 0, "no network kernel for nsf=%d nnod=%d layers=%d", h->nsf, h->nnod, h->nl); return bail(ANNP_HIP_ESHAPE); }
+            h->img_stride = img.size();
+            img_all.insert(img_all.end(), img.begin(), img.end());
+        }
+        INIT_TRY(hipMalloc((void **)&h->d_mlp_img, sizeof(double) * img_all.size()));
+        INIT_TRY(hipMemcpy(h->d_mlp_img, img_all.data(), sizeof(double) * img_all.size(), hipMemcpyHostToDevice));
+        h->bytes += sizeof(double) * img_all.size();
     }
     if (p->descriptor == ANNP_HIP_DESC_BEHLER) {
         h->sym_rad.assign(p->cofsymrad, p->cofsymrad + 3 * p->npsf);
@@ -920,14 +981,20 @@ static int host_evaluate(annp_hip_handle *h, int inum, int nall, const int *host
     int rc;
     if ((rc = ensure(h, h->f, (size_t)nall * 3)) || (rc = ensure(h, h->eatom, (size_t)nall))) return rc;
     if (vatom && (rc = ensure(h, h->vatom, (size_t)nall * 6))) return rc;
-    (void)host_type;
+    const int *d_type = nullptr;
+    if (h->multi) {             // atom types select the element's network (and drop atoms of unmapped types)
+        if (!host_type) return fail(h, ANNP_HIP_EARG, "this potential distinguishes atom types: host_type is required");
+        if ((rc = ensure(h, h->type, (size_t)nall))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->type.p, host_type, sizeof(int) * (size_t)nall, hipMemcpyHostToDevice, s));
+        d_type = h->type.p;
+    }
     const bool want_eatom = eflag && eatom_flag && eatom;
     for (int attempt = 0;; attempt++) {
         HIP_TRY(h, hipMemsetAsync(h->f.p, 0, sizeof(double) * (size_t)nall * 3, s));
         HIP_TRY(h, hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), s));
         if (want_eatom) HIP_TRY(h, hipMemsetAsync(h->eatom.p, 0, sizeof(double) * (size_t)nall, s));
         if (vatom) HIP_TRY(h, hipMemsetAsync(h->vatom.p, 0, sizeof(double) * (size_t)nall * 6, s));
-        rc = compute_device_impl(h, inum, nall, h->x.p, nullptr, d_ilist, d_numneigh, d_first, d_neigh, max_numneigh,
+        rc = compute_device_impl(h, inum, nall, h->x.p, d_type, d_ilist, d_numneigh, d_first, d_neigh, max_numneigh,
                                  h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr,
                                  vatom ? h->vatom.p : nullptr, s);
         if (!rc) rc = host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, vatom);

@@ -39,6 +39,8 @@ struct FeArgs {
     int n_cap;                 // LDS record capacity per wave (null record sits at index n_cap)
     const int *ilist;          // nullable: identity
     const double *x;           // [nall][3]
+    const int *type;           // nullable [nall]: LAMMPS types, given when some type is unmapped (see `active`)
+    unsigned active;           // bit t set: atoms of type t take part (map[t] >= 0, i.e. cutsq[.][t] > 0, fe:144)
     const int *numneigh;       // by atom index
     const long long *first;    // by atom index
     const int *neigh;
@@ -101,6 +103,10 @@ __device__ __forceinline__ int fe_compact(const FeArgs &p, int i, int lane, doub
             const int jj = c0 + 64 * u + lane;
             valid[u] = jj < jn;
             j[u] = valid[u] ? (p.neigh[base + jj] & ANNP_NEIGHMASK) : i;
+        }
+        if (p.type) {          // wave-uniform: only potentials with an unmapped type pay for the gather
+#pragma unroll
+            for (int u = 0; u < 4; u++) valid[u] = valid[u] && ((p.active >> p.type[j[u]]) & 1u);
         }
         double dx[4], dy[4], dz[4];
 #pragma unroll
@@ -180,6 +186,11 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
     const double two_over_rcp = 2.0 / p.rc_par;
 
+    if (p.type && !((p.active >> p.type[i]) & 1u)) {      // centre of an unmapped type: no neighbours, no energy
+        if (p.ncount && lane == 0) p.ncount[ii] = 0;
+        if (lane < ANNP_GPAD) p.G[(size_t)ii * ANNP_GPAD + lane] = 0.0;
+        return;
+    }
     const int n = fe_compact<false>(p, i, lane, recA, recB, nullptr);
     if (p.ncount && lane == 0) p.ncount[ii] = n;
     if (n > p.n_cap) {                      // capacity exceeded: report, leave G zero
@@ -372,6 +383,7 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
     const double two_over_rcp = 2.0 / p.rc_par;
     const double *cf = p.coef + (size_t)ii * ANNP_CPAD;
 
+    if (p.type && !((p.active >> p.type[i]) & 1u)) return;
     const int n = fe_compact<true>(p, i, lane, recA, recB, auxJ);
     if (n > p.n_cap) {          // does not fit this launch's records: hand the atom to the fix-up launch
         if (lane == 0) {

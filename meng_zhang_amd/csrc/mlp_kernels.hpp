@@ -48,6 +48,11 @@ struct MlpArgs {
     double *coef;                 // [inum][ANNP_CPAD]
     double *eatom;                // nullable, indexed by atom
     double *eng;                  // nullable, one double
+    // potentials with several elements (or unmapped types): one launch per element, each taking the atoms whose
+    // type maps to `elem` and leaving every other row of coef alone (fe_v2/src/pair_annp.cpp:767-768)
+    const int *type;              // nullable [nall]
+    const int *map;               // device [ntypes+1]
+    int elem;
 };
 
 // tanh(y) to a few ulp without libm's branches: e^{-2|y|} = 2^k (1 + q), q = expm1 of the reduced argument, so
@@ -204,7 +209,12 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
     const int wave_stride = gridDim.x * ANNP_WAVES_PER_BLOCK;
     for (int tile = wave_global; tile < ntiles; tile += wave_stride) {
         const int ia = tile * 16 + lr;            // this lane's atom (column)
-        const bool aval = ia < p.inum;
+        bool aval = ia < p.inum;
+        if (p.type) {
+            if (aval) aval = p.map[p.type[p.ilist ? p.ilist[ia] : ia]] == p.elem;
+            if (__ballot(aval) == 0ull) continue;                            // no atom of this element in the tile
+        }
+        const unsigned rowmask = (unsigned)(__ballot(aval) & 0xffffull);     // lanes 0..15 speak for the 16 atoms
         // ---- input fragment: Ghat[k = 4s+lq][atom]
         double hin[KS0];
 #pragma unroll
@@ -303,7 +313,8 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
         {
             const int nrow = min(16, p.inum - tile * 16);
             double *dst = p.coef + (size_t)tile * 16 * ANNP_CPAD;
-            for (int idx = lane; idx < nrow * ANNP_CPAD; idx += 64) dst[idx] = cbuf[idx + idx / ANNP_CPAD];
+            for (int idx = lane; idx < nrow * ANNP_CPAD; idx += 64)
+                if ((rowmask >> (idx / ANNP_CPAD)) & 1u) dst[idx] = cbuf[idx + idx / ANNP_CPAD];
         }
         wave_lds_sync();
     }

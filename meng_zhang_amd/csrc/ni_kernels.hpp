@@ -44,6 +44,8 @@ struct NiArgs {
     int inum, n_cap;            // n_cap: in-range neighbours held per atom (LDS records), host-sized
     const int *ilist;
     const double *x;
+    const int *type;            // nullable [nall], with `active` as in FeArgs
+    unsigned active;
     const int *numneigh;
     const long long *first;
     const int *neigh;
@@ -383,6 +385,7 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
         if (ii < p.inum) {
             hi = p.ilist ? p.ilist[ii] : ii;
             hjn = p.numneigh[hi];
+            if (p.type && !((p.active >> p.type[hi]) & 1u)) hjn = 0;      // centre of an unmapped type: nothing in range
             hbase = p.first[hi];
             hx = p.x[3 * (size_t)hi]; hy = p.x[3 * (size_t)hi + 1]; hz = p.x[3 * (size_t)hi + 2];
         }
@@ -414,6 +417,10 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
                 const int jj = c0 + 64 * u + lane;
                 valid[u] = jj < jn;
                 j[u] = valid[u] ? (row[jj] & ANNP_NEIGHMASK) : 0;
+            }
+            if (p.type) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) valid[u] = valid[u] && ((p.active >> p.type[j[u]]) & 1u);
             }
             double dx[4], dy[4], dz[4];
 #pragma unroll

@@ -43,7 +43,7 @@ int PairANNP::coeff(int narg, const char *const *arg)
     }
     std::string perr;
     const bool ok = anna_ ? read_potential_anna(arg[2], (int)elements_.size(), pot_, perr)
-                          : read_potential(arg[2], (int)elements_.size(), pot_, perr);
+                          : read_potential(arg[2], (int)elements_.size(), pot_, perr, blocks_by_name_ ? &elements_ : nullptr);
     if (!ok) return fail(ANNP_HIP_EARG, perr);
     if ((int)elements_.size() != (int)pot_.elements.size()) return fail(ANNP_HIP_EARG, "Incorrect args for pair coefficients");
     cutmax_ = pot_.cut;                                            // fe:291-292
@@ -97,8 +97,10 @@ int PairANNP::init_style(int newton_pair, int device)
     } else {                                                       // ni pair_annp_gpu.cpp:231-235
         for (int k = 0; k < nsf; ++k) { avg[k] = pot_.norm_a[k]; scal[k] = pot_.norm_b[k] - pot_.norm_a[k]; }
     }
-    std::vector<const double *> wp(nl), bp(nl);
-    for (int l = 0; l < nl; ++l) { wp[l] = pot_.weights[l].data(); bp[l] = pot_.biases[l].data(); }
+    // weight_all[element][layer] as PairANNPGPU::init_style lays it out (pair_annp_gpu.cpp:185-205)
+    const int ne = anna_ ? 1 : (int)pot_.elements.size();
+    std::vector<const double *> wp((size_t)ne * nl), bp((size_t)ne * nl);
+    for (size_t k = 0; k < wp.size(); ++k) { wp[k] = pot_.weights[k].data(); bp[k] = pot_.biases[k].data(); }
 
     annp_hip_params prm;
     std::memset(&prm, 0, sizeof(prm));
@@ -108,6 +110,7 @@ int PairANNP::init_style(int newton_pair, int device)
     prm.nout = pot_.nout; prm.ngp = (int)pot_.gparams.size(); prm.gparams = pot_.gparams.empty() ? nullptr : pot_.gparams.data();
     prm.e_base = pot_.e_base;
     prm.ntypes = ntypes_;
+    prm.nelements = ne;
     prm.ntl = pot_.ntl; prm.nhl = pot_.nhl; prm.nnod = pot_.nnod;
     prm.nsf = nsf; prm.npsf = pot_.npsf; prm.ntsf = pot_.ntsf;
     prm.flagsym = pot_.flagsym;
@@ -188,6 +191,7 @@ void annp_pair_destroy(annp_pair *p) { delete p; }
 int annp_pair_settings(annp_pair *p, int narg, const char *const *arg) { return p ? p->impl.settings(narg, arg) : ANNP_HIP_EARG; }
 int annp_pair_coeff(annp_pair *p, int narg, const char *const *arg) { return p ? p->impl.coeff(narg, arg) : ANNP_HIP_EARG; }
 int annp_pair_set_ni_compat(annp_pair *p, int on) { if (!p) return ANNP_HIP_EARG; p->impl.set_ni_compat(on); return 0; }
+int annp_pair_set_blocks_by_name(annp_pair *p, int on) { if (!p) return ANNP_HIP_EARG; p->impl.set_blocks_by_name(on); return 0; }
 int annp_pair_init_style(annp_pair *p, int newton_pair, int device) { return p ? p->impl.init_style(newton_pair, device) : ANNP_HIP_EARG; }
 double annp_pair_init_one(annp_pair *p, int i, int j) { return p ? p->impl.init_one(i, j) : -1.0; }
 int annp_pair_compute(annp_pair *p, int eflag, int vflag, int eflag_atom, int ago, int inum, int nall, int nghost,
@@ -225,7 +229,7 @@ int annp_pair_potential_layer(const annp_pair *p, int layer, double *w, double *
 {
     if (!p) return ANNP_HIP_EARG;
     const annp_host::Potential &q = p->impl.potential();
-    if (layer < 0 || layer >= q.ntl - 1) return ANNP_HIP_EARG;
+    if (layer < 0 || layer >= (int)q.weights.size()) return ANNP_HIP_EARG;     // element e, layer l: e * (ntl-1) + l
     if (w) std::memcpy(w, q.weights[layer].data(), sizeof(double) * q.weights[layer].size());
     if (b) std::memcpy(b, q.biases[layer].data(), sizeof(double) * q.biases[layer].size());
     return 0;

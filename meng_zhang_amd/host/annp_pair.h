@@ -51,6 +51,9 @@ class PairANNP {
     const std::string &error() const { return err_; }
     annp_hip_handle *handle() const { return handle_; }
     void set_ni_compat(int v) { ni_compat_ = v; }
+    // files with several elements: 0 (default) = the reference parser's behaviour, 1 = "#El" lines select the element
+    // of the blocks below them (annp_potential.h); call before coeff()
+    void set_blocks_by_name(int v) { blocks_by_name_ = v != 0; }
     bool behler() const { return pot_.has_symcoef; }
     bool anna() const { return anna_; }
 
@@ -58,6 +61,7 @@ class PairANNP {
     int ntypes_;
     bool anna_ = false;
     int ni_compat_ = 0;
+    bool blocks_by_name_ = false;
     bool coeff_done_ = false;
     double cutmax_ = 0.0;
     std::vector<int> map_;                 // type -> element
@@ -80,6 +84,7 @@ void annp_pair_destroy(annp_pair *p);
 int annp_pair_settings(annp_pair *p, int narg, const char *const *arg);
 int annp_pair_coeff(annp_pair *p, int narg, const char *const *arg);
 int annp_pair_set_ni_compat(annp_pair *p, int on);
+int annp_pair_set_blocks_by_name(annp_pair *p, int on);
 int annp_pair_init_style(annp_pair *p, int newton_pair, int device);
 double annp_pair_init_one(annp_pair *p, int i, int j);
 int annp_pair_compute(annp_pair *p, int eflag, int vflag, int eflag_atom, int ago, int inum, int nall, int nghost,

@@ -55,7 +55,8 @@ int activation_code(char a, char b)
 
 }  // namespace
 
-bool read_potential(const std::string &path, int nelements_coeff, Potential &pot, std::string &err)
+bool read_potential(const std::string &path, int nelements_coeff, Potential &pot, std::string &err,
+                    const std::vector<std::string> *blocks_by_name)
 {
     std::ifstream fin(path.c_str());
     if (!fin.is_open()) { err = "Cannot open neural network potential file"; return false; }
@@ -106,15 +107,31 @@ bool read_potential(const std::string &path, int nelements_coeff, Potential &pot
     const int nl = pot.ntl - 1;
     if ((int)pot.flagact.size() < nl) { err = "potential file: fewer activation names than layers"; return false; }
     pot.flagact.resize(nl);
-    pot.weights.assign(nl, std::vector<double>());
-    pot.biases.assign(nl, std::vector<double>());
-    for (int l = 0; l < nl; ++l) {
-        pot.weights[l].assign((size_t)pot.rows(l) * pot.cols(l), 0.0);
-        pot.biases[l].assign(pot.rows(l), 0.0);
-    }
+    // one zero-filled network per element (fe:441-448: c_3d_matrix memsets), element e's layer l at [e * nl + l]
+    pot.weights.assign((size_t)ne * nl, std::vector<double>());
+    pot.biases.assign((size_t)ne * nl, std::vector<double>());
+    for (int e = 0; e < ne; ++e)
+        for (int l = 0; l < nl; ++l) {
+            pot.weights[(size_t)e * nl + l].assign((size_t)pot.rows(l) * pot.cols(l), 0.0);
+            pot.biases[(size_t)e * nl + l].assign(pot.rows(l), 0.0);
+        }
 
+    // Which element a block belongs to.  The reference declares `type_elem = 0` INSIDE its line loop (fe:455), so the
+    // element named on a "#El" line is forgotten before the "#k_(weight)" line that follows it is read: every block
+    // of every element lands in element 0 (the last one in the file wins) and elements 1.. keep their zero-filled
+    // networks.  That is what `blocks_by_name == nullptr` reproduces (the default: parity with the reference).
+    // With the pair_coeff element names given, a "#El" line selects the element of the blocks below it, which is
+    // evidently what the file format means.
+    int cur = 0;
     while (std::getline(fin, line)) {
         if (line.compare(0, 5, "#coef") == 0) { pot.has_symcoef = true; break; }
+        if (blocks_by_name && line.size() >= 2 && line[0] == '#' && std::isupper((unsigned char)line[1])) {
+            std::string name;
+            for (char c : line) if (c != '#' && c != '\r' && c != '\n' && c != '\t' && c != ' ') name += c;
+            for (size_t k = 0; k < blocks_by_name->size() && (int)k < ne; ++k)
+                if ((*blocks_by_name)[k] == name) cur = (int)k;
+            continue;
+        }
         if (line.size() < 2 || line[0] != '#' || !std::isdigit((unsigned char)line[1])) continue;
         int layer = 0;
         bool is_bias = false;
@@ -125,16 +142,17 @@ bool read_potential(const std::string &path, int nelements_coeff, Potential &pot
         }
         const int l = layer - 1;
         if (l < 0 || l >= nl) { err = "potential file: layer number out of range"; return false; }
+        std::vector<double> &W = pot.weights[(size_t)cur * nl + l], &B = pot.biases[(size_t)cur * nl + l];
         if (!is_bias) {
             for (int r = 0; r < pot.rows(l); ++r) {
                 if (!std::getline(fin, line)) { err = "potential file ends inside a weight block"; return false; }
                 const std::vector<double> v = row_values(line, true);
-                for (int c = 0; c < pot.cols(l) && c < (int)v.size(); ++c) pot.weights[l][(size_t)r * pot.cols(l) + c] = v[c];
+                for (int c = 0; c < pot.cols(l) && c < (int)v.size(); ++c) W[(size_t)r * pot.cols(l) + c] = v[c];
             }
         } else {
             if (!std::getline(fin, line)) { err = "potential file ends inside a bias block"; return false; }
             const std::vector<double> v = row_values(line, true);
-            for (int c = 0; c < pot.rows(l) && c < (int)v.size(); ++c) pot.biases[l][c] = v[c];
+            for (int c = 0; c < pot.rows(l) && c < (int)v.size(); ++c) B[c] = v[c];
         }
     }
     if (pot.has_symcoef) {

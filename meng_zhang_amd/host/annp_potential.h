@@ -25,7 +25,7 @@ struct Potential {
     int flagsym = 0;                       // Ch 0, Be/BP 1, Cu 2 (two-character probes, fe:415-417)
     std::vector<int> flagact;              // per weight layer: li 0, hy 1, si 2, mo 3, ta 4
     std::vector<double> norm_a, norm_b;    // Fe: sfnor_cov, sfnor_avg;  Ni: sf_min, sf_max
-    // weights[l] row-major [rows(l)][cols(l)], element 0
+    // weights[e * (ntl-1) + l]: element e, layer l, row-major [rows(l)][cols(l)]  (weights[l] is element 0)
     std::vector<std::vector<double>> weights, biases;
     bool has_symcoef = false;              // "#coefficent of symmetry funciton" section present
     std::vector<double> sym_rad;           // [npsf][3] eta, Rs, Rc
@@ -45,7 +45,10 @@ struct Potential {
 // nelements_coeff: number of distinct element names on the pair_coeff line.
 // Returns true on success; on failure `err` says why (text matches the reference's
 // error where it has one: "Cannot open neural network potential file").
-bool read_potential(const std::string &path, int nelements_coeff, Potential &pot, std::string &err);
+// blocks_by_name: nullptr = the reference's behaviour for files with several elements (every weight block lands in
+// element 0, see the .cpp); the pair_coeff element names = "#El" lines select the element of the blocks below them.
+bool read_potential(const std::string &path, int nelements_coeff, Potential &pot, std::string &err,
+                    const std::vector<std::string> *blocks_by_name = nullptr);
 
 // The `.anna` file of pair_style anna_adp, as PairANNA_ADP::read_file consumes it
 // (anna-gpu-lammps/bcc_fe/src/pair_anna_adp.cpp:392-566).

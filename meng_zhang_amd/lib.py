@@ -13,7 +13,7 @@ ABI_SYMBOLS = [
     "annp_hip_clear", "annp_hip_bytes", "annp_hip_last_error", "annp_hip_abi_version",
 ]
 PAIR_SYMBOLS = [
-    "annp_pair_create", "annp_pair_destroy", "annp_pair_settings", "annp_pair_coeff", "annp_pair_set_ni_compat",
+    "annp_pair_create", "annp_pair_destroy", "annp_pair_settings", "annp_pair_coeff", "annp_pair_set_ni_compat", "annp_pair_set_blocks_by_name",
     "annp_pair_init_style", "annp_pair_init_one", "annp_pair_compute", "annp_pair_compute_n",
     "annp_pair_memory_usage", "annp_pair_error", "annp_pair_handle", "annp_pair_potential_info",
     "annp_pair_potential_layer", "annp_pair_potential_sym", "annp_pair_create_style", "annp_pair_potential_anna",
@@ -66,6 +66,7 @@ def load_library():
     lib.annp_pair_settings.argtypes = [vp, C.c_int, cpp]
     lib.annp_pair_coeff.argtypes = [vp, C.c_int, cpp]
     lib.annp_pair_set_ni_compat.argtypes = [vp, C.c_int]
+    lib.annp_pair_set_blocks_by_name.argtypes = [vp, C.c_int]
     lib.annp_pair_init_style.argtypes = [vp, C.c_int, C.c_int]
     lib.annp_pair_init_one.argtypes = [vp, C.c_int, C.c_int]
     lib.annp_pair_init_one.restype = C.c_double

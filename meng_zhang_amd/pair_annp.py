@@ -103,6 +103,11 @@ class PairANNP:
     def set_ni_compat(self, on):
         self._lib.annp_pair_set_ni_compat(self._p, int(bool(on)))
 
+    def set_blocks_by_name(self, on):
+        """potential files with several elements: False (default) = the reference parser's behaviour (every weight
+        block lands in element 0), True = "#El" lines select the element of the blocks below them; before coeff()"""
+        self._lib.annp_pair_set_blocks_by_name(self._p, int(bool(on)))
+
     def init_style(self):
         self._check(self._lib.annp_pair_init_style(self._p, self.newton_pair, self.device))
 
@@ -179,13 +184,24 @@ class PairANNP:
                 self._check(ngp)
             nout = no.value
             out.update(nout=nout, e_base=eb.value, e_scal=es.value, gparams=gp[:ngp].copy())
-        for l in range(ntl - 1):
-            nr = nout if l == ntl - 2 else nnod
-            nc = nsf if l == 0 else nnod
-            w, b = np.zeros(nr * nc), np.zeros(nr)
-            self._check(self._lib.annp_pair_potential_layer(self._p, l, _dp(w), _dp(b)))
-            out["W"].append(w.reshape(nr, nc))
-            out["B"].append(b)
+        e = 0
+        while True:                         # element e, layer l sits at index e * (ntl-1) + l; W / B are element 0's
+            Ws, Bs = [], []
+            for l in range(ntl - 1):
+                nr = nout if l == ntl - 2 else nnod
+                nc = nsf if l == 0 else nnod
+                w, b = np.zeros(nr * nc), np.zeros(nr)
+                if self._lib.annp_pair_potential_layer(self._p, e * (ntl - 1) + l, _dp(w), _dp(b)) != 0:
+                    break
+                Ws.append(w.reshape(nr, nc))
+                Bs.append(b)
+            if len(Ws) != ntl - 1:
+                break
+            if e == 0:
+                out["W"], out["B"] = Ws, Bs
+            out.setdefault("W_elem", []).append(Ws)
+            out.setdefault("B_elem", []).append(Bs)
+            e += 1
         if has_sym:
             rad, ang = np.zeros(npsf * 3), np.zeros(ntsf * 4)
             self._check(self._lib.annp_pair_potential_sym(self._p, _dp(rad), _dp(ang)))

@@ -73,13 +73,30 @@ static int parse_row(const char *s, double *out, int maxn, int first_at_zero)
     return n;
 }
 
+static int read_file_impl(const char *path, int nelem_coeff, const char *const *names, int by_name,
+                          annp_oracle_pot *pots, int maxpots);
+
 int annp_oracle_read_file(const char *path, int nelem_coeff, annp_oracle_pot *pot)
+{
+    return read_file_impl(path, nelem_coeff, NULL, 0, pot, 1);
+}
+
+int annp_oracle_read_file_elems(const char *path, int nelem_coeff, const char *const *names, int by_name,
+                                annp_oracle_pot *pots, int maxpots)
+{
+    return read_file_impl(path, nelem_coeff, names, by_name, pots, maxpots);
+}
+
+/* pots[e] receives the header (identical for all) and the network of element e */
+static int read_file_impl(const char *path, int nelem_coeff, const char *const *names, int by_name,
+                          annp_oracle_pot *pots, int maxpots)
 {
     FILE *fp = fopen(path, "rb");
     char *line = NULL;
     size_t cap = 0;
+    annp_oracle_pot *pot = pots;
     if (!fp) return -1;
-    memset(pot, 0, sizeof(*pot));
+    memset(pots, 0, sizeof(*pots) * (size_t)maxpots);
 
     /* header: fe:347-434 (ni:339-430 identical apart from field names) */
     int ne = 0;
@@ -88,15 +105,16 @@ int annp_oracle_read_file(const char *path, int nelem_coeff, annp_oracle_pot *po
         size_t len = strlen(line);
         if (i == 5) {
             pot->nelements = ne = atoi(line);
-            if (ne != 1) { fclose(fp); free(line); return -3; }
+            if (ne < 1 || ne > maxpots) { fclose(fp); free(line); return -3; }
         }
         if (i >= 6 && i < 6 + ne) {                               /* fe:354-366 */
             int p = 0;
+            annp_oracle_pot *q = pots + (i - 6);
             for (size_t j = 0; j < len; j++) {
-                if (isalpha((unsigned char)line[j]) && p < 15) pot->element[p++] = line[j];
-                if (line[j] == '\t' && isdigit((unsigned char)line[j + 1])) pot->mass = atof(line + j + 1);
+                if (isalpha((unsigned char)line[j]) && p < 15) q->element[p++] = line[j];
+                if (line[j] == '\t' && isdigit((unsigned char)line[j + 1])) q->mass = atof(line + j + 1);
             }
-            pot->element[p] = 0;
+            q->element[p] = 0;
         }
         if (i == 8 + ne) {                                        /* fe:367-384 */
             int np = 1;
@@ -141,9 +159,35 @@ int annp_oracle_read_file(const char *path, int nelem_coeff, annp_oracle_pot *po
         if (i == 20 + ne) pot->e_atom = atof(line);
     }
 
-    /* weight / bias blocks: fe:450-517; ni:445-512 stops at "#coef" */
+    /* every element starts from the same header and a zero network (c_3d_matrix memsets, fe:441-448) */
+    for (int e = 1; e < ne; e++) {
+        char name[16];
+        double mass = pots[e].mass;
+        memcpy(name, pots[e].element, sizeof(name));
+        pots[e] = pots[0];
+        memcpy(pots[e].element, name, sizeof(name));
+        pots[e].mass = mass;
+    }
+    /* weight / bias blocks: fe:450-517; ni:445-512 stops at "#coef".
+     * Which element a block goes to: fe:455 declares `int type_elem = 0;` inside the line loop, so the match made on
+     * a "#El" line (fe:457-466) is gone when the next line ("#k_(weight)") is read -- EVERY block is stored in
+     * element 0 (the file's last one wins), elements 1.. keep zero weights.  (SURVEY.md 8a's "#Fe\r never equals Fe"
+     * is a second reason the match would fail; it never gets that far.)  by_name = 0 restates exactly that;
+     * by_name = 1 lets a "#El" line select the element of the blocks below it (test-only alternative, mirrored by the
+     * product's set_blocks_by_name). */
+    int cur = 0;
     while (read_line(fp, &line, &cap)) {
         if (strncmp(line, "#coef", 5) == 0) { pot->has_symcoef = 1; break; }
+        if (by_name && names && line[0] == '#' && isupper((unsigned char)line[1])) {
+            char nm[32];
+            int q = 0;
+            for (size_t i = 0; line[i] && q < 31; i++)
+                if (line[i] != '#' && line[i] != '\r' && line[i] != '\n' && line[i] != '\t' && line[i] != ' ') nm[q++] = line[i];
+            nm[q] = 0;
+            for (int k = 0; k < nelem_coeff && k < ne; k++) if (strcmp(nm, names[k]) == 0) cur = k;
+            continue;
+        }
+        pot = pots + cur;
         if (line[0] == '#' && isdigit((unsigned char)line[1])) {
             int no_layer = 0, flag_wb = 0;
             for (size_t i = 0; line[i]; i++) {
@@ -168,6 +212,8 @@ int annp_oracle_read_file(const char *path, int nelem_coeff, annp_oracle_pot *po
         }
     }
     if (pot->has_symcoef) {                                        /* ni:524-545 */
+        pots[0].has_symcoef = 1;
+        pot = pots;
         read_line(fp, &line, &cap);                                /* "#rad n" */
         for (int i = 0; i < pot->npsf; i++) {
             read_line(fp, &line, &cap);
@@ -178,6 +224,11 @@ int annp_oracle_read_file(const char *path, int nelem_coeff, annp_oracle_pot *po
             read_line(fp, &line, &cap);
             parse_row(line, pot->sym_ang[i], 4, 0);
         }
+    }
+    for (int e = 1; e < ne; e++) {                                 /* the coefficient section belongs to the file */
+        pots[e].has_symcoef = pots[0].has_symcoef;
+        memcpy(pots[e].sym_rad, pots[0].sym_rad, sizeof(pots[0].sym_rad));
+        memcpy(pots[e].sym_ang, pots[0].sym_ang, sizeof(pots[0].sym_ang));
     }
     fclose(fp);
     free(line);
@@ -797,6 +848,46 @@ int annp_oracle_compute(const annp_oracle_pot *pot, int kind, int strategy,
     if (eng) *eng += etot;
     if (virial) for (int m = 0; m < 6; m++) virial[m] += vtot[m];
     return 0;
+}
+
+/* Potentials with several elements: atom i is evaluated with the network of element map[type[i]]
+ * (fe:767-768 `params->all_annp[itype]`), the descriptor is species-blind.  A type that is not mapped (map < 0) has
+ * cutsq = 0 against everything (fe:144 `rsqij > cutsq[ritype][rjtype]` then rejects every pair with it): such atoms are
+ * neither neighbours nor centres.  pots[e] = element e's network (annp_oracle_read_file_elems). */
+int annp_oracle_compute_types(const annp_oracle_pot *pots, int nelem, int kind, int strategy,
+                              int nall, const double *x, const int *type, const int *map,
+                              int inum, const int *ilist, const int *numneigh,
+                              const long long *first, const int *neigh,
+                              double cutsq, int ni_calls,
+                              double *f, double *eatom, double *eng, double *virial, int nthreads)
+{
+    long long tot = 0;
+    for (int ii = 0; ii < inum; ii++) tot += numneigh[ilist[ii]];
+    int *nn = (int *)calloc((size_t)nall, sizeof(int));
+    long long *ff = (long long *)calloc((size_t)nall + 1, sizeof(long long));
+    int *ng = (int *)malloc(sizeof(int) * (size_t)(tot > 0 ? tot : 1));
+    int *il = (int *)malloc(sizeof(int) * (size_t)(inum > 0 ? inum : 1));
+    if (!nn || !ff || !ng || !il) { free(nn); free(ff); free(ng); free(il); return -3; }
+    long long w = 0;
+    for (int ii = 0; ii < inum; ii++) {                       /* rows without the unmapped neighbours, order kept */
+        const int i = ilist[ii];
+        ff[i] = w;
+        for (int jj = 0; jj < numneigh[i]; jj++) {
+            const int jraw = neigh[first[i] + jj];
+            if (map[type[jraw & NEIGHMASK]] >= 0) ng[w++] = jraw;
+        }
+        nn[i] = (int)(w - ff[i]);
+    }
+    int rc = 0;
+    for (int e = 0; e < nelem && rc == 0; e++) {
+        int m = 0;
+        for (int ii = 0; ii < inum; ii++) if (map[type[ilist[ii]]] == e) il[m++] = ilist[ii];
+        if (m > 0)
+            rc = annp_oracle_compute(pots + e, kind, strategy, nall, x, m, il, nn, ff, ng, cutsq, ni_calls,
+                                     f, eatom, eng, virial, NULL, NULL, nthreads);
+    }
+    free(nn); free(ff); free(ng); free(il);
+    return rc;
 }
 
 /* Per-atom virial, LITERAL strategy re-run with a force probe: the pair term of (i, j) is

@@ -24,7 +24,7 @@ extern "C" {
 #define ANNP_ORACLE_MAXLAY 6     /* max weight layers (ntl-1)          */
 
 /* Parsed potential, restating Param_ANNP (fe_v2/src/pair_annp.h:53-62,
- * ni/src/pair_annp.h:54-64).  Single element (index 0), as in every shipped file. */
+ * ni/src/pair_annp.h:54-64): the header of the file plus the network of ONE element. */
 typedef struct annp_oracle_pot {
     int nelements;
     int ntl, nhl, nnod, nsf, npsf, ntsf;
@@ -41,6 +41,13 @@ typedef struct annp_oracle_pot {
     double sym_ang[ANNP_ORACLE_MAXSF][4];   /* eta, lambda, zeta, Rc */
     char element[16];
 } annp_oracle_pot;
+
+/* Files with several elements: pots[e] receives the shared header and the network of element e.  names = the
+ * element names of the pair_coeff line (nelem_coeff of them).  by_name = 0 restates the reference parser, which stores
+ * every weight block in element 0 (fe_v2/src/pair_annp.cpp:455: `type_elem` is re-declared for every line) and leaves
+ * elements 1.. at zero; by_name = 1: a "#El" line selects the element of the blocks below it. */
+int annp_oracle_read_file_elems(const char *path, int nelem_coeff, const char *const *names, int by_name,
+                                annp_oracle_pot *pots, int maxpots);
 
 /* kinds of arithmetic (which reference translation unit is restated) */
 #define ANNP_ORACLE_FE        0   /* fe, fe_v2: Chebyshev descriptor, twisted tanh      */
@@ -75,6 +82,15 @@ int annp_oracle_compute(const annp_oracle_pot *pot, int kind, int strategy,
                         double cutsq, int ni_calls,
                         double *f, double *eatom, double *eng, double *virial,
                         double *Gout, double *dEdGout, int nthreads);
+
+/* annp_oracle_compute for a potential with several elements: type[nall] (LAMMPS types), map[ntypes+1]
+ * (type -> element, -1 = not mapped: such atoms are neither neighbours nor centres). */
+int annp_oracle_compute_types(const annp_oracle_pot *pots, int nelem, int kind, int strategy,
+                              int nall, const double *x, const int *type, const int *map,
+                              int inum, const int *ilist, const int *numneigh,
+                              const long long *first, const int *neigh,
+                              double cutsq, int ni_calls,
+                              double *f, double *eatom, double *eng, double *virial, int nthreads);
 
 /* Same evaluation, also tallying the per-atom virial vatom[nall*6] (+=) the way
  * ev_tally_xyz does with newton_pair on: half of each pair term to i, half to j. */

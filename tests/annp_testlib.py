@@ -89,6 +89,12 @@ def oracle_lib():
             C.c_double, C.c_int, dp, dp, dp, dp, dp, dp, C.c_int]
         lib.annp_oracle_compute.restype = C.c_int
         lib.annp_oracle_max_threads.restype = C.c_int
+        lib.annp_oracle_read_file_elems.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(OraclePot), C.c_int]
+        lib.annp_oracle_read_file_elems.restype = C.c_int
+        lib.annp_oracle_compute_types.argtypes = [
+            C.POINTER(OraclePot), C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, ip, C.c_int, ip, ip, lp, ip,
+            C.c_double, C.c_int, dp, dp, dp, dp, C.c_int]
+        lib.annp_oracle_compute_types.restype = C.c_int
         lib.annp_oracle_compute_vatom.argtypes = [C.POINTER(OraclePot), C.c_int, C.c_int, dp, C.c_int, ip, ip, lp, ip,
                                                   C.c_double, C.c_int, dp]
         lib.annp_oracle_compute_vatom.restype = C.c_int
@@ -123,6 +129,36 @@ def read_pot(path):
     if rc != 0:
         raise RuntimeError("annp_oracle_read_file(%s) -> %d" % (path, rc))
     return pot
+
+
+def read_pot_elems(path, names, by_name=False):
+    """the networks of a file with several elements: ctypes array of OraclePot, one per element name of the
+    pair_coeff line.  by_name=False restates the reference parser (everything lands in element 0)."""
+    ne = len(names)
+    pots = (OraclePot * ne)()
+    arr = (C.c_char_p * ne)(*[n.encode() for n in names])
+    rc = oracle_lib().annp_oracle_read_file_elems(path.encode(), ne, arr, int(bool(by_name)), pots, ne)
+    if rc != 0:
+        raise RuntimeError("annp_oracle_read_file_elems(%s) -> %d" % (path, rc))
+    return pots
+
+
+def oracle_compute_types(pots, sysm, kind, types, tmap, strategy=FAST, want_virial=False, nthreads=0):
+    """oracle_compute for atoms of several types: types[nall] (1-based LAMMPS types), tmap[ntypes+1] type -> element"""
+    lib = oracle_lib()
+    types = np.ascontiguousarray(types, dtype=np.int32)
+    tmap = np.ascontiguousarray(tmap, dtype=np.int32)
+    f = np.zeros((sysm.nall, 3))
+    eatom = np.zeros(sysm.nall)
+    eng = np.zeros(1)
+    vir = np.zeros(6) if want_virial else None
+    cutsq = pots[0].cut * pots[0].cut
+    rc = lib.annp_oracle_compute_types(pots, len(pots), kind, strategy, sysm.nall, _dp(sysm.x), _ip(types), _ip(tmap),
+                                       sysm.inum, _ip(sysm.ilist), _ip(sysm.numneigh), _lp(sysm.first), _ip(sysm.neigh),
+                                       cutsq, 1, _dp(f), _dp(eatom), _dp(eng), _dp(vir), nthreads)
+    if rc != 0:
+        raise RuntimeError("annp_oracle_compute_types -> %d" % rc)
+    return dict(f_all=f, f=sysm.fold(f), eatom=eatom[: sysm.nlocal], energy=float(eng[0]), virial=vir)
 
 
 def read_anna(path):
@@ -338,7 +374,7 @@ def check_cg_log(r0, r2, alpha_max):
 
 # ---------------------------------------------------------------- synthetic potential files
 def write_ann(path, npsf=9, ntsf=19, nnod=10, ntl=4, acts=("tanh", "tanh", "linear"), cut=6.5, seed=1, element="Fe",
-              behler=None):
+              behler=None, elements=None):
     """A .ann file in the layout the reference's read_file expects (same line positions, CRLF, tab-separated:
     fe_v2/src/pair_annp.cpp:335-585; ni/src/pair_annp.cpp:324-638) with seeded random weights.  Used to exercise
     network shapes, activation names and function sets the shipped potentials do not use.
@@ -346,6 +382,8 @@ def write_ann(path, npsf=9, ntsf=19, nnod=10, ntl=4, acts=("tanh", "tanh", "line
     (sf_min / sf_max normalisation, '#coefficent' section); npsf/ntsf are then taken from the rows."""
     assert len(acts) == ntl - 1
     rng = np.random.default_rng(seed)
+    elements = list(elements) if elements else [element]       # several: one block set per element, "#El" before each
+    element = elements[0]
     if behler is not None:
         npsf, ntsf = len(behler[0]), len(behler[1])
     nsf = npsf + ntsf
@@ -359,24 +397,26 @@ def write_ann(path, npsf=9, ntsf=19, nnod=10, ntl=4, acts=("tanh", "tanh", "line
     def row(v):
         return "\t".join("%.12f" % x for x in v) + "\t"
     L = ["#Source: synthetic test potential", "#Date: -", "#contact information: -", "",
-         "#element parameters_(nelement #n element mass)", "1", "1\t%s\t55.847" % element, "",
+         "#element parameters_(nelement #n element mass)", "%d" % len(elements)] + [
+         "%d\t%s\t%.3f" % (k + 1, el, 55.847 + k) for k, el in enumerate(elements)] + ["",
          "#artificial neural network parameters_(TL HL Nodes_HL Num_SF Num_PSF Num_TSF Cut) ",
          "%d\t%d\t%d\t%d\t%d\t%d\t%g " % (ntl, ntl - 2, nnod, nsf, npsf, ntsf, cut), "",
          "#symmetry function normization_(sfval_cov sfval_avg)", row(cov), row(avg), "",
          "#types of symmetry function and activation function", "Chebyshev\t" + "\t".join(acts), "",
          "#energy scale_(E_scale E_shift E_atom)", "0.80684104305538540", "-1019.0781365280557", "-3460.0000000000000", "",
          "#weight_bias_matrix_(#1.....#TL)"]
-    for l in range(ntl - 1):
-        nr = 1 if l == ntl - 2 else nnod
-        nc = nsf if l == 0 else nnod
-        W = rng.normal(0.0, 0.35, (nr, nc))
-        B = rng.normal(0.0, 0.5, nr)
-        L.append("#%s" % element)
-        L.append("#%d_(weight)" % (l + 1))
-        L.extend(row(W[r]) for r in range(nr))
-        L.append("#%d_(bias)" % (l + 1))
-        L.append(row(B))
-        L.append("")
+    for el in elements:
+        for l in range(ntl - 1):
+            nr = 1 if l == ntl - 2 else nnod
+            nc = nsf if l == 0 else nnod
+            W = rng.normal(0.0, 0.35, (nr, nc))
+            B = rng.normal(0.0, 0.5, nr)
+            L.append("#%s" % el)
+            L.append("#%d_(weight)" % (l + 1))
+            L.extend(row(W[r]) for r in range(nr))
+            L.append("#%d_(bias)" % (l + 1))
+            L.append(row(B))
+            L.append("")
     if behler is not None:
         L.append("#coefficent of symmetry funciton")
         L.append("#rad\t%d\t\t\t\t" % npsf)
