@@ -169,6 +169,13 @@ int annp_hip_neigh_build_device(annp_hip_handle *handle, int nlocal, int nall, c
                                 const int **d_numneigh, const long long **d_first, const int **d_neigh,
                                 int *max_numneigh, void *stream);
 
+/* Copies the list the device built last (annp_hip_compute_n / annp_hip_neigh_build_device) to the host, rows packed in
+ * atom order: numneigh[nlocal], first[nlocal+1] (nullable; offsets into neigh), neigh[neigh_capacity] (nullable: only
+ * counts and *total).  This is what lets annp_gpu_compute_n hand LAMMPS a firstneigh (lal_base_annp.cpp:159-175).
+ * Blocks until the device is idle. */
+int annp_hip_neigh_to_host(annp_hip_handle *handle, int nlocal, int *numneigh, long long *first, int *neigh,
+                           long long neigh_capacity, long long *total);
+
 /* Blocks until the handle's enqueued work is done and reports deferred device-side
  * errors (e.g. ANNP_HIP_ENEIGHCAP). */
 int annp_hip_sync(annp_hip_handle *handle);
@@ -203,6 +210,9 @@ double annp_hip_bytes(const annp_hip_handle *handle);
 const char *annp_hip_last_error(const annp_hip_handle *handle);
 
 int annp_hip_abi_version(void);
+
+/* HIP devices visible to this process (0 when there is none or the runtime cannot start) */
+int annp_hip_device_count(void);
 
 #ifdef __cplusplus
 }

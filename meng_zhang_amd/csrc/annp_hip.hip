@@ -488,6 +488,12 @@ extern "C" {
 
 int annp_hip_abi_version(void) { return ANNP_HIP_ABI_VERSION; }
 
+int annp_hip_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 const char *annp_hip_last_error(const annp_hip_handle *h) { return h ? h->err.c_str() : g_init_error.c_str(); }
 
 double annp_hip_bytes(const annp_hip_handle *h) { return h ? (double)h->bytes : 0.0; }
@@ -925,6 +931,37 @@ int annp_hip_neigh_build_device(annp_hip_handle *h, int nlocal, int nall, const 
     if (d_first) *d_first = h->nb.first;
     if (d_neigh) *d_neigh = h->nb.neigh;
     if (max_numneigh) *max_numneigh = h->nb.max_numneigh;
+    return 0;
+}
+
+int annp_hip_neigh_to_host(annp_hip_handle *h, int nlocal, int *numneigh, long long *first, int *neigh,
+                           long long neigh_capacity, long long *total_out)
+{
+    if (!h || nlocal < 0 || !numneigh) return h ? fail(h, ANNP_HIP_EARG, "neigh_to_host: bad argument") : ANNP_HIP_EARG;
+    if (!h->nb.valid || h->nb.nlocal != nlocal)
+        return fail(h, ANNP_HIP_EARG, "neigh_to_host: no device-built list for %d atoms on this handle", nlocal);
+    DEVICE_GUARD(h);
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (nlocal == 0) { if (total_out) *total_out = 0; return 0; }
+    HIP_TRY(h, hipMemcpy(numneigh, h->nb.numneigh, sizeof(int) * (size_t)nlocal, hipMemcpyDeviceToHost));
+    long long tot = 0;
+    for (int i = 0; i < nlocal; i++) { if (first) first[i] = tot; tot += numneigh[i]; }
+    if (first) first[nlocal] = tot;
+    if (total_out) *total_out = tot;
+    if (!neigh) return 0;
+    if (neigh_capacity < tot) return fail(h, ANNP_HIP_EARG, "neigh_to_host: room for %lld entries, the list has %lld", neigh_capacity, tot);
+    if (!h->nb.pitched) {           // exact CSR on the device: rows already packed in atom order
+        HIP_TRY(h, hipMemcpy(neigh, h->nb.neigh, sizeof(int) * (size_t)tot, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    const size_t pitch = (size_t)h->nb.pitch_used;
+    std::vector<int> raw((size_t)nlocal * pitch);
+    HIP_TRY(h, hipMemcpy(raw.data(), h->nb.neigh, sizeof(int) * raw.size(), hipMemcpyDeviceToHost));
+    long long w = 0;
+    for (int i = 0; i < nlocal; i++) {
+        std::memcpy(neigh + w, raw.data() + (size_t)i * pitch, sizeof(int) * (size_t)numneigh[i]);
+        w += numneigh[i];
+    }
     return 0;
 }
 

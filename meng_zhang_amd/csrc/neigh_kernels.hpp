@@ -22,6 +22,9 @@ struct NeighBuild {
     int nlocal = 0, nall = 0;
     bool valid = false;
     int pitch = 0;                  // row pitch learned from the last build (0 = none yet): next build tries one pass
+    bool pitched = false;           // layout of the current list: rows `pitch_used` apart (else exact CSR)
+    int pitch_used = 0;
+    double mean_exact = 0.0;        // list entries per atom found by the last exact (two-pass) build
     // scratch
     int *binof = nullptr, *bincount = nullptr, *binstart = nullptr, *binfill = nullptr, *binitems = nullptr;
     long long *blocksum = nullptr;
@@ -296,8 +299,17 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     auto learn_pitch = [&]() { nb.pitch = (nb.max_numneigh + nb.max_numneigh / 16 + 4 + 7) / 8 * 8; };
     // One pass when the previous build left a row pitch: the distance tests are the whole cost and the exact layout
     // needs them twice (count, then fill).  Rows that outgrow the pitch only show in the count; then fall through.
-    if (nb.pitch > 0 && (long long)nlocal * nb.pitch < (1ll << 33)) {
-        if (nb_alloc(nb.neigh, nb.cap_neigh, (size_t)nlocal * nb.pitch, nb.bytes, msg)) return -3;
+    // Not for very uneven systems (surfaces, voids: the maximum far above the mean makes the pitched array much larger than
+    // the exact one), and if its allocation fails the exact layout below is tried before giving up.
+    bool try_pitched = nb.pitch > 0 && (long long)nlocal * nb.pitch < (1ll << 33) &&
+                       (nb.mean_exact <= 0.0 || nb.pitch <= 1.5 * nb.mean_exact + 8.0);
+    if (try_pitched && nb_alloc(nb.neigh, nb.cap_neigh, (size_t)nlocal * nb.pitch, nb.bytes, msg)) {
+        try_pitched = false;
+        nb.pitch = 0;
+        msg.clear();
+        (void)hipGetLastError();
+    }
+    if (try_pitched) {
         NB_TRY(hipMemsetAsync(nb.dmax, 0, 4 * sizeof(long long), s));
         hipLaunchKernelGGL(annp_first_pitched, dim3((nall + 1 + 255) / 256), dim3(256), 0, s, nb.first, nall, nb.pitch);
         hipLaunchKernelGGL((annp_neigh_pass<true>), dim3(wb), dim3(256), 0, s, d_x, nb.xs, nlocal, g, rc2, nb.binof, nb.binstart, nb.binitems,
@@ -308,8 +320,9 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
         NB_TRY(hipStreamSynchronize(s));
         nb.max_numneigh = (int)(h1[0] & 0xffffffffll);
         const bool fits = nb.max_numneigh <= nb.pitch;
+        const int used = nb.pitch;
         learn_pitch();
-        if (fits) { nb.nlocal = nlocal; nb.nall = nall; nb.valid = true; return 0; }
+        if (fits) { nb.nlocal = nlocal; nb.nall = nall; nb.valid = true; nb.pitched = true; nb.pitch_used = used; return 0; }
         NB_TRY(hipMemsetAsync(nb.numneigh, 0, sizeof(int) * (size_t)nall, s));
     }
     hipLaunchKernelGGL((annp_neigh_pass<false>), dim3(wb), dim3(256), 0, s, d_x, nb.xs, nlocal, g, rc2, nb.binof, nb.binstart, nb.binitems,
@@ -331,7 +344,8 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
                        nb.numneigh, (const long long *)nb.first, nb.neigh, 0);
     NB_TRY(hipGetLastError());
     learn_pitch();
-    nb.nlocal = nlocal; nb.nall = nall; nb.valid = true;
+    nb.nlocal = nlocal; nb.nall = nall; nb.valid = true; nb.pitched = false; nb.pitch_used = 0;
+    nb.mean_exact = (double)total / (double)nlocal;
     return 0;
 #undef NB_TRY
 }

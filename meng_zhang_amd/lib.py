@@ -8,9 +8,9 @@ _LIB = None
 # symbols include/annp_hip.h declares
 ABI_SYMBOLS = [
     "annp_hip_init", "annp_hip_compute", "annp_hip_compute_n", "annp_hip_compute_device",
-    "annp_hip_neigh_build_device", "annp_hip_sync", "annp_hip_eval_info", "annp_hip_set_timing", "annp_hip_last_timing",
+    "annp_hip_neigh_build_device", "annp_hip_neigh_to_host", "annp_hip_sync", "annp_hip_eval_info", "annp_hip_set_timing", "annp_hip_last_timing",
     "annp_hip_timing_stats", "annp_hip_last_counts",
-    "annp_hip_clear", "annp_hip_bytes", "annp_hip_last_error", "annp_hip_abi_version",
+    "annp_hip_clear", "annp_hip_bytes", "annp_hip_last_error", "annp_hip_abi_version", "annp_hip_device_count",
 ]
 PAIR_SYMBOLS = [
     "annp_pair_create", "annp_pair_destroy", "annp_pair_settings", "annp_pair_coeff", "annp_pair_set_ni_compat", "annp_pair_set_blocks_by_name",
@@ -46,6 +46,7 @@ def load_library():
     lib.annp_hip_clear.argtypes = [vp]
     lib.annp_hip_clear.restype = None
     lib.annp_hip_sync.argtypes = [vp]
+    lib.annp_hip_neigh_to_host.argtypes = [vp, C.c_int, ip, lp, ip, C.c_longlong, lp]
     lib.annp_hip_eval_info.argtypes = [vp, ip]
     lib.annp_hip_set_timing.argtypes = [vp, C.c_int]
     lib.annp_hip_last_timing.argtypes = [vp, dp]
