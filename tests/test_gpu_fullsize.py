@@ -94,6 +94,48 @@ def test_sample_of_atoms_matches_oracle(big, fe_pot):
     assert np.abs(eatom[:m].cpu().numpy() - o["eatom"][:m]).max() < 1e-6
 
 
+def test_forces_of_an_interior_region_match_oracle(big, fe_pot):
+    """cfg2 forces against the oracle: the force on an atom collects a term from every centre
+    within Rc of it, and each of those needs its own neighbours within Rc -- so the oracle is run for all centres
+    within Rc of a core region, on the cluster of everything within 2 Rc of it; the core atoms' forces are then
+    complete and must equal the 1 M-atom GPU result.  Region in the middle of the box: no ghost is involved."""
+    e, f, eatom = big["evaluate"]()
+    dom, box = big["dom"], big["box"]
+    n = dom.nlocal
+    x = dom.x[:n].cpu().numpy()
+    centre = 0.5 * (box[:3] + box[3:]) + np.array([1.3, -0.7, 2.1])
+    r = np.linalg.norm(x - centre, axis=1)
+    r_core, rc = 15.0, 6.5
+    core = np.nonzero(r < r_core)[0]
+    centres = np.nonzero(r < r_core + rc + 0.2)[0]                   # + the displacements' reach
+    shell = np.nonzero((r >= r_core + rc + 0.2) & (r < r_core + 2 * rc + 0.4))[0]
+    assert core.size > 1000 and r.max() > r_core + 2 * rc + 10.0      # the cluster is far from the box faces
+    ids = np.concatenate([centres, shell])                            # centres first: the harness lists the first m atoms
+    s = System.__new__(System)
+    s.nlocal = s.inum = m = centres.size
+    s.nall = ids.size
+    s.nghost = s.nall - m
+    s.x = np.ascontiguousarray(x[ids])
+    s.type = np.ones(s.nall, dtype=np.int32)
+    ol = oracle_lib()
+    s.numneigh = np.zeros(s.nall, dtype=np.int32)
+    tot = ol.harness_neigh(m, s.nall, _dp(s.x), rc + 0.1, _ip(s.numneigh), None, None)
+    s.first = np.zeros(s.nall + 1, dtype=np.int64)
+    np.cumsum(s.numneigh, out=s.first[1:])
+    s.neigh = np.empty(int(tot), dtype=np.int32)
+    ol.harness_neigh(m, s.nall, _dp(s.x), rc + 0.1, _ip(s.numneigh), _lp(s.first), _ip(s.neigh))
+    s.ilist = np.arange(m, dtype=np.int32)
+    s.owner = np.zeros(s.nghost, dtype=np.int32)
+    o = oracle_compute(fe_pot, s, KIND_FE, FAST)
+    where = {g: k for k, g in enumerate(ids)}
+    k_core = np.array([where[g] for g in core])
+    f_gpu = f.cpu().numpy()[core]
+    f_ref = o["f_all"][k_core]
+    assert np.abs(f_gpu - f_ref).max() < 1e-5                                         # BASELINE.json's tolerance
+    assert np.abs(f_gpu - f_ref).max() < 1e-9 * max(1.0, np.abs(f_ref).max())         # what fp64 actually gives
+    assert np.abs(eatom.cpu().numpy()[centres] - o["eatom"][:m]).max() < 1e-6
+
+
 def test_nve_energy_conservation(big):
     """velocity-Verlet from rest over 40 fs.  Forces are the gradient of the reported energy, so
     E_pot + E_kin only shows the integrator's bounded O(dt^2) error: small against the kinetic
