@@ -9,9 +9,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -38,6 +44,58 @@ struct DevBuf {
 };
 
 }  // namespace
+
+// A few host threads that copy memory (the re-pack of LAMMPS' paged neighbour list into pinned staging).  They never
+// call HIP: every runtime call stays on the caller's thread.
+class CopyPool {
+   public:
+    explicit CopyPool(int n)
+    {
+        for (int t = 0; t < n; t++) workers_.emplace_back([this, t] { loop(t); });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (std::thread &w : workers_) w.join();
+    }
+    int size() const { return (int)workers_.size() + 1; }
+    // job(part, nparts) on every worker and on the caller; returns when all parts are done
+    void run(const std::function<void(int, int)> &job)
+    {
+        { std::lock_guard<std::mutex> g(m_); job_ = &job; left_ = (int)workers_.size(); gen_++; }
+        cv_.notify_all();
+        job((int)workers_.size(), size());
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return left_ == 0; });
+        job_ = nullptr;
+    }
+
+   private:
+    void loop(int t)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int, int)> *job;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                job = job_;
+            }
+            (*job)(t, size());
+            { std::lock_guard<std::mutex> g(m_); if (--left_ == 0) done_.notify_one(); }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int, int)> *job_ = nullptr;
+    unsigned long gen_ = 0;
+    int left_ = 0;
+    bool stop_ = false;
+};
 
 struct annp_hip_handle {
     int device = 0;
@@ -89,8 +147,16 @@ struct annp_hip_handle {
     // page faults and a second copy inside the runtime: ~3 ms per 1 M atoms)
     double *pin_f = nullptr, *pin_e = nullptr, *pin_v = nullptr;
     size_t pin_f_cap = 0, pin_e_cap = 0, pin_v_cap = 0;
-    std::vector<long long> h_first;
-    std::vector<int> h_numneigh, h_neigh;
+    // host-list upload (annp_hip_compute, ago == 0): CSR headers and the rows go through pinned staging; the rows in
+    // chunks, packed by a few threads while the previous chunk is on the wire
+    long long *pin_first = nullptr;
+    int *pin_num = nullptr;
+    size_t pin_hdr_cap = 0;             // atoms
+    static constexpr int kListBufs = 3;
+    static constexpr size_t kListChunk = (size_t)8 << 20;      // ints per staging buffer (32 MB)
+    int *pin_list[kListBufs] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_list[kListBufs] = {nullptr, nullptr, nullptr};
+    CopyPool *pool = nullptr;
     int list_max = 0;                   // max numneigh of the uploaded list
     bool list_valid = false;
     size_t bytes = 0;
@@ -520,6 +586,13 @@ void annp_hip_clear(annp_hip_handle *h)
     if (h->pin_f) (void)hipHostFree(h->pin_f);
     if (h->pin_e) (void)hipHostFree(h->pin_e);
     if (h->pin_v) (void)hipHostFree(h->pin_v);
+    if (h->pin_first) (void)hipHostFree(h->pin_first);
+    if (h->pin_num) (void)hipHostFree(h->pin_num);
+    for (int b = 0; b < annp_hip_handle::kListBufs; b++) {
+        if (h->pin_list[b]) (void)hipHostFree(h->pin_list[b]);
+        if (h->ev_list[b]) (void)hipEventDestroy(h->ev_list[b]);
+    }
+    delete h->pool;
     if (h->h_scalars) (void)hipHostFree(h->h_scalars);
     for (hipEvent_t e : h->evring) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1040,6 +1113,82 @@ static int host_evaluate(annp_hip_handle *h, int inum, int nall, const int *host
     }
 }
 
+// LAMMPS' list (ilist, numneigh[i], firstneigh[i] pointing into its pages) -> CSR on the device.
+// 230 M entries at 1 M atoms: the rows are packed into pinned staging buffers of 32 MB by a few host threads and each
+// buffer goes out with its own asynchronous copy, so packing chunk c + 1 overlaps the transfer of chunk c; the
+// headers take the same road.  (A single-threaded pack into pageable memory and one blocking copy cost 250 ms.)
+static int upload_host_list(annp_hip_handle *h, int inum, int nall, const int *ilist, const int *numj,
+                            const int *const *firstneigh, hipStream_t s)
+{
+    int rc;
+    if ((size_t)nall + 1 > h->pin_hdr_cap) {
+        if (h->pin_first) { (void)hipHostFree(h->pin_first); h->pin_first = nullptr; }
+        if (h->pin_num) { (void)hipHostFree(h->pin_num); h->pin_num = nullptr; }
+        const size_t want = (size_t)nall + 1 + (size_t)nall / 8;
+        HIP_TRY(h, hipHostMalloc((void **)&h->pin_first, want * sizeof(long long)));
+        HIP_TRY(h, hipHostMalloc((void **)&h->pin_num, want * sizeof(int)));
+        h->pin_hdr_cap = want;
+    }
+    for (int b = 0; b < annp_hip_handle::kListBufs; b++) {
+        if (!h->pin_list[b]) HIP_TRY(h, hipHostMalloc((void **)&h->pin_list[b], annp_hip_handle::kListChunk * sizeof(int)));
+        if (!h->ev_list[b]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_list[b], hipEventDisableTiming));
+    }
+    if (!h->pool) {
+        const unsigned hc = std::thread::hardware_concurrency();
+        int nthr = (int)std::min<unsigned>(hc ? hc : 4u, 16u);
+        if (const char *e = std::getenv("ANNP_HIP_COPY_THREADS")) nthr = std::max(1, std::atoi(e));
+        h->pool = new (std::nothrow) CopyPool(nthr - 1);
+        if (!h->pool) return fail(h, ANNP_HIP_ENOMEM, "host allocation failed");
+    }
+    // headers: offsets in ilist order
+    std::memset(h->pin_first, 0, sizeof(long long) * ((size_t)nall + 1));
+    std::memset(h->pin_num, 0, sizeof(int) * (size_t)nall);
+    long long tot = 0;
+    int mx = 0;
+    for (int ii = 0; ii < inum; ii++) {
+        const int i = ilist[ii];
+        if (i < 0 || i >= nall) return fail(h, ANNP_HIP_EARG, "ilist[%d]=%d out of range", ii, i);
+        h->pin_first[i] = tot;
+        h->pin_num[i] = numj[i];
+        tot += numj[i];
+        mx = std::max(mx, numj[i]);
+    }
+    if (mx > (int)annp_hip_handle::kListChunk) return fail(h, ANNP_HIP_ENEIGHCAP, "a list row has %d entries", mx);
+    if ((rc = ensure(h, h->first, (size_t)nall + 1)) || (rc = ensure(h, h->numneigh, (size_t)nall)) ||
+        (rc = ensure(h, h->neigh, (size_t)std::max<long long>(tot, 1))) || (rc = ensure(h, h->ilist, (size_t)std::max(inum, 1))))
+        return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->first.p, h->pin_first, sizeof(long long) * ((size_t)nall + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->numneigh.p, h->pin_num, sizeof(int) * (size_t)nall, hipMemcpyHostToDevice, s));
+    if (inum > 0) HIP_TRY(h, hipMemcpyAsync(h->ilist.p, ilist, sizeof(int) * (size_t)inum, hipMemcpyHostToDevice, s));
+    // rows, chunk by chunk (whole rows per chunk)
+    int ii0 = 0, chunk = 0;
+    while (ii0 < inum) {
+        const long long base = h->pin_first[ilist[ii0]];
+        int ii1 = ii0;
+        long long fill = 0;
+        while (ii1 < inum && fill + numj[ilist[ii1]] <= (long long)annp_hip_handle::kListChunk) fill += numj[ilist[ii1++]];
+        const int b = chunk % annp_hip_handle::kListBufs;
+        if (chunk >= annp_hip_handle::kListBufs) HIP_TRY(h, hipEventSynchronize(h->ev_list[b]));      // its previous copy has left
+        int *dst = h->pin_list[b];
+        const long long *pf = h->pin_first;
+        h->pool->run([=](int part, int nparts) {
+            const int span = ii1 - ii0, lo = ii0 + (int)((long long)span * part / nparts), hi = ii0 + (int)((long long)span * (part + 1) / nparts);
+            for (int ii = lo; ii < hi; ii++) {
+                const int i = ilist[ii];
+                if (numj[i] > 0) std::memcpy(dst + (pf[i] - base), firstneigh[i], sizeof(int) * (size_t)numj[i]);
+            }
+        });
+        if (fill > 0) HIP_TRY(h, hipMemcpyAsync(h->neigh.p + base, dst, sizeof(int) * (size_t)fill, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipEventRecord(h->ev_list[b], s));
+        ii0 = ii1;
+        chunk++;
+    }
+    HIP_TRY(h, hipStreamSynchronize(s));     // ilist and the staging buffers are the caller's / reused
+    h->list_max = mx;
+    h->list_valid = true;
+    return 0;
+}
+
 int annp_hip_compute(annp_hip_handle *h, int ago, int inum, int nall, int nghost,
                      const double *host_x, const int *host_type,
                      const int *ilist, const int *numj, const int *const *firstneigh,
@@ -1056,33 +1205,7 @@ int annp_hip_compute(annp_hip_handle *h, int ago, int inum, int nall, int nghost
     int rc;
     // neighbour list: re-packed to CSR and uploaded when LAMMPS rebuilt it (ago == 0)
     if (ago == 0 || !h->list_valid) {
-        h->h_first.assign((size_t)nall + 1, 0);
-        h->h_numneigh.assign((size_t)nall, 0);
-        long long tot = 0;
-        int mx = 0;
-        for (int ii = 0; ii < inum; ii++) {
-            const int i = ilist[ii];
-            if (i < 0 || i >= nall) return fail(h, ANNP_HIP_EARG, "ilist[%d]=%d out of range", ii, i);
-            h->h_first[i] = tot;
-            h->h_numneigh[i] = numj[i];
-            tot += numj[i];
-            mx = std::max(mx, numj[i]);
-        }
-        h->h_neigh.resize((size_t)std::max<long long>(tot, 1));
-        for (int ii = 0; ii < inum; ii++) {
-            const int i = ilist[ii];
-            if (numj[i] > 0) std::memcpy(h->h_neigh.data() + h->h_first[i], firstneigh[i], sizeof(int) * (size_t)numj[i]);
-        }
-        if ((rc = ensure(h, h->first, (size_t)nall + 1)) || (rc = ensure(h, h->numneigh, (size_t)nall)) ||
-            (rc = ensure(h, h->neigh, h->h_neigh.size())) || (rc = ensure(h, h->ilist, (size_t)std::max(inum, 1))))
-            return rc;
-        HIP_TRY(h, hipMemcpyAsync(h->first.p, h->h_first.data(), sizeof(long long) * ((size_t)nall + 1), hipMemcpyHostToDevice, s));
-        HIP_TRY(h, hipMemcpyAsync(h->numneigh.p, h->h_numneigh.data(), sizeof(int) * (size_t)nall, hipMemcpyHostToDevice, s));
-        HIP_TRY(h, hipMemcpyAsync(h->neigh.p, h->h_neigh.data(), sizeof(int) * h->h_neigh.size(), hipMemcpyHostToDevice, s));
-        if (inum > 0) HIP_TRY(h, hipMemcpyAsync(h->ilist.p, ilist, sizeof(int) * (size_t)inum, hipMemcpyHostToDevice, s));
-        HIP_TRY(h, hipStreamSynchronize(s));     // h_* are reused next rebuild
-        h->list_max = mx;
-        h->list_valid = true;
+        if ((rc = upload_host_list(h, inum, nall, ilist, numj, firstneigh, s))) return rc;
     }
     if ((rc = ensure(h, h->x, (size_t)nall * 3))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->x.p, host_x, sizeof(double) * (size_t)nall * 3, hipMemcpyHostToDevice, s));
