@@ -33,6 +33,12 @@ constexpr int NI_RED = 9;         // sums per LDS reduction round (desc)
 constexpr int NI_REDROW = 17;     // padded row of 16 lane partials
 constexpr int NI_CH = 16;         // trips per chunk of the pair pre-pass: 256 pair slots per atom
 constexpr int NI_PLIST = NI_CH * NI_GL;   // in-range pair list per atom (ushort: a | b << 8)
+// Force pass: a wave takes NI_RUN consecutive groups of four atoms (16 atoms: four fcc cells of a row reference 304 atoms,
+// ~80 of them distinct) and sends their force contributions through a wave-private table keyed by atom index, flushed
+// with one global atomic per distinct atom and component at the end of the run (same scheme as annp_anna_adp).
+constexpr int NI_RUN = 4;
+constexpr int NI_TSLOTS = 128;
+constexpr int NI_TPROBE = 8;
 #ifndef NI_WAVES_PER_SIMD
 #define NI_WAVES_PER_SIMD 4     // descriptor pass: 512 / 4 = 128 VGPRs
 #endif
@@ -70,7 +76,8 @@ __host__ __device__ inline int ni_coef_stride(int nsf) { return nsf | 1; }
 __host__ __device__ inline size_t ni_lds_per_wave(int cap, bool force, int nsf)
 {
     const size_t R = (size_t)NI_GA * cap + 2;          // + two dummy records for idle lanes
-    size_t b = R * 7 * 8 + (force ? R * 3 * 8 + (size_t)NI_GA * ni_coef_stride(nsf) * 8 : 0) + R * 4 + NI_GA * 4 + (size_t)NI_GA * NI_PLIST * 2;
+    size_t b = R * 7 * 8 + (force ? R * 3 * 8 + (size_t)NI_GA * ni_coef_stride(nsf) * 8 + (size_t)NI_TSLOTS * (3 * 8 + 4) : 0) + R * 4 + NI_GA * 4 +
+               (size_t)NI_GA * NI_PLIST * 2;
     const size_t scratch = (size_t)NI_GA * NI_RED * NI_REDROW * 8;
     if (!force && b < scratch) b = scratch;
     return (b + 15) / 16 * 16;
@@ -341,6 +348,8 @@ struct NiLds {
     double *dx, *dy, *dz, *r, *rinv, *fc, *dfc;   // [NI_GA * cap] each, atom g at g*cap
     double *a0, *a1, *a2;                         // force accumulators (force pass)
     double *coef;                                 // [NI_GA][stride] weights: radial, then angular in visit order
+    double *tacc;                                 // [NI_TSLOTS][3] force table of the run (force pass)
+    int *tkey;                                    // [NI_TSLOTS]
     int *j;                                       // [NI_GA * cap]
     int *ci;                                      // [NI_GA] atom index of each group, -1 = none
     unsigned short *pl;                           // [NI_GA][NI_PLIST] in-range pairs of the current chunk
@@ -354,11 +363,14 @@ __device__ __forceinline__ NiLds ni_carve(unsigned char *wbase, int cap, int cst
     double *d = reinterpret_cast<double *>(wbase);
     L.dx = d; L.dy = L.dx + R; L.dz = L.dy + R; L.r = L.dz + R; L.rinv = L.r + R; L.fc = L.rinv + R; L.dfc = L.fc + R;
     d = L.dfc + R;
-    L.a0 = L.a1 = L.a2 = L.coef = nullptr;
-    if (FORCE) { L.a0 = d; L.a1 = L.a0 + R; L.a2 = L.a1 + R; L.coef = L.a2 + R; d = L.coef + NI_GA * cstride; }
+    L.a0 = L.a1 = L.a2 = L.coef = L.tacc = nullptr;
+    L.tkey = nullptr;
+    if (FORCE) { L.a0 = d; L.a1 = L.a0 + R; L.a2 = L.a1 + R; L.coef = L.a2 + R; L.tacc = L.coef + NI_GA * cstride; d = L.tacc + 3 * NI_TSLOTS; }
     L.j = reinterpret_cast<int *>(d);
     L.ci = L.j + R;
-    L.pl = reinterpret_cast<unsigned short *>(L.ci + NI_GA);
+    int *after = L.ci + NI_GA;
+    if (FORCE) { L.tkey = after; after += NI_TSLOTS; }
+    L.pl = reinterpret_cast<unsigned short *>(after);
     return L;
 }
 
@@ -714,8 +726,8 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int ii0 = uniform((xcd_block() * ANNP_WAVES_PER_BLOCK + wave) * NI_GA);
-    if (ii0 >= p.inum) return;
+    const int run = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
+    if (run * NI_RUN * NI_GA >= p.inum) return;
     const int nsf = p.npsf + p.ntsf;
     const int cap = p.n_cap;
     const int cstride = ni_coef_stride(nsf);
@@ -726,6 +738,26 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     unsigned char *wbase = lds_raw + NI_TABLE_DOUBLES * 8 + (size_t)wave * ni_lds_per_wave(cap, true, nsf);
     const NiLds L = ni_carve<true>(wbase, cap, cstride);
     const int g = lane >> 4, l = lane & 15;
+    for (int sl = lane; sl < NI_TSLOTS; sl += 64) { L.tkey[sl] = -1; L.tacc[3 * sl] = 0.0; L.tacc[3 * sl + 1] = 0.0; L.tacc[3 * sl + 2] = 0.0; }
+    // add a force to atom j's entry of the run's table; after NI_TPROBE occupied slots it goes straight to global memory
+    auto table_add = [&](int j, double fx, double fy, double fz) {
+        unsigned sl = ((unsigned)j * 0x9E3779B1u) >> 25;
+#pragma unroll 1
+        for (int probe = 0; probe < NI_TPROBE; probe++) {
+            const int old = atomicCAS(&L.tkey[sl], -1, j);
+            if (old == -1 || old == j) {
+                atomicAdd(&L.tacc[3 * sl], fx); atomicAdd(&L.tacc[3 * sl + 1], fy); atomicAdd(&L.tacc[3 * sl + 2], fz);
+                return;
+            }
+            sl = (sl + 1) & (NI_TSLOTS - 1);
+        }
+        atomicAdd(&p.f[3 * (size_t)j], fx); atomicAdd(&p.f[3 * (size_t)j + 1], fy); atomicAdd(&p.f[3 * (size_t)j + 2], fz);
+    };
+#pragma unroll 1
+    for (int gk = 0; gk < NI_RUN; gk++) {
+    const int ii0 = uniform((run * NI_RUN + gk) * NI_GA);
+    if (ii0 >= p.inum) break;
+    ni_forget_lds();            // nothing read from the LDS tables is carried from one group to the next in registers
     // this wave's coefficient rows: radial as they are, angular in visit order
     for (int idx = lane; idx < NI_GA * nsf; idx += 64) {
         const int gq = idx / nsf, k = idx % nsf;
@@ -735,7 +767,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     }
     int nl;
     const int nmax = ni_stage_compact(p, ii0, L, T, lane, nl);
-    if (nmax > cap) { if (lane == 0) atomicMax(p.errflag, nmax); return; }
+    if (nmax > cap) { if (lane == 0) atomicMax(p.errflag, nmax); wave_lds_sync(); continue; }
     wave_lds_sync();
     const double *cr = L.coef + g * cstride;        // radial weights of this lane's atom
     const double *cw = cr + p.npsf;                 // angular, visit order
@@ -820,9 +852,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
                 g0 = fma(sc, d0, g0); g1 = fma(sc, d1, g1); g2 = fma(sc, d2, g2);
             }
             const int j = L.j[s];
-            atomicAdd(&p.f[3 * (size_t)j], -g0 * ANNP_CFFORCE);       // ni:186-189
-            atomicAdd(&p.f[3 * (size_t)j + 1], -g1 * ANNP_CFFORCE);
-            atomicAdd(&p.f[3 * (size_t)j + 2], -g2 * ANNP_CFFORCE);
+            table_add(j, -g0 * ANNP_CFFORCE, -g1 * ANNP_CFFORCE, -g2 * ANNP_CFFORCE);       // ni:186-189
             fi0 += g0; fi1 += g1; fi2 += g2;
             if (VIRIAL) {       // the reference tallies the un-converted force (ni:190-198)
                 const double w0 = d0 * g0, w1 = d1 * g1, w2 = d2 * g2, w3 = d0 * g1, w4 = d0 * g2, w5 = d1 * g2;
@@ -841,11 +871,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     for (int off = 8; off > 0; off >>= 1) {
         fi0 += __shfl_xor(fi0, off, 64); fi1 += __shfl_xor(fi1, off, 64); fi2 += __shfl_xor(fi2, off, 64);
     }
-    if (l == 0 && i >= 0) {
-        atomicAdd(&p.f[3 * (size_t)i], fi0 * ANNP_CFFORCE);
-        atomicAdd(&p.f[3 * (size_t)i + 1], fi1 * ANNP_CFFORCE);
-        atomicAdd(&p.f[3 * (size_t)i + 2], fi2 * ANNP_CFFORCE);
-    }
+    if (l == 0 && i >= 0) table_add(i, fi0 * ANNP_CFFORCE, fi1 * ANNP_CFFORCE, fi2 * ANNP_CFFORCE);
     if (VIRIAL) {
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
@@ -867,6 +893,17 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
                 atomicAdd(&p.virial[0], v0); atomicAdd(&p.virial[1], v1); atomicAdd(&p.virial[2], v2);
                 atomicAdd(&p.virial[3], v3); atomicAdd(&p.virial[4], v4); atomicAdd(&p.virial[5], v5);
             }
+        }
+    }
+    wave_lds_sync();            // the next group of the run reuses the records
+    }
+    // flush the run's table: one global atomic per distinct atom and component
+    wave_lds_sync();
+    for (int sl = lane; sl < NI_TSLOTS; sl += 64) {
+        const int j = L.tkey[sl];
+        if (j >= 0) {
+            atomicAdd(&p.f[3 * (size_t)j], L.tacc[3 * sl]); atomicAdd(&p.f[3 * (size_t)j + 1], L.tacc[3 * sl + 1]);
+            atomicAdd(&p.f[3 * (size_t)j + 2], L.tacc[3 * sl + 2]);
         }
     }
 }
@@ -911,7 +948,8 @@ inline int ni_launch_desc(const NiArgs &a, NiShape sh, hipStream_t s)
 inline void ni_launch_force(const NiArgs &a, NiShape sh, bool virial, hipStream_t s)
 {
     const size_t lds = ni_lds_block(a.n_cap, true, a.npsf + a.ntsf);
-    const int blocks = ni_blocks(a.inum);
+    const int per_block = ANNP_WAVES_PER_BLOCK * NI_GA * NI_RUN;
+    const int blocks = (a.inum + per_block - 1) / per_block;
     if (ni_is_shipped_shape(a, sh)) {
         if (virial) hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, true>), dim3(blocks), dim3(256), lds, s, a);
         else hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, false>), dim3(blocks), dim3(256), lds, s, a);
