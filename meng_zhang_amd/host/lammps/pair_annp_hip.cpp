@@ -80,8 +80,9 @@ void PairANNPHIP::init_style()
   const int rc = impl->init_style(force->newton_pair, device_id);
   if (rc != 0) error->all(FLERR, impl->error());     // GPU_EXTRA::check_flag equivalent
   const char *nm = std::getenv("ANNP_HIP_NEIGH");
-  device_neigh = (nm && std::strcmp(nm, "device") == 0) ? 1 : 0;
-  // host list (gpu_mode == GPU_FORCE, pair_annp_gpu.cpp:228-236) unless the device builds its own
+  device_neigh = (nm && std::strcmp(nm, "host") == 0) ? 0 : 1;
+  // the device builds its own list (only positions and forces cross PCIe) unless ANNP_HIP_NEIGH=host asks for
+  // LAMMPS' list (gpu_mode == GPU_FORCE, pair_annp_gpu.cpp:228-236)
   if (!device_neigh) neighbor->add_request(this, NeighConst::REQ_FULL); // fe_v2/src/pair_annp.cpp:317
 }
 
