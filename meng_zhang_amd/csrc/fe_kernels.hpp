@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
+    const int ii = uniform(xcd_block() * (int)(blockDim.x >> 6) + wave);
     if (ii >= p.inum) return;
     unsigned char *wbase = lds_raw + (size_t)wave * fe_desc_lds_per_wave(p.n_cap);
     double2 *recA = reinterpret_cast<double2 *>(wbase);
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
+    const int ii = uniform(xcd_block() * (int)(blockDim.x >> 6) + wave);
     if (ii >= p.inum) return;
     fe_force_atom<NP, NT, VIRIAL, AUXREG>(p, ii, lane, lds_raw + (size_t)wave * fe_force_lds_per_wave(p.n_cap, AUXREG));
 }
