@@ -365,7 +365,9 @@ void launch_fe_force(const FeArgs &a, hipStream_t s)
 {
     const int wpb = fe_wpb_force();
     const int blocks = (a.inum + wpb - 1) / wpb;
-    if (fe_force_auxreg(a.n_cap))
+    if (a.n_cap == 128)         // the capacity of a bcc-Fe box: layout offsets are compile-time constants
+        hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, VIR, true, 128>), dim3(blocks), dim3(64 * wpb), fe_force_lds_per_wave(128, true) * wpb, s, a);
+    else if (fe_force_auxreg(a.n_cap))
         hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, VIR, true>), dim3(blocks), dim3(64 * wpb), fe_force_lds_per_wave(a.n_cap, true) * wpb, s, a);
     else
         hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, VIR, false>), dim3(blocks), dim3(64 * wpb), fe_force_lds_per_wave(a.n_cap, false) * wpb, s, a);
@@ -883,6 +885,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_fixup<FE_NP, FE_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_fixup<FE_NP, FE_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(ni_set_lds_attributes());

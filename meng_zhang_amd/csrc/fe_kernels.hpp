@@ -32,7 +32,7 @@ constexpr int FE_NP = 9;      // radial Chebyshev orders the kernels are instant
 constexpr int FE_NT = 19;     // angular orders (T_0..T_18); smaller bases are embedded with zero weights (annp_hip_init)
 constexpr int FE_Q = 4;       // chunks per tournament row
 constexpr int FE_REDROW = 72; // row pitch (doubles) of the reduction scratch: rows 16 banks apart, see annp_fe_desc
-constexpr int FE_DUMP = 8;    // null / dump slots behind the records: where masked-off pair steps read and scatter
+constexpr int FE_DUMP = 4;    // null / dump slots behind the records: where masked-off pair steps read and scatter
 
 struct FeArgs {
     int inum;
@@ -68,27 +68,30 @@ struct FeArgs {
 //   [0,n)            the in-cutoff neighbours
 //   [n,n+L)          copies of records 0..L-1, so a run of L consecutive partners never wraps
 //   [NZ,NZ+FE_DUMP)  null records (fc = 0); NZ = n_cap + fe_lcap(n_cap)
-// The force pass keeps 5 accumulators (40 B) per record slot in a parallel array.
-__host__ __device__ inline int fe_lcap(int n_cap) { return n_cap / 8 + 1; }       // >= ceil(floor(n/2)/FE_Q)
-__host__ __device__ inline int fe_slots(int n_cap) { return n_cap + fe_lcap(n_cap) + FE_DUMP; }
+// The force pass keeps 4 accumulators per record slot, one array per component (consecutive slots = consecutive
+// 8-byte words: the 64 distinct targets of a pair step never share a bank).
+__host__ __device__ constexpr int fe_lcap(int n_cap) { return (n_cap + 7) / 8; }   // >= ceil(floor(n/2)/FE_Q) for every n <= n_cap
+__host__ __device__ constexpr int fe_slots(int n_cap) { return n_cap + fe_lcap(n_cap) + FE_DUMP; }
 __host__ __device__ inline size_t fe_desc_lds_per_wave(int n_cap)
 {
     size_t rec = (size_t)fe_slots(n_cap) * 32;      // multiple of 16: every wave's base stays b128-aligned
     return rec < 8 * FE_REDROW * 8 + 512 ? 8 * FE_REDROW * 8 + 512 : rec;     // reduction scratch [8][FE_REDROW] + [64] results
 }
-// AUXREG (n_cap <= 128): a lane owns neighbours lane and lane+64 and keeps their 1/r and fc' in registers;
+// AUXREG (n_cap <= 128): a lane owns neighbours lane and lane+64 and keeps their 1/r, fc' and radial term in registers;
 // otherwise they live in LDS.  The neighbour index always does (it is written by the compacting lane).
-__host__ __device__ inline bool fe_force_auxreg(int n_cap) { return n_cap <= 128; }
-__host__ __device__ inline size_t fe_force_lds_per_wave(int n_cap, bool auxreg)
+// n_cap = 128 (the capacity of a bcc-Fe box: 112 in-cutoff neighbours + thermal spread) gives 148 slots * 64 B + 512 B
+// = 9 984 B per wave: four 4-wave workgroups per CU, 4 waves per SIMD.  (5 accumulators at a 40-byte pitch made it 11.3 KB
+// and 3 waves per SIMD.)
+__host__ __device__ constexpr bool fe_force_auxreg(int n_cap) { return n_cap <= 128; }
+__host__ __device__ constexpr size_t fe_force_lds_per_wave(int n_cap, bool auxreg)
 {
-    const size_t b = (size_t)fe_slots(n_cap) * (32 + 40) + (size_t)n_cap * (auxreg ? 4 : 16 + 4);
-    return (b + 15) & ~(size_t)15;                  // every wave's base stays b128-aligned
+    return (((size_t)fe_slots(n_cap) * (32 + 32) + (size_t)n_cap * (auxreg ? 4 : 24 + 4)) + 15) & ~(size_t)15;   // b128-aligned bases
 }
-__host__ __device__ inline size_t fe_force_lds_per_wave(int n_cap) { return fe_force_lds_per_wave(n_cap, fe_force_auxreg(n_cap)); }
+__host__ __device__ constexpr size_t fe_force_lds_per_wave(int n_cap) { return fe_force_lds_per_wave(n_cap, fe_force_auxreg(n_cap)); }
 
 // ---- stage A, first sweep: candidates -> compacted raw entries (dx,dy | dz,r^2) [+ index]
 template <bool WITH_J>
-__device__ __forceinline__ int fe_compact(const FeArgs &p, int i, int lane, double2 *recA, double2 *recB, int *auxJ)
+__device__ __forceinline__ int fe_compact(const FeArgs &p, int i, int lane, double2 *recA, double2 *recB, int *auxJ, const int n_cap)
 {
     const double xi = p.x[3 * (size_t)i], yi = p.x[3 * (size_t)i + 1], zi = p.x[3 * (size_t)i + 2];
     const long long base = p.first[i];
@@ -119,7 +122,7 @@ __device__ __forceinline__ int fe_compact(const FeArgs &p, int i, int lane, doub
             const bool in = valid[u] && !(rsq > p.cutsq) && !(rsq < 1.0e-12);        // fe:144
             const unsigned long long m = __ballot(in);
             const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-            if (in && pos < p.n_cap) {
+            if (in && pos < n_cap) {
                 recA[pos] = make_double2(dx[u], dy[u]);
                 recB[pos] = make_double2(dz[u], rsq);
                 if (WITH_J) auxJ[pos] = j[u];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
         if (lane < ANNP_GPAD) p.G[(size_t)ii * ANNP_GPAD + lane] = 0.0;
         return;
     }
-    const int n = fe_compact<false>(p, i, lane, recA, recB, nullptr);
+    const int n = fe_compact<false>(p, i, lane, recA, recB, nullptr, p.n_cap);
     if (p.ncount && lane == 0) p.ncount[ii] = n;
     if (n > p.n_cap) {                      // capacity exceeded: report, leave G zero
         if (lane == 0) atomicMax(p.errflag, n);
@@ -362,21 +365,24 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
 //   (5 doubles) with LDS atomics into the accumulator slot that parallels the record slot
 //   (copies behind n have their own accumulators, folded back at the end).
 // ---------------------------------------------------------------------------------
-template <int NP, int NT, bool VIRIAL, bool AUXREG>
+// NCAP: record capacity fixed at compile time (128: every offset of the LDS layout becomes an immediate operand of the
+// ds instructions and the pair loop advances two address registers), 0 = p.n_cap at run time
+template <int NP, int NT, bool VIRIAL, bool AUXREG, int NCAP>
 __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, const int lane, unsigned char *wbase)
 {
-    const int nslot = fe_slots(p.n_cap);
-    const int NZ = p.n_cap + fe_lcap(p.n_cap);
+    const int n_cap = NCAP ? NCAP : p.n_cap;
+    const int nslot = fe_slots(n_cap);
+    const int NZ = n_cap + fe_lcap(n_cap);
     double2 *recA = reinterpret_cast<double2 *>(wbase);
     double2 *recB = recA + nslot;
-    // 5 accumulators per slot (stride 40 B: the 16 lanes of an LDS pass land on 16 distinct even
-    // banks, so 64-bit atomics of consecutive b stay conflict-free and share one address register):
-    //   [0..2] V = sum alpha e_b   [3] S = sum P fc_b   [4] C = sum alpha cos
+    // 4 accumulators per slot, one array per component (slot s of component k at acc[k * nslot + s]):
+    //   [0..2] V' = sum dP/dz fc_partner e_partner   [3] S = sum P fc_partner
     double *acc = reinterpret_cast<double *>(recB + nslot);
-    int *auxJ = reinterpret_cast<int *>(acc + 5 * (size_t)nslot);
-    double *auxRinv = reinterpret_cast<double *>(auxJ + p.n_cap + (p.n_cap & 1));   // LDS copies, !AUXREG only
-    double *auxDfc = auxRinv + p.n_cap;
-    double reg_rinv[2] = {0.0, 0.0}, reg_dfc[2] = {0.0, 0.0};                       // AUXREG: rows lane, lane+64
+    int *auxJ = reinterpret_cast<int *>(acc + 4 * (size_t)nslot);
+    double *auxRinv = reinterpret_cast<double *>(auxJ + n_cap + (n_cap & 1));       // LDS copies, !AUXREG only
+    double *auxDfc = auxRinv + n_cap;
+    double *auxRr = auxDfc + n_cap;
+    double reg_rinv[2] = {0.0, 0.0}, reg_dfc[2] = {0.0, 0.0}, reg_rr[2] = {0.0, 0.0};   // AUXREG: rows lane, lane+64
 
     const int i = p.ilist ? p.ilist[ii] : ii;
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
@@ -384,8 +390,8 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
     const double *cf = p.coef + (size_t)ii * ANNP_CPAD;
 
     if (p.type && !((p.active >> p.type[i]) & 1u)) return;
-    const int n = fe_compact<true>(p, i, lane, recA, recB, auxJ);
-    if (n > p.n_cap) {          // does not fit this launch's records: hand the atom to the fix-up launch
+    const int n = fe_compact<true>(p, i, lane, recA, recB, auxJ, n_cap);
+    if (n > n_cap) {            // does not fit this launch's records: hand the atom to the fix-up launch
         if (lane == 0) {
             const int k = p.ovf_list ? atomicAdd(p.ovf_count, 1) : p.ovf_cap;
             if (k < p.ovf_cap) p.ovf_list[k] = ii;
@@ -396,21 +402,21 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
     wave_lds_sync();
     const int H = n >> 1;
     const int L = (H + FE_Q - 1) / FE_Q;
-    // accumulators start at zero; slot 4 holds -R r (radial term), the pair loop only adds to slots 0..3:
-    //   Fn_a = (-V_a + C_a e_a)/r_a - S_a fc'_a e_a   with   C_a = e_a . V_a - R_a r_a
-    for (int k = lane; k < 5 * (n + L); k += 64) acc[k] = 0.0;
+    // accumulators start at zero.  Fn_a = (-V_a + C_a e_a)/r_a - S_a fc'_a e_a  with  C_a = e_a . V_a - R_a r_a;
+    // the radial term R_a r_a stays with the lane that owns neighbour a (register, or LDS beyond 128 neighbours)
+    for (int k = lane; k < n + L; k += 64) { acc[k] = 0.0; acc[nslot + k] = 0.0; acc[2 * nslot + k] = 0.0; acc[3 * nslot + k] = 0.0; }
     if (lane < FE_DUMP) {
         recA[NZ + lane] = make_double2(0.0, 0.0);
         recB[NZ + lane] = make_double2(0.0, 0.0);
 #pragma unroll
-        for (int k = 0; k < 5; k++) acc[5 * (NZ + lane) + k] = 0.0;
+        for (int k = 0; k < 4; k++) acc[k * nslot + NZ + lane] = 0.0;
     }
     wave_lds_sync();
     {
         double cr[NP];
 #pragma unroll
         for (int m = 0; m < NP; m++) cr[m] = cf[m];
-        auto sweep = [&](int a, double &rinv_out, double &dfc_out) {
+        auto sweep = [&](int a, double &rinv_out, double &dfc_out, double &rr_out) {
             const FeNbr g = fe_geometry(recA[a], recB[a], pi_over_rc);
             const double2 RA = make_double2(g.ex, g.ey), RB = make_double2(g.ez, g.fc);
             recA[a] = RA; recB[a] = RB;
@@ -430,20 +436,20 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
                 tm2 = tm1; tm1 = t; dm2 = dm1; dm1 = d;
             }
             const double R = fma(sd * two_over_rcp, g.fc, st * g.dfc);
-            acc[5 * a + 4] = -R * g.r;
+            rr_out = -R * g.r;
             rinv_out = g.rinv; dfc_out = g.dfc;
         };
         if constexpr (AUXREG) {
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const int a = lane + 64 * k;
-                if (a < n) sweep(a, reg_rinv[k], reg_dfc[k]);
+                if (a < n) sweep(a, reg_rinv[k], reg_dfc[k], reg_rr[k]);
             }
         } else {
             for (int a = lane; a < n; a += 64) {
-                double ri, df;
-                sweep(a, ri, df);
-                auxRinv[a] = ri; auxDfc[a] = df;
+                double ri, df, rr;
+                sweep(a, ri, df, rr);
+                auxRinv[a] = ri; auxDfc[a] = df; auxRr[a] = rr;
             }
         }
     }
@@ -480,8 +486,8 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
         if (!act) b = dump;
         // the run b, b+1, .. never wraps: records and accumulators have copies behind n
         const double2 *pA = recA + b, *pB = recB + b;
-        double *qb = acc + 5 * b;
-        const int incr = act ? 1 : 0, inca = act ? 5 : 0;
+        double *qb = acc + b;
+        const int incr = act ? 1 : 0, inca = incr;
         const int Lm = fe_round_min_steps(it.q, H, L, even);
 
         // one pair: evaluate, keep the a-side, scatter the b-side to accumulator slot q
@@ -502,10 +508,10 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
             const double be = Pd * B1.y;           // dP/dz fc_b
             va0 = fma(be, B0.x, va0); va1 = fma(be, B0.y, va1); va2 = fma(be, B1.x, va2);
             sa = fma(P, B1.y, sa);
-            atomicAdd(q + 0, Pd * fa0);            // dP/dz fc_a e_a
-            atomicAdd(q + 1, Pd * fa1);
-            atomicAdd(q + 2, Pd * fa2);
-            atomicAdd(q + 3, P * A1.y);
+            atomicAdd(q, Pd * fa0);                // dP/dz fc_a e_a
+            atomicAdd(q + nslot, Pd * fa1);
+            atomicAdd(q + 2 * nslot, Pd * fa2);
+            atomicAdd(q + 3 * nslot, P * A1.y);
         };
 
         int s = 0;
@@ -534,33 +540,33 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
         }
         for (; s < L; ++s) {                       // ragged tail of the round
             const bool ok = s <= smax;
-            step(ok ? *pA : recA[NZ], ok ? *pB : recB[NZ], ok ? qb : acc + 5 * dump);
+            step(ok ? *pA : recA[NZ], ok ? *pB : recB[NZ], ok ? qb : acc + dump);
             pA += incr; pB += incr; qb += inca;
         }
         {
-            double *q = acc + 5 * ar;
-            atomicAdd(q + 0, va0);
-            atomicAdd(q + 1, va1);
-            atomicAdd(q + 2, va2);
-            atomicAdd(q + 3, sa);
+            double *q = acc + ar;
+            atomicAdd(q, va0);
+            atomicAdd(q + nslot, va1);
+            atomicAdd(q + 2 * nslot, va2);
+            atomicAdd(q + 3 * nslot, sa);
         }
         it.next(n);
     }
     wave_lds_sync();
     // fold the accumulators of the copies back onto their originals
-    for (int k = lane; k < 5 * L; k += 64) acc[k] += acc[5 * n + k];
+    for (int k = lane; k < 4 * L; k += 64) { const int c = k / L, r = k - c * L; acc[c * nslot + r] += acc[c * nslot + n + r]; }
     wave_lds_sync();
 
     // ---- finalize: Fn_a = sum_n c_n dG_n/dx_a ; F_a = -Fn_a to neighbour, +Fn_a to centre (fe:190-213)
     double fi0 = 0.0, fi1 = 0.0, fi2 = 0.0;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
-    auto finish = [&](int a, double rinv, double dfc) {
+    auto finish = [&](int a, double rinv, double dfc, double rr) {
         const double2 E0 = recA[a], E1 = recB[a];
-        const double *q = acc + 5 * a;
-        // V_a = fc_a V'_a;  C_a = sum_b alpha_ab cos(theta_ab) = e_a . V_a, plus the radial -R r parked in slot 4
-        const double V0 = E1.y * q[0], V1 = E1.y * q[1], V2 = E1.y * q[2];
-        const double cq = fma(E0.x, V0, fma(E0.y, V1, fma(E1.x, V2, q[4])));
-        const double t = fma(cq, rinv, -q[3] * dfc);
+        const double *q = acc + a;
+        // V_a = fc_a V'_a;  C_a = sum_b alpha_ab cos(theta_ab) = e_a . V_a, plus the radial term -R r
+        const double V0 = E1.y * q[0], V1 = E1.y * q[nslot], V2 = E1.y * q[2 * nslot];
+        const double cq = fma(E0.x, V0, fma(E0.y, V1, fma(E1.x, V2, rr)));
+        const double t = fma(cq, rinv, -q[3 * nslot] * dfc);
         const double g0 = fma(t, E0.x, -V0 * rinv);
         const double g1 = fma(t, E0.y, -V1 * rinv);
         const double g2 = fma(t, E1.x, -V2 * rinv);
@@ -585,10 +591,10 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int a = lane + 64 * k;
-            if (a < n) finish(a, reg_rinv[k], reg_dfc[k]);
+            if (a < n) finish(a, reg_rinv[k], reg_dfc[k], reg_rr[k]);
         }
     } else {
-        for (int a = lane; a < n; a += 64) finish(a, auxRinv[a], auxDfc[a]);
+        for (int a = lane; a < n; a += 64) finish(a, auxRinv[a], auxDfc[a], auxRr[a]);
     }
     fi0 = wave_sum(fi0); fi1 = wave_sum(fi1); fi2 = wave_sum(fi2);
     if (lane == 0) {
@@ -614,7 +620,7 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
 }
 
 // one wave per atom of the launch
-template <int NP, int NT, bool VIRIAL, bool AUXREG>
+template <int NP, int NT, bool VIRIAL, bool AUXREG, int NCAP = 0>
 __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -622,7 +628,7 @@ __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
     const int wave = uniform(threadIdx.x >> 6);
     const int ii = uniform(xcd_block() * (int)(blockDim.x >> 6) + wave);
     if (ii >= p.inum) return;
-    fe_force_atom<NP, NT, VIRIAL, AUXREG>(p, ii, lane, lds_raw + (size_t)wave * fe_force_lds_per_wave(p.n_cap, AUXREG));
+    fe_force_atom<NP, NT, VIRIAL, AUXREG, NCAP>(p, ii, lane, lds_raw + (size_t)wave * fe_force_lds_per_wave(NCAP ? NCAP : p.n_cap, AUXREG));
 }
 
 // Fix-up launch: the atoms the main launch queued (their in-cutoff count exceeded the capacity its LDS records were
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(256) void annp_fe_force_fixup(FeArgs p)
     q.ovf_list = nullptr; q.ovf_cap = 0;          // nothing behind this launch: a second overflow is an error
     const int wpb = blockDim.x >> 6;              // launched with one wave per workgroup: the whole LDS for one list row
     for (int k = blockIdx.x * wpb + wave; k < count; k += gridDim.x * wpb) {
-        fe_force_atom<NP, NT, VIRIAL, false>(q, uniform(p.ovf_list[k]), lane, wbase);
+        fe_force_atom<NP, NT, VIRIAL, false, 0>(q, uniform(p.ovf_list[k]), lane, wbase);
         wave_lds_sync();
     }
 }
