@@ -52,8 +52,14 @@ SURVEY_FLOP_PAIR, SURVEY_FLOP_NBR, SURVEY_FLOP_MLP = 350.0, 175.0, 1600.0
 BYTES_ATOM_STEP = 9960.0                          # gathered bytes per atom-step
 PEAK_FP64_VECTOR = 78.6                           # TFLOP/s, MI355X (MI355X_MICROARCH.md: half of FP32 vector 157.3)
 PEAK_HBM = 8000.0                                 # GB/s spec
-# SURVEY.md 8d, Ni: per (j,k) pair 24 functions x 40 + 150, network 5 k
-NI_FLOP_PAIR, NI_FLOP_MLP = 24 * 40.0 + 150.0, 5000.0
+# Ni (Behler G2/G4), counted from the kernels: per candidate (j,k) pair the distance pre-pass of both passes
+# (2 x 20); per pair that survives r_ij, r_ik, r_jk < Rc (39 % of them in fcc Ni, the figure used here) geometry + cutoff
+# function of r_jk 75, one exp and its powers 44, squaring ladders 10, the 8 (lambda, zeta) steps 64 (descriptor) / 136 (force),
+# force assembly 57: 195 + 320; per in-range neighbour sincos + 3 exp in each pass 380; network 27-24-24-1 forward + reverse 5 k.
+# (SURVEY.md 8d's 24 x 40 + 150 per candidate pair priced a pow() per function and every candidate pair.)
+NI_IN_RANGE_PAIR_FRACTION = 0.39
+NI_FLOP_PAIR = 40.0 + NI_IN_RANGE_PAIR_FRACTION * (195.0 + 320.0)
+NI_FLOP_NBR, NI_FLOP_MLP = 380.0, 5000.0
 
 
 def parse_args():
@@ -321,8 +327,9 @@ def run_rank(args):
     flop_desc = pairs * FLOP_PAIR_DESC + nbrs * FLOP_NBR_DESC
     flop_eval = flop_force + flop_desc + nlocal * FLOP_MLP
     flop_survey = pairs * SURVEY_FLOP_PAIR + nbrs * SURVEY_FLOP_NBR + nlocal * SURVEY_FLOP_MLP
-    if wl == "ni":          # only SURVEY's estimate exists for the G2/G4 passes: both figures are that one
-        flop_eval = flop_survey = pairs * NI_FLOP_PAIR + nlocal * NI_FLOP_MLP
+    if wl == "ni":
+        flop_eval = pairs * NI_FLOP_PAIR + nbrs * NI_FLOP_NBR + nlocal * NI_FLOP_MLP
+        flop_survey = pairs * (24 * 40.0 + 150.0) + nlocal * NI_FLOP_MLP
     force_ms, desc_ms, mlp_ms = float(ms4[2]), float(ms4[0]), float(ms4[1])
 
     if rank != 0:
@@ -405,9 +412,11 @@ def run_rank(args):
             "kernel": "annp_ni_desc + annp_mlp_mfma + annp_ni_force (whole evaluation)", "bound": "fp64_valu",
             "achieved": ev, "peak": PEAK_FP64_VECTOR, "unit": "TFLOP/s", "frac": ev / PEAK_FP64_VECTOR, "traffic": None,
             "algorithmic_flop_per_launch": flop_eval,
-            "flop_per_unit": {"pair": NI_FLOP_PAIR, "atom": NI_FLOP_MLP},
-            "note": "SURVEY.md 8d's estimate for the G2/G4 formulation (24 functions x 40 + 150 per in-range pair); with ~18 "
-                    "neighbours per atom the passes are issue- and LDS-bound, not HBM-bound (DESIGN.md 4.4)"}
+            "flop_per_unit": {"candidate_pair": NI_FLOP_PAIR, "neighbour": NI_FLOP_NBR, "atom": NI_FLOP_MLP},
+            "survey_budget_TFLOPs": flop_survey / (float(ms4[3]) * 1e-3) / 1e12,
+            "note": "flop counted from the kernels (DESIGN.md 4.5): ~50 kflop per atom-step, a third of SURVEY.md 8d's 0.17 MFLOP "
+                    "estimate; with ~18 neighbours per atom the passes are bound by LDS and memory latency at 3-4 waves per SIMD, "
+                    "not by FP64 issue and not by HBM (DESIGN.md 4.4)"}
     elif wl == "anna":
         dd = flop_desc / (desc_ms * 1e-3) / 1e12
         out["roofline"] = {
