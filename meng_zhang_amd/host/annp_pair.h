@@ -54,6 +54,7 @@ class PairANNP {
     // files with several elements: 0 (default) = the reference parser's behaviour, 1 = "#El" lines select the element
     // of the blocks below them (annp_potential.h); call before coeff()
     void set_blocks_by_name(int v) { blocks_by_name_ = v != 0; }
+    int map(int type) const { return (type >= 1 && type <= ntypes_) ? map_[type] : -1; }     // element of a LAMMPS type, -1 = not mapped
     bool behler() const { return pot_.has_symcoef; }
     bool anna() const { return anna_; }
 

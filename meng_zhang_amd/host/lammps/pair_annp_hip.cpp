@@ -60,7 +60,8 @@ void PairANNPHIP::coeff(int narg, char **arg)
   if (impl->coeff(narg, arg) != 0) error->all(FLERR, impl->error());
   cutmax = impl->cutmax();
   for (int i = 1; i <= atom->ntypes; i++)
-    for (int j = i; j <= atom->ntypes; j++) setflag[i][j] = 1;   // every type maps to the single element
+    for (int j = i; j <= atom->ntypes; j++)
+      setflag[i][j] = (impl->map(i) >= 0 && impl->map(j) >= 0) ? 1 : 0;     // fe_v2/src/pair_annp.cpp:293-300
 }
 
 void PairANNPHIP::init_style()
