@@ -284,7 +284,7 @@ int fe_next_cap(int mx)
 }
 // Behler kernels: nothing stands behind an overflow (it is reported and the evaluation has to be re-issued), so the
 // slack is generous: an eighth of the count, at least 2.
-int ni_next_cap(int mx) { return std::max(16, round_up(mx + std::max(2, mx / 8), 8)); }
+int ni_next_cap(int mx) { return std::max(16, round_up(mx + std::max(2, mx / 8), 4)); }
 
 // Look at the flag words an evaluation copied back.  Updates the capacities for the next evaluation and turns a
 // device-side capacity error into sticky_rc.

@@ -31,8 +31,11 @@ constexpr int NI_MAXP = 8;        // radial functions supported
 constexpr int NI_MAXT = 32;       // angular functions supported
 constexpr int NI_RED = 9;         // sums per LDS reduction round (desc)
 constexpr int NI_REDROW = 17;     // padded row of 16 lane partials
-constexpr int NI_CH = 16;         // trips per chunk of the pair pre-pass: 256 pair slots per atom
-constexpr int NI_PLIST = NI_CH * NI_GL;   // in-range pair list per atom (ushort: a | b << 8)
+// trips per chunk of the pair pre-pass and the in-range pair list per atom that goes with it (ushort: a | b << 8):
+// 16 trips = 256 slots in the descriptor pass; 8 in the force pass, whose LDS decides its occupancy (4 x 12.4 KB
+// + tables = three workgroups per CU; with 16 trips and 24-record capacity it was two)
+__host__ __device__ constexpr int ni_ch(bool force) { return force ? 8 : 16; }
+__host__ __device__ constexpr int ni_plist(bool force) { return ni_ch(force) * 16; }
 // Force pass: a wave takes NI_RUN consecutive groups of four atoms (16 atoms: four fcc cells of a row reference 304 atoms,
 // ~80 of them distinct) and sends their force contributions through a wave-private table keyed by atom index, flushed
 // with one global atomic per distinct atom and component at the end of the run (same scheme as annp_anna_adp).
@@ -77,7 +80,7 @@ __host__ __device__ inline size_t ni_lds_per_wave(int cap, bool force, int nsf)
 {
     const size_t R = (size_t)NI_GA * cap + 2;          // + two dummy records for idle lanes
     size_t b = R * 7 * 8 + (force ? R * 3 * 8 + (size_t)NI_GA * ni_coef_stride(nsf) * 8 + (size_t)NI_TSLOTS * (3 * 8 + 4) : 0) + R * 4 + NI_GA * 4 +
-               (size_t)NI_GA * NI_PLIST * 2;
+               (size_t)NI_GA * ni_plist(force) * 2;
     const size_t scratch = (size_t)NI_GA * NI_RED * NI_REDROW * 8;
     if (!force && b < scratch) b = scratch;
     return (b + 15) / 16 * 16;
@@ -352,7 +355,7 @@ struct NiLds {
     int *tkey;                                    // [NI_TSLOTS]
     int *j;                                       // [NI_GA * cap]
     int *ci;                                      // [NI_GA] atom index of each group, -1 = none
-    unsigned short *pl;                           // [NI_GA][NI_PLIST] in-range pairs of the current chunk
+    unsigned short *pl;                           // [NI_GA][ni_plist] in-range pairs of the current chunk
 };
 
 template <bool FORCE>
@@ -588,7 +591,7 @@ __device__ __forceinline__ void ni_forget_lds() { asm volatile("" ::: "memory");
 // = 4 trips instead of 10.  The test is computed exactly as ni_pair computes it, so the list and the visit agree.
 // Returns this lane's atom's count for the chunk (same value in the 16 lanes of a group).
 __device__ __forceinline__ int ni_prepass(const NiLds &L, const NiConst &c, NiWalk &walk, int g, int l, int sbase, int cap,
-                                          int npl, int t0, int t1)
+                                          int npl, int t0, int t1, const int plist)
 {
     const double cfl = c.K[NI_KM + 2], rc = c.K[NI_KM + 1];
     int cnt = 0;
@@ -604,7 +607,7 @@ __device__ __forceinline__ int ni_prepass(const NiLds &L, const NiConst &c, NiWa
         const bool ok = live && (L.r[sa] * cfl < rc) && (L.r[sb] * cfl < rc) && (rgm < rc);
         const unsigned long long m = __ballot(ok);
         const unsigned m16 = (unsigned)(m >> (NI_GL * g)) & 0xffffu;
-        if (ok) L.pl[g * NI_PLIST + cnt + __popc(m16 & ((1u << l) - 1u))] = (unsigned short)(a | (b << 8));
+        if (ok) L.pl[g * plist + cnt + __popc(m16 & ((1u << l) - 1u))] = (unsigned short)(a | (b << 8));
         cnt += __popc(m16);
     }
     return cnt;
@@ -667,15 +670,16 @@ __global__ __launch_bounds__(256, NI_WAVES_PER_SIMD) void annp_ni_desc(NiArgs p)
     const int npl = nl * (nl - 1) / 2;
     const int trips = (nmax * (nmax - 1) / 2 + NI_GL - 1) / NI_GL;
     NiWalk walk = ni_walk_init(l, nl);
-    for (int t0 = 0; t0 < trips; t0 += NI_CH) {
-        const int cnt = ni_prepass(L, kc, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + NI_CH));
+    constexpr int CH = ni_ch(false), PLIST = ni_plist(false);
+    for (int t0 = 0; t0 < trips; t0 += CH) {
+        const int cnt = ni_prepass(L, kc, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST);
         wave_lds_sync();
         const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
                              max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
         for (int t2 = 0; t2 * NI_GL < cmax; t2++) {
             const int idx = t2 * NI_GL + l;
             const bool live = idx < cnt;
-            const int v = live ? L.pl[g * NI_PLIST + idx] : 0;
+            const int v = live ? L.pl[g * PLIST + idx] : 0;
             const NiPairS q = ni_pair(L, kc, live ? sbase + (v & 255) : NI_GA * cap, live ? sbase + (v >> 8) : NI_GA * cap + 1);
             const double r2sum = q.rjm * q.rjm + q.rkm * q.rkm + q.rgm * q.rgm;
             const double tfc = q.tfc;                                   // idle lanes add zeros
@@ -776,15 +780,16 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     const int npl = nl * (nl - 1) / 2;
     const int trips = (nmax * (nmax - 1) / 2 + NI_GL - 1) / NI_GL;
     NiWalk walk = ni_walk_init(l, nl);
-    for (int t0 = 0; t0 < trips; t0 += NI_CH) {
-    const int cnt = ni_prepass(L, kc, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + NI_CH));
+    constexpr int CH = ni_ch(true), PLIST = ni_plist(true);
+    for (int t0 = 0; t0 < trips; t0 += CH) {
+    const int cnt = ni_prepass(L, kc, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST);
     wave_lds_sync();
     const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
                          max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
     for (int t2 = 0; t2 * NI_GL < cmax; t2++) {
         const int idx = t2 * NI_GL + l;
         const bool lv = idx < cnt;
-        const int pv = lv ? L.pl[g * NI_PLIST + idx] : 0;
+        const int pv = lv ? L.pl[g * PLIST + idx] : 0;
         const int sa = lv ? sbase + (pv & 255) : NI_GA * cap, sb = lv ? sbase + (pv >> 8) : NI_GA * cap + 1;
         const NiPairS q = ni_pair(L, kc, sa, sb);
         const double r2sum = q.rjm * q.rjm + q.rkm * q.rkm + q.rgm * q.rgm;
