@@ -193,3 +193,80 @@ def test_ranks_over_gloo(world):
     assert np.abs(f1 - f_ref).max() < 1e-11
     assert np.abs(f2 - f_ref2).max() < 1e-9 * max(1.0, np.abs(f_ref2).max())
     assert sum(r[5] for r in res) > 0
+
+
+def _soft_sphere_forces(x_all, nlocal, rc):
+    """a cheap pair force (purely repulsive, smooth at rc) on [owned | ghost] positions, newton on: each owned centre i
+    pushes every neighbour j inside rc and takes the reaction -- ghosts collect forces too, like the potential does"""
+    from scipy.spatial import cKDTree
+    tree = cKDTree(x_all)
+    pairs = tree.query_pairs(rc, output_type="ndarray")
+    f = np.zeros_like(x_all)
+    e = 0.0
+    for (i, j) in ((pairs[:, 0], pairs[:, 1]), (pairs[:, 1], pairs[:, 0])):       # full list: each owned centre sees all its neighbours
+        m = i < nlocal
+        i, j = i[m], j[m]
+        d = x_all[i] - x_all[j]
+        r = np.linalg.norm(d, axis=1)
+        w = 0.5 * 4.0 * (1.0 - r / rc) ** 3 / r              # half of -dU/dr / r for U = (1 - r/rc)^4: a pair is seen from both ends
+        np.add.at(f, i, w[:, None] * d)
+        np.add.at(f, j, -w[:, None] * d)
+        e += 0.5 * float(((1.0 - r / rc) ** 4).sum())
+    return f, e
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_md_with_migration_equals_single_domain(world):
+    """200 velocity-Verlet steps of a hot soft-sphere fluid, ghosts re-derived and atoms re-homed every 10 steps
+    (Comm::exchange + borders), on `world` slabs and on one: the same trajectory, atom by atom.  A third of the atoms
+    change rank on the way; velocities travel with them.  (The engine is a numpy pair force: the decomposition does not
+    care what fills `f`.)"""
+    import torch
+    from meng_zhang_amd.domain import SlabDomain
+    rc, skin = 3.0, 1.0
+    x0, box = bcc(14, 4, 4, 2.4)                       # 33.6 A along x: slabs >= 11.2 A
+    rng = np.random.default_rng(3)
+    v0 = rng.normal(0.0, 4.0, x0.shape)
+    v0 -= v0.mean(0)
+    dt, nsteps, every = 0.004, 200, 10
+
+    def run(rank, tp):
+        dom = SlabDomain.from_global(x0, box, (1, 1, 1), rc + skin, torch.device("cpu"), tp, extra={"v": v0})
+        moved = 0
+        home = dom.ids.clone()
+
+        def force():
+            f, e = _soft_sphere_forces(dom.x.numpy(), dom.nlocal, rc)
+            dom.f.copy_(torch.from_numpy(f))
+            dom.reverse()
+            return e
+        force()
+        for k in range(nsteps):
+            if k % every == 0 and k:
+                assert dom.max_displacement() < skin         # the list criterion would have held: half the skin per atom pair
+                dom.replan()
+                moved += dom.migrated_last
+            n = dom.nlocal
+            v = dom.extra["v"]
+            v += 0.5 * dt * dom.f[:n]
+            dom.x[:n] += dt * v
+            dom.forward()
+            force()
+            v += 0.5 * dt * dom.f[:n]
+        ids = dom.ids.numpy()
+        return ids, dom.x[: dom.nlocal].numpy().copy(), dom.extra["v"].numpy().copy(), moved, int((~np.isin(ids, home.numpy())).sum())
+
+    single = ThreadFabric(1).run(run)[0]
+    multi = ThreadFabric(world).run(run)
+    L = box[3:] - box[:3]
+    xs, vs = np.empty_like(x0), np.empty_like(x0)
+    xs[single[0]], vs[single[0]] = single[1], single[2]
+    xm, vm = np.full_like(x0, np.nan), np.full_like(x0, np.nan)
+    for ids, x, v, _, _ in multi:
+        xm[ids], vm[ids] = x, v
+    d = xm - xs
+    d -= np.round(d / L) * L                                 # same atom, possibly another periodic image
+    assert np.abs(d).max() < 1e-7 and np.abs(vm - vs).max() < 1e-6
+    assert sum(r[3] for r in multi) > x0.shape[0] // 10      # plenty of migration events ...
+    assert sum(r[4] for r in multi) > x0.shape[0] // 20      # ... and atoms that ended on another rank than they started on
+    assert np.abs(xs - x0).max() > 1.0                       # it is a fluid: atoms went places
