@@ -79,6 +79,36 @@ def test_fe_mixed_density_only_some_atoms_overflow(fe_pot):
         p.close()
 
 
+@pytest.mark.parametrize("seed,density", [(31, 0.02), (32, 0.05), (33, 0.075), (34, 0.095)])
+def test_fe_compiled_capacity_kernel_on_ragged_clusters(fe_pot, seed, density):
+    """The steady-state instantiation of the force pass has its record capacity (128) compiled in.  Prime a handle with a
+    bcc box (capacity -> 128), then give it disordered clusters: every in-cutoff count from 0 to 128 in that kernel, and
+    whatever exceeds 128 through the fix-up launch, in one evaluation."""
+    from test_gpu_parity import _random_cluster
+    x0, box0 = bcc(5, 5, 5, A_FE)
+    s0 = System(perturb(x0, 1, 0.05), box0)
+    x = _random_cluster(seed, density, 26.0, 1.6)
+    s = System(x, np.array([0, 0, 0, 26.0, 26.0, 26.0]), periodic=(0, 0, 0))
+    o = oracle_compute(fe_pot, s, KIND_FE, FAST, want_virial=True)
+    p = make_pair(FE_POT, "Fe")
+    try:
+        run(p, s0)
+        assert eval_info(p)[3] == 128
+        p.eatom = None
+        r = run(p, s, vflag=1)
+        mx, nfix, cap, _ = eval_info(p)
+        row_cap = max(16, -(-int(s.numneigh[: s.nlocal].max()) // 16) * 16)       # never more records than a list row has entries
+        assert cap == min(128, row_cap) and (nfix > 0) == (mx > cap)
+        if density >= 0.09:
+            assert cap == 128                        # the densest clusters run in the compiled-capacity kernel
+    finally:
+        p.close()
+    scale = max(1.0, np.abs(o["f"]).max())
+    assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6 * max(1.0, np.abs(o["eatom"] + 4479.0).max())
+    assert np.abs(r["f"] - o["f"]).max() < 1e-9 * scale
+    assert np.allclose(r["virial"], o["virial"], rtol=1e-9, atol=1e-6 * scale)
+
+
 def _device_handles(pair, s, want_e=True):
     import torch
     from meng_zhang_amd.lib import load_library
