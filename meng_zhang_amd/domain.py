@@ -199,8 +199,13 @@ class SlabDomain:
         dest = t.clamp(t.floor((x[:, 0] - self.box[0]) / L[0] * self.world).to(t.int64), 0, self.world - 1)
         rel = (dest - self.rank) % self.world
         stay = t.nonzero(rel == 0).flatten()
-        go_r = t.nonzero(rel == 1).flatten() if self.right is not None else stay[:0]
-        go_l = t.nonzero(rel == self.world - 1).flatten() if (self.left is not None and self.world > 2) else stay[:0]
+        if self.world == 2:         # one other rank: it is my right neighbour, my left one (open box), or both (periodic)
+            other = t.nonzero(rel != 0).flatten()
+            go_r = other if self.right is not None else stay[:0]
+            go_l = other if (self.right is None and self.left is not None) else stay[:0]
+        else:
+            go_r = t.nonzero(rel == 1).flatten() if self.right is not None else stay[:0]
+            go_l = t.nonzero(rel == self.world - 1).flatten() if self.left is not None else stay[:0]
         if int(stay.numel() + go_r.numel() + go_l.numel()) != n:
             raise RuntimeError("an atom moved further than the neighbouring slab between two rebuilds")
         cols = [x, self.ids.to(t.float64).reshape(n, 1)] + [self.extra[k] for k in sorted(self.extra)]

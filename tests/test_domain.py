@@ -127,6 +127,42 @@ def test_slabs_reproduce_single_domain(world):
         assert sum(r[4] for r in res) > 0           # atoms did change owner
 
 
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_open_box_along_x(world):
+    """free surfaces in x (the reference's own benchmark deck has `boundary m p m`): the end slabs have one neighbour,
+    nothing wraps in x, atoms that drift out of the box stay with the end rank"""
+    import torch
+    from meng_zhang_amd.domain import SlabDomain
+    x0, box = bcc(cells_x(max(world, 2)), 3, 3, A_FE)
+    xg = perturb(x0, 11, 0.05)
+    xd = drift(xg, box, 5, 1.0)
+    pot = read_pot(FE_POT)
+    per = (0, 1, 1)
+
+    def ref(x):
+        s = System(x, box, periodic=per)
+        r = oracle_compute(pot, s, KIND_FE, FAST)
+        return r["f"], r["energy"]
+
+    def rank_program(rank, tp):
+        dom = SlabDomain.from_global(xg, box, per, RC_LIST, torch.device("cpu"), tp)
+        e1 = oracle_step(dom, pot, nthreads=1)
+        r1 = dom.gather_owned(dom.f)
+        dom.x[: dom.nlocal] = torch.from_numpy(xd[dom.ids.numpy()])
+        dom.replan()
+        e2 = oracle_step(dom, pot, nthreads=1)
+        return e1, r1, e2, dom.gather_owned(dom.f)
+
+    res = ThreadFabric(world).run(rank_program)
+    for k, x in ((1, xg), (3, xd)):
+        f_ref, e_ref = ref(x)
+        f = np.full_like(x, np.nan)
+        for r in res:
+            f[r[k][0]] = r[k][1]
+        assert abs(sum(r[k - 1] for r in res) - e_ref) < 1e-7
+        assert np.abs(f - f_ref).max() < 1e-9 * max(1.0, np.abs(f_ref).max())
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
