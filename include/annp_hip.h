@@ -126,7 +126,9 @@ int annp_hip_compute(annp_hip_handle *handle, int ago, int inum, int nall, int n
                      double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom);
 
 /* Replaces annp_gpu_compute_n (neighbour list built on the device from host_x
- * when ago == 0).  sublo/subhi bound the owned atoms; cutneigh = cutoff + skin.
+ * when ago == 0).  cutneigh = cutoff + skin.  sublo/subhi (the sub-domain bounds the reference passes on to its
+ * cell grid) are accepted for signature compatibility and not read: the build bins the bounding box of the
+ * positions it is given, ghosts included.  host_type is read when the potential distinguishes atom types.
  * Owned atoms are the first inum entries of host_x, ghosts follow.  Atomic
  * systems only (no special-bond exclusions), like the potential itself. */
 int annp_hip_compute_n(annp_hip_handle *handle, int ago, int inum, int nall, int nghost,
