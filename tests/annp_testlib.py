@@ -327,11 +327,16 @@ def load_fe_st():
 # GPU builds (fe_v2 = "new", fe = "old") for fe_st.dat:
 CG_LOG = {
     "new": dict(e0=-684876292.365723, e1=-684876369.462402, fnorm0=39.623051, fnorm1=19.978295, fmax0=0.93490135,
-                fmax1=0.52800152, alpha=0.10696316, max_move=0.056476709, press0=-40423.638, press1=-39424.375),
+                fmax1=0.52800152, alpha=0.10696316, max_move=0.056476709, press0=-40423.638, press1=-39424.375,
+                npt0_pdiag=(-35417.504, -38755.784, -33395.071)),
     "old": dict(e0=-684876292.28418, e1=-684876369.487793, fnorm0=39.623117, fnorm1=19.978156, fmax0=0.93490485,
-                fmax1=0.52800456, alpha=0.10696276, max_move=0.056476823, press0=-40426.438, press1=-39426.375),
+                fmax1=0.52800456, alpha=0.10696276, max_move=0.056476823, press0=-40426.438, press1=-39426.375,
+                npt0_pdiag=(-35419.429, -38757.739, -33396.977)),
 }
 CG_VOLUME, NKTV2P = 1773495.9, 1.6021765e6      # log thermo column "Volume"; LAMMPS metal units
+# first thermo line of the NPT run that follows the minimisation (same positions, `velocity all create 300`): Pxx Pyy Pzz
+# = virial tensor / V + kinetic part, V = 1773388.1, KinEng = 5928.3485 eV (T = 300 K exactly at that step)
+NPT0_VOLUME, NPT0_KE = 1773388.1, 5928.3485
 
 
 def cg_first_iteration(evaluate, x0):
@@ -369,6 +374,10 @@ def check_cg_log(r0, r2, alpha_max):
         # The energy drop is the weak one: the reference builds evaluate E_i in float (ulp of 4479.87 = 4.9e-4 eV) and
         # their systematic per-atom offset moves with the configuration: 2.2e-5 eV/atom at step 0, 4.6e-5 at step 1.
         assert abs(de - (L["e1"] - L["e0"])) < 2.5e-5 * 152880, tag            # observed 3.7 eV of -77.1
+        # the anisotropic virial: diagonal components against the first NPT line.  The kinetic part is 2 KE / 3V per
+        # component only on average (random velocities: +-0.26 % of 3 571 bar); the three components differ by 3 000 bar.
+        pdiag = r2["virial"][:3] / NPT0_VOLUME * NKTV2P + 2.0 * NPT0_KE / (3.0 * NPT0_VOLUME) * NKTV2P
+        assert np.abs(pdiag - np.array(L["npt0_pdiag"])).max() < 25.0, tag       # observed 3.3 / 6.6 / 3.7 bar
     return dict(fnorm=fn, fmax=fm, press=press, de=de)
 
 

@@ -330,3 +330,4 @@ def test_two_slabs_of_the_reference_benchmark_match_its_log():
     assert [r[0] for r in res] == [77040, 75840]
     assert [r[1] for r in res] == [22500, 22300]
     assert [float("%.5e" % r[2]) for r in res] == [1.67621e+07, 1.64983e+07]
+    assert res[0][2] + res[1][2] == 33260400                  # "Total # of neighbors = 33260400" (:142), to the last digit
