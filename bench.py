@@ -237,12 +237,19 @@ def run_rank(args):
             check(lib.annp_hip_compute_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), None, None, p_num, p_first, p_neigh,
                                               mx.value, dom.f.data_ptr(), None, eng.data_ptr(), None, None, stream), "compute_device")
 
-    def step():
+    def step(rebuild=False):
+        """LAMMPS Verlet::run order: initial_integrate; on a reneighbouring step exchange + borders + neighbour build,
+        otherwise forward_comm; force_clear, pair compute, reverse_comm; final_integrate"""
         n = dom.nlocal
-        xo, fo, vel = dom.x[:n], dom.f[:n], dom.extra["v"]
-        vel.add_(fo, alpha=dtf)             # velocity-Verlet, first half
-        xo.add_(vel, alpha=args.dt)
-        dom.forward()                       # Comm::forward_comm
+        vel = dom.extra["v"]
+        vel.add_(dom.f[:n], alpha=dtf)      # velocity-Verlet, first half
+        dom.x[:n].add_(vel, alpha=args.dt)
+        if rebuild:
+            dom.replan()                    # Comm::exchange + Comm::borders (atoms, velocities and ids change rank here)
+            build_list()                    # Neighbor::build
+            n, vel = dom.nlocal, dom.extra["v"]
+        else:
+            dom.forward()                   # Comm::forward_comm
         force_eval()                        # Pair::compute
         dom.reverse()                       # Comm::reverse_comm
         vel.add_(dom.f[:n], alpha=dtf)      # second half
@@ -302,11 +309,10 @@ def run_rank(args):
         barrier()
         t1 = time.perf_counter()
         for k in range(args.steps):
-            if k % args.rebuild_every == 0:
-                dom.replan()                # Comm::exchange + Comm::borders
-                build_list()                # Neighbor::build
+            rebuild = k % args.rebuild_every == 0
+            step(rebuild)
+            if rebuild:
                 md_migrated += dom.migrated_last
-            step()
         barrier()
         t_md = time.perf_counter() - t1
         if use_dist:

@@ -244,7 +244,7 @@ def _soft_sphere_forces(x_all, nlocal, rc):
         i, j = i[m], j[m]
         d = x_all[i] - x_all[j]
         r = np.linalg.norm(d, axis=1)
-        w = 0.5 * 4.0 * (1.0 - r / rc) ** 3 / r              # half of -dU/dr / r for U = (1 - r/rc)^4: a pair is seen from both ends
+        w = 0.5 * 4.0 * (1.0 - r / rc) ** 3 / (rc * r)       # half of -dU/dr / r for U = (1 - r/rc)^4: a pair is seen from both ends
         np.add.at(f, i, w[:, None] * d)
         np.add.at(f, j, -w[:, None] * d)
         e += 0.5 * float(((1.0 - r / rc) ** 4).sum())
@@ -277,18 +277,23 @@ def test_md_with_migration_equals_single_domain(world):
             dom.reverse()
             return e
         force()
+        etot = []
         for k in range(nsteps):
-            if k % every == 0 and k:
+            n = dom.nlocal
+            v = dom.extra["v"]
+            v += 0.5 * dt * dom.f[:n]                        # Verlet::run order: initial_integrate ...
+            dom.x[:n] += dt * v
+            if k % every == 0 and k:                         # ... exchange + borders on a reneighbouring step, else forward_comm ...
                 assert dom.max_displacement() < skin         # the list criterion would have held: half the skin per atom pair
                 dom.replan()
                 moved += dom.migrated_last
-            n = dom.nlocal
-            v = dom.extra["v"]
+                n, v = dom.nlocal, dom.extra["v"]
+            else:
+                dom.forward()
+            e = force()                                      # ... forces, reverse_comm, final_integrate
             v += 0.5 * dt * dom.f[:n]
-            dom.x[:n] += dt * v
-            dom.forward()
-            force()
-            v += 0.5 * dt * dom.f[:n]
+            etot.append(float(tp.allreduce_sum_(torch.tensor([e + 0.5 * float((v * v).sum())], dtype=torch.float64))))
+        assert max(etot) - min(etot) < 1e-3 * abs(0.5 * (v0 * v0).sum())      # energy survives the re-planning (a lost half-kick would show)
         ids = dom.ids.numpy()
         return ids, dom.x[: dom.nlocal].numpy().copy(), dom.extra["v"].numpy().copy(), moved, int((~np.isin(ids, home.numpy())).sum())
 

@@ -74,3 +74,81 @@ def test_nve_100_steps_hip_vs_oracle(fe_pot):
     assert np.abs(eg - eo).max() < 1e-6 * n
     ke = 1.5 * (n - 1) * KB * 300.0
     assert np.abs(eg - eg[0]).max() < 5e-3 * ke          # bounded O(dt^2) fluctuation of the integrator
+
+
+def test_nve_with_rehoming_and_device_list_rebuilds():
+    """The mini-MD leg of bench.py in small: hot bcc Fe (1 500 K, atoms travel ~0.5 A in 120 fs), SlabDomain.replan() +
+    device list rebuild every 10 steps, velocity-Verlet on device tensors, HIP engine.  Total energy must stay on the
+    integrator's O(dt^2) band straight through the rebuilds (a lost ghost or a stale list shows as a jump), momentum
+    stays zero, and the final state equals a run that never re-plans (list cutoff 8.5 A vs 6.5 A: still valid)."""
+    import ctypes as C
+    import torch
+    from meng_zhang_amd import PairANNP
+    from meng_zhang_amd.domain import SlabDomain
+    from meng_zhang_amd.lib import load_library
+    lib = load_library()
+    dev = torch.device("cuda", 0)
+    x_ideal, box = bcc(12, 12, 12, A_FE)
+    x0 = perturb(x_ideal, 7, 0.05)
+    n = x0.shape[0]
+    v0 = maxwell(n, 1500.0, 99)
+    dt, nsteps = 0.001, 120
+    dtf = 0.5 * dt * FTM2V / MASS
+
+    def run(every):
+        dom = SlabDomain.from_global(x0, box, (1, 1, 1), 8.5, dev, extra={"v": v0})
+        pair = PairANNP(1, device=0)
+        pair.settings([])
+        pair.coeff(["*", "*", FE_POT, "Fe"])
+        pair.init_style()
+        h = pair.handle
+        st = torch.cuda.current_stream(dev).cuda_stream
+        pn, pf, pg, mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+        eng = torch.zeros(1, dtype=torch.float64, device=dev)
+
+        def build():
+            assert lib.annp_hip_neigh_build_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), 8.5, C.byref(pn), C.byref(pf), C.byref(pg),
+                                                   C.byref(mx), st) == 0
+
+        def force():
+            dom.f.zero_()
+            eng.zero_()
+            assert lib.annp_hip_compute_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value,
+                                               dom.f.data_ptr(), None, eng.data_ptr(), None, None, st) == 0
+            dom.reverse()
+
+        build()
+        force()
+        etot = []
+        for k in range(nsteps):
+            nl = dom.nlocal
+            v = dom.extra["v"]
+            v.add_(dom.f[:nl], alpha=dtf)                     # Verlet::run order: initial_integrate ...
+            dom.x[:nl].add_(v, alpha=dt)
+            if every and k and k % every == 0:                # ... then exchange + borders + neighbour build, or forward_comm ...
+                dom.replan()
+                build()
+                nl, v = dom.nlocal, dom.extra["v"]
+            else:
+                dom.forward()
+            force()                                           # ... force_clear, pair compute, reverse_comm ...
+            v.add_(dom.f[:nl], alpha=dtf)                     # ... final_integrate
+            etot.append(float(eng.item()) + 0.5 * MVV2E * MASS * float((v * v).sum()))
+        assert lib.annp_hip_sync(h) == 0
+        ids = dom.ids.cpu().numpy()
+        x = np.empty((n, 3)); vv = np.empty((n, 3))
+        x[ids] = dom.x[: dom.nlocal].cpu().numpy(); vv[ids] = dom.extra["v"].cpu().numpy()
+        pair.close()
+        return np.array(etot), x, vv
+
+    e_a, x_a, v_a = run(10)
+    e_b, x_b, v_b = run(0)
+    ke = 1.5 * (n - 1) * KB * 1500.0
+    assert np.abs(e_a - e_a[0]).max() < 5e-3 * ke                    # no jump at the rebuilds
+    assert np.abs(np.diff(e_a)).max() < 2e-3 * ke
+    L = box[3:] - box[:3]
+    d = x_a - x_b
+    d -= np.round(d / L) * L                                          # replan wraps atoms into the box
+    assert np.abs(d).max() < 1e-7 and np.abs(v_a - v_b).max() < 1e-6
+    assert np.abs((MASS * v_a).sum(0)).max() < 1e-6
+    assert np.abs(x_b - x0).max() > 0.3
