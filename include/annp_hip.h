@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define ANNP_HIP_ABI_VERSION 3
+#define ANNP_HIP_ABI_VERSION 4
 
 #define ANNP_HIP_OK 0
 #define ANNP_HIP_EARG (-1)
@@ -163,13 +163,26 @@ int annp_hip_compute_device(annp_hip_handle *handle, int inum, int nall,
                             double *d_f, double *d_eatom, double *d_eng, double *d_virial, double *d_vatom,
                             void *stream);
 
-/* Device neighbour-list build (binned, full list, r^2 <= cutneigh^2) for the
- * first nlocal of nall atoms at d_x.  The list lives in handle-owned memory and
+/* Device neighbour-list build (binned, full list, r^2 <= c^2 with c = annp_hip_list_cutoff(handle, cutneigh):
+ * cutneigh itself except for Behler potentials) for the first nlocal of nall atoms at d_x.  The list lives in handle-owned memory and
  * stays valid until the next build or annp_hip_clear. */
 int annp_hip_neigh_build_device(annp_hip_handle *handle, int nlocal, int nall, const double *d_x,
                                 double cutneigh,
                                 const int **d_numneigh, const long long **d_first, const int **d_neigh,
                                 int *max_numneigh, void *stream);
+
+/* The cutoff a list built by this library for `cutneigh` = cutmax + skin is really cut at.  Chebyshev and anna_adp:
+ * cutneigh.  Behler (gradient-consistent derivative): max Rc of the symmetry functions / 1.889726 + the same skin
+ * (5.9 A instead of 8.5 A for the shipped Ni file): beyond Rc a neighbour contributes exactly nothing
+ * (ni/src/pair_annp.cpp:693, 729), so forces and energies are those of the long list up to the order of the sums while
+ * the kernels filter a third of the candidates.  ANNP_HIP_FULL_LIST=1 in the environment at init keeps cutneigh; so
+ * does ni_compat = 1, whose derivative depends on the order of the list (ni:737-738). */
+double annp_hip_list_cutoff(const annp_hip_handle *handle, double cutneigh);
+
+/* Layout of the list the device built last: info4[0] 1 = rows a fixed pitch apart (a rebuild that reused the previous
+ * build's pitch: one pass over the candidates), 0 = exact CSR (first build, or rows too uneven for a pitch);
+ * [1] the pitch; [2] longest row; [3] atoms. */
+int annp_hip_list_layout(const annp_hip_handle *handle, int *info4);
 
 /* Copies the list the device built last (annp_hip_compute_n / annp_hip_neigh_build_device) to the host, rows packed in
  * atom order: numneigh[nlocal], first[nlocal+1] (nullable; offsets into neigh), neigh[neigh_capacity] (nullable: only
@@ -177,6 +190,33 @@ int annp_hip_neigh_build_device(annp_hip_handle *handle, int nlocal, int nall, c
  * Blocks until the device is idle. */
 int annp_hip_neigh_to_host(annp_hip_handle *handle, int nlocal, int *numneigh, long long *first, int *neigh,
                            long long neigh_capacity, long long *total);
+
+/* ---- the MD step around the evaluation, for callers that keep atoms in HBM --------------------------------------
+ * What LAMMPS core does around Pair::compute for the reference (Comm::forward_comm / reverse_comm with newton_pair on --
+ * fe_v2/src/pair_annp.cpp:199 writes ghost forces and relies on them -- and FixNVE's two half steps), as one kernel
+ * each.  Device pointers, rows of 3 doubles, int32 indices; asynchronous on `stream`; the wire itself (RCCL
+ * send/recv between slab neighbours) stays with the caller.  Deterministic: no atomics, fixed summation order.
+ *
+ * annp_hip_halo_pack           out[k] = x[idx[k]] + shift[k], k < n: the forward pack of boundary atoms into a send
+ *                              buffer (shift = the periodic image offset the receiving side sees).
+ * annp_hip_halo_unpack_images  x[first_image_row + k] = x[root[k]] + shift[k], k < nimg: the local periodic images
+ *                              (roots are owned atoms or ghosts received over the wire, never images).  The same
+ *                              launch clears n_clear doubles at d_f_clear and the word at d_eng_clear (both nullable):
+ *                              Verlet::force_clear for the evaluation that follows.
+ * annp_hip_reverse_fold        f[seg_dst[s]] += sum_{k = seg_start[s]}^{seg_start[s+1]-1} src[perm[k]], s < nseg, k ascending:
+ *                              ghost forces back onto their owners -- image rows of f onto their roots (src = f +
+ *                              3 first_image_row), then the rows that came back over the wire onto the boundary atoms
+ *                              (src = receive buffer, perm = position in it).  seg_start has nseg + 1 entries.
+ * annp_hip_verlet_half         v += dtf f, then x += dt v if dt != 0 (FixNVE::initial_integrate; dt = 0: final_integrate);
+ *                              dtf = 0.5 dt ftm2v / mass; product and sum rounded separately (no FMA contraction). */
+int annp_hip_halo_pack(annp_hip_handle *handle, int n, const int *d_idx, const double *d_shift, const double *d_x,
+                       double *d_out, void *stream);
+int annp_hip_halo_unpack_images(annp_hip_handle *handle, int nimg, const int *d_root, const double *d_shift, double *d_x,
+                                int first_image_row, double *d_f_clear, long long n_clear, double *d_eng_clear, void *stream);
+int annp_hip_reverse_fold(annp_hip_handle *handle, int nseg, const int *d_seg_dst, const int *d_seg_start, const int *d_perm,
+                          const double *d_src, double *d_f, void *stream);
+int annp_hip_verlet_half(annp_hip_handle *handle, int n, double *d_x, double *d_v, const double *d_f, double dtf, double dt,
+                         void *stream);
 
 /* Blocks until the handle's enqueued work is done and reports deferred device-side
  * errors (e.g. ANNP_HIP_ENEIGHCAP). */

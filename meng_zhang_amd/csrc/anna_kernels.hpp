@@ -31,7 +31,8 @@ struct AnnaArgs {
     int net_doubles;                // size of `net`
     int net_in_lds;                 // 1: the block keeps a copy of `net` in LDS (it fits ANNA_NET_LDS_MAX doubles)
     int nl, nin, nnod, nout;        // nin = columns of layer 0 (device layout)
-    int act[ANNA_MAXL];
+    unsigned actp;                  // activation flag of layer l in bits 4l..4l+3 (an int[ANNA_MAXL] indexed by the running layer
+                                    // makes the compiler copy the argument block to scratch: 132 B per lane)
     double gp[17];                  // A0 yy gamma C0 c1F c2F V0 b1 b2 delta r0 r1 hc d1 q1 d3 q3
     double e_base;
     double *f, *eatom, *eng, *virial, *vatom;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
                 for (int c = part; c < nc; c += P) a = fma(wr[c], hin[c], a);
             }
             for (int off = P >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
-            if (r < nr && part == 0) hout[r] = anna_act(p.act[l], a + w[(size_t)nr * nc + r]);
+            if (r < nr && part == 0) hout[r] = anna_act((int)((p.actp >> (4 * l)) & 15u), a + w[(size_t)nr * nc + r]);
             w += (size_t)nr * nc + nr;
             wave_lds_sync();
             double *t = hin; hin = hout; hout = t;

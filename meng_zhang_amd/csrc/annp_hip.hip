@@ -7,6 +7,7 @@
 // Per call: descriptor pass -> network pass (FP64 MFMA) -> force pass, all on one
 // stream, buffers owned by the handle.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -30,12 +31,13 @@
 #include "neigh_kernels.hpp"
 #include "ni_kernels.hpp"
 #include "anna_kernels.hpp"
+#include "step_kernels.hpp"
 
 using namespace annp;
 
 namespace {
 
-std::string g_init_error;
+thread_local std::string g_init_error;     // text of the calling thread's last failed annp_hip_init (handles are one thread each)
 
 template <typename T>
 struct DevBuf {
@@ -105,6 +107,7 @@ struct annp_hip_handle {
     int descriptor = 0, ntypes = 1, ntl = 0, nhl = 0, nnod = 0, nsf = 0, npsf = 0, ntsf = 0, nl = 0;
     int nsf_dev = 0;                    // features in the device layout (Chebyshev: always 9 + 19 slots, unused ones carry zero weights)
     int ni_compat = 0;
+    bool full_list = false;             // ANNP_HIP_FULL_LIST=1: library-built lists are cut where the caller says (list_cutoff)
     // pair_style anna_adp
     int nout = 1;
     double e_base = 0.0, gp[17] = {0};
@@ -114,7 +117,8 @@ struct annp_hip_handle {
     bool ni_primed = false;             // ... has been sized from a completed evaluation (else the next one sizes it synchronously)
     int fe_cap = 0;                     // Chebyshev force pass: record capacity for the next evaluation (0 = not sized yet)
     int cap_last = 0;                   // capacity the last force pass ran with
-    int flagact[MLP_MAXL] = {0, 0, 0, 0};
+    int flagact[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // up to max(MLP_MAXL, ANNA_MAXL) weight layers
+    static_assert(MLP_MAXL <= 8 && ANNA_MAXL <= 8, "flagact holds 8 layers");
     double e_scale = 0, e_shift = 0, e_atom = 0, cut = 0, cutsq = 0;
     double *d_norm = nullptr;           // nmul | nsub | nden, ANNP_GPAD each
     double *d_mlp_img = nullptr;        // network pass: MFMA operand images (weights, biases, coefmat), one per element, mlp_build_image
@@ -145,8 +149,15 @@ struct annp_hip_handle {
     // host-list cache
     // pinned, persistent staging for what host_finish brings back (a fresh pageable vector per call costs its
     // page faults and a second copy inside the runtime: ~3 ms per 1 M atoms)
-    double *pin_f = nullptr, *pin_e = nullptr, *pin_v = nullptr;
-    size_t pin_f_cap = 0, pin_e_cap = 0, pin_v_cap = 0;
+    double *pin_f = nullptr, *pin_e = nullptr, *pin_v = nullptr, *pin_x = nullptr;
+    size_t pin_f_cap = 0, pin_e_cap = 0, pin_v_cap = 0, pin_x_cap = 0;
+    // the caller's x and f, page-locked in place (host_register)
+    struct HostReg { const void *ptr = nullptr; size_t bytes = 0; bool ok = false; };
+    HostReg reg_x, reg_f;
+    bool use_register = true;           // ANNP_HIP_REGISTER=0 turns it off (pinned staging + host folds instead)
+    hipStream_t stream2 = nullptr;      // uploads that overlap the first passes of an evaluation
+    hipEvent_t ev_f_up = nullptr;
+    hipEvent_t pre_force_wait = nullptr;    // set by the host path: the force pass must not start before this event
     // host-list upload (annp_hip_compute, ago == 0): CSR headers and the rows go through pinned staging; the rows in
     // chunks, packed by a few threads while the previous chunk is on the wire
     long long *pin_first = nullptr;
@@ -339,6 +350,26 @@ int poll_flags(annp_hip_handle *h, bool wait)
     return 0;
 }
 
+// Cutoff of a neighbour list the library builds itself (annp_hip_neigh_build_device, annp_hip_compute_n) when the caller
+// asks for `cutneigh` = cutmax + skin.  Behler potentials: a neighbour only contributes while r * CFLENGTH < Rc of the
+// functions (ni:693, 729) -- 3.9 A for the shipped Ni file, whose cutmax line says 6.5 -- so a list cut at that distance
+// plus the SAME skin holds every atom that can come into range before the caller's next rebuild (its criterion, a
+// displacement of skin / 2, is about the skin only) and the kernels filter 3x fewer candidates (~75 instead of ~224 per
+// atom in fcc Ni).  Results are those of the long list up to the order of the sums.  Not in compat mode (ni:737-738 depends
+// on list order: there the list is exactly what was asked for) and not with ANNP_HIP_FULL_LIST=1.
+double list_cutoff(const annp_hip_handle *h, double cutneigh)
+{
+    if (h->descriptor != ANNP_HIP_DESC_BEHLER || h->ni_compat || h->full_list) return cutneigh;
+    const double rc_desc = std::max(h->sym_rad.size() >= 3 ? h->sym_rad[2] : 0.0, h->sym_ang.size() >= 4 ? h->sym_ang[3] : 0.0);
+    if (!(rc_desc > 0.0)) return cutneigh;
+    double rc_a = 0.0;      // every function's own Rc is honoured: the largest one decides
+    for (size_t k = 2; k < h->sym_rad.size(); k += 3) rc_a = std::max(rc_a, h->sym_rad[k]);
+    for (size_t k = 3; k < h->sym_ang.size(); k += 4) rc_a = std::max(rc_a, h->sym_ang[k]);
+    const double skin = std::max(0.0, cutneigh - h->cut);
+    const double c = rc_a / ANNP_CFLENGTH * (1.0 + 1e-9) + skin;
+    return std::min(c, cutneigh);
+}
+
 // the calling thread's current device is put back when an entry point returns
 struct DeviceGuard {
     int prev = -1;
@@ -407,7 +438,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     MlpArgs m{};
     m.type = types; m.map = h->d_map; m.elem = 0;
     m.inum = inum; m.ilist = d_ilist; m.nsf = h->nsf_dev; m.nnod = h->nnod; m.nl = h->nl;
-    for (int l = 0; l < h->nl; l++) m.act[l] = h->flagact[l];
+    for (int l = 0; l < std::min(h->nl, (int)MLP_MAXL); l++) m.act[l] = h->flagact[l];      // (anna_adp may have more layers; it does not use m)
     m.nmul = h->d_norm; m.nsub = h->d_norm + ANNP_GPAD; m.nden = h->d_norm + 2 * ANNP_GPAD; m.img = h->d_mlp_img;
     m.e_scale = h->e_scale; m.e_shift = h->e_shift; m.e_atom = h->e_atom;
     m.G = h->G.p; m.coef = h->coef.p; m.eatom = d_eatom; m.eng = d_eng;
@@ -436,7 +467,11 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         // pass 3: LDS records sized by the in-cutoff maximum of the previous evaluation; an atom that has more
         // is queued by the kernel and taken by the fix-up launch behind it, which has room for a whole list row
         int cap3;
-        if (h->fe_cap == 0) {       // first evaluation on this handle: read the maximum just measured, once
+        const size_t lds_fix = fe_force_lds_per_wave(cap_list, false);      // the fix-up runs one wave per workgroup
+        const bool fix_possible = lds_fix <= 160 * 1024;
+        // first evaluation on this handle: read the maximum just measured, once.  Also whenever a whole list row would not
+        // fit the fix-up launch's LDS (very long rows): nothing would stand behind a stale capacity then
+        if (h->fe_cap == 0 || (!fix_possible && h->fe_cap < cap_list)) {
             HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
             if (h->h_flags[0] > 0) {
@@ -451,11 +486,11 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         const bool vir = d_virial || d_vatom;
         if ((rc = ensure(h, h->ovf, (size_t)inum))) return rc;
         a.n_cap = cap3;
-        const size_t lds_fix = fe_force_lds_per_wave(cap_list, false);      // the fix-up runs one wave per workgroup
-        const bool fixup = cap3 < cap_list && lds_fix <= 160 * 1024;
+        const bool fixup = cap3 < cap_list && fix_possible;
         a.ovf_count = h->d_flags + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
         if (fe_force_lds_per_wave(cap3) * fe_wpb_force() > 160 * 1024)
             return fail(h, ANNP_HIP_ENEIGHCAP, "too many in-cutoff neighbours for LDS (%d)", cap3);
+        if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
         if (vir) launch_fe_force<true>(a, s); else launch_fe_force<false>(a, s);
         HIP_TRY(h, hipGetLastError());
         if (fixup) {
@@ -485,11 +520,12 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         q.n_cap = 64 * ANNA_NR; q.rc = h->cut; q.G = h->G.p; q.net = h->d_net;
         q.net_doubles = h->net_doubles; q.net_in_lds = h->net_doubles <= ANNA_NET_LDS_MAX;
         q.nl = h->nl; q.nin = h->nsf_dev; q.nnod = h->nnod; q.nout = h->nout;
-        for (int l = 0; l < h->nl; l++) q.act[l] = h->flagact[l];
+        for (int l = 0; l < h->nl; l++) q.actp |= (unsigned)(h->flagact[l] & 15) << (4 * l);
         for (int k = 0; k < 17; k++) q.gp[k] = h->gp[k];
         q.e_base = h->e_base;
         q.f = d_f; q.eatom = d_eatom; q.eng = d_eng; q.virial = d_virial; q.vatom = d_vatom; q.errflag = h->d_flags;
         const size_t lds2 = anna_lds_per_wave(q.n_cap) * ANNP_WAVES_PER_BLOCK + anna_lds_net(h->net_doubles);
+        if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
         if (d_virial || d_vatom) hipLaunchKernelGGL((annp_anna_adp<true>), dim3(anna_blocks(inum)), dim3(256), lds2, s, q);
         else hipLaunchKernelGGL((annp_anna_adp<false>), dim3(anna_blocks(inum)), dim3(256), lds2, s, q);
         HIP_TRY(h, hipGetLastError());
@@ -545,6 +581,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
         a.n_cap = cap_force;
         h->cap_last = cap_force;
+        if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
         ni_launch_force(a, h->ni_shape, d_virial != nullptr || d_vatom != nullptr, s);
         HIP_TRY(h, hipGetLastError());
     }
@@ -555,6 +592,47 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[3], s)); h->ev_count++; }
     (void)nall; (void)d_type;
     return 0;
+}
+
+// CPUs this process may use: the affinity mask capped by the cgroup quota (hardware_concurrency() knows neither, and
+// under the usual one-core-per-rank MPI binding sixteen copy threads would time-share that one core)
+int usable_cpus()
+{
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32];
+        long long period = 0;
+        if (std::fscanf(fp, "%31s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0)
+            n = (int)std::min<long long>(n, std::max<long long>(1, std::atoll(quota) / period));
+        std::fclose(fp);
+    }
+    return n;
+}
+
+int ensure_pool(annp_hip_handle *h)
+{
+    if (h->pool) return 0;
+    int nthr = std::min(usable_cpus(), 8);
+    if (const char *e = std::getenv("ANNP_HIP_COPY_THREADS")) nthr = std::max(1, std::atoi(e));
+    h->pool = new (std::nothrow) CopyPool(nthr - 1);
+    if (!h->pool) return fail(h, ANNP_HIP_ENOMEM, "host allocation failed");
+    return 0;
+}
+
+// pinned staging buffers (32 MB each) + their events, shared by the host-list upload and the list hand-back
+int ensure_list_staging(annp_hip_handle *h)
+{
+    for (int b = 0; b < annp_hip_handle::kListBufs; b++) {
+        if (!h->pin_list[b]) {
+            HIP_TRY(h, hipHostMalloc((void **)&h->pin_list[b], annp_hip_handle::kListChunk * sizeof(int)));
+            h->bytes += annp_hip_handle::kListChunk * sizeof(int);
+        }
+        if (!h->ev_list[b]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_list[b], hipEventDisableTiming));
+    }
+    return ensure_pool(h);
 }
 
 }  // namespace
@@ -593,6 +671,11 @@ void annp_hip_clear(annp_hip_handle *h)
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     if (h->ev_flags) (void)hipEventDestroy(h->ev_flags);
+    if (h->reg_x.ok) (void)hipHostUnregister(const_cast<void *>(h->reg_x.ptr));
+    if (h->reg_f.ok) (void)hipHostUnregister(const_cast<void *>(h->reg_f.ptr));
+    if (h->pin_x) (void)hipHostFree(h->pin_x);
+    if (h->ev_f_up) (void)hipEventDestroy(h->ev_f_up);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->pin_f) (void)hipHostFree(h->pin_f);
     if (h->pin_e) (void)hipHostFree(h->pin_e);
     if (h->pin_v) (void)hipHostFree(h->pin_v);
@@ -680,9 +763,13 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     INIT_TRY(guard_.err);
     INIT_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     INIT_TRY(hipEventCreateWithFlags(&h->ev_flags, hipEventDisableTiming));
+    INIT_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    INIT_TRY(hipEventCreateWithFlags(&h->ev_f_up, hipEventDisableTiming));
+    if (const char *e = std::getenv("ANNP_HIP_REGISTER")) h->use_register = std::atoi(e) != 0;
     h->descriptor = p->descriptor; h->ntypes = p->ntypes; h->ntl = p->ntl; h->nhl = p->nhl; h->nnod = p->nnod;
     h->nsf = p->nsf; h->npsf = p->npsf; h->ntsf = p->ntsf; h->nl = nl; h->ni_compat = p->ni_compat;
     h->e_scale = p->e_scale; h->e_shift = p->e_shift; h->e_atom = p->e_atom; h->cut = p->cut;
+    if (const char *e = std::getenv("ANNP_HIP_FULL_LIST")) h->full_list = std::atoi(e) != 0;
     h->cutsq = cutsq_all;
     h->nelem = ne; h->multi = multi; h->active = active;
     if (multi) {
@@ -1009,13 +1096,26 @@ int annp_hip_neigh_build_device(annp_hip_handle *h, int nlocal, int nall, const 
     DEVICE_GUARD(h);
     std::string msg;
     size_t before = h->nb.bytes;
-    int rc = neigh_build(h->nb, nlocal, nall, d_x, cutneigh, (hipStream_t)stream, msg);
+    int rc = neigh_build(h->nb, nlocal, nall, d_x, list_cutoff(h, cutneigh), (hipStream_t)stream, msg);
+    h->ni_primed = false;       // Behler: the evaluation behind a rebuild sizes its records from its own counts (one sync)
     h->bytes += h->nb.bytes - before;
     if (rc) return fail(h, rc, "%s", msg.c_str());
     if (d_numneigh) *d_numneigh = h->nb.numneigh;
     if (d_first) *d_first = h->nb.first;
     if (d_neigh) *d_neigh = h->nb.neigh;
     if (max_numneigh) *max_numneigh = h->nb.max_numneigh;
+    return 0;
+}
+
+double annp_hip_list_cutoff(const annp_hip_handle *h, double cutneigh) { return h ? list_cutoff(h, cutneigh) : cutneigh; }
+
+int annp_hip_list_layout(const annp_hip_handle *h, int *info4)
+{
+    if (!h || !info4) return ANNP_HIP_EARG;
+    info4[0] = (h->nb.valid && h->nb.pitched) ? 1 : 0;
+    info4[1] = h->nb.valid ? (h->nb.pitched ? h->nb.pitch_used : 0) : 0;
+    info4[2] = h->nb.valid ? h->nb.max_numneigh : 0;
+    info4[3] = h->nb.valid ? h->nb.nlocal : 0;
     return 0;
 }
 
@@ -1039,14 +1139,92 @@ int annp_hip_neigh_to_host(annp_hip_handle *h, int nlocal, int *numneigh, long l
         HIP_TRY(h, hipMemcpy(neigh, h->nb.neigh, sizeof(int) * (size_t)tot, hipMemcpyDeviceToHost));
         return 0;
     }
+    // rows sit `pitch` entries apart on the device: whole rows come over in chunks through the pinned staging buffers
+    // of the list upload, and a chunk is packed by the copy threads while the next one is on the wire
     const size_t pitch = (size_t)h->nb.pitch_used;
-    std::vector<int> raw((size_t)nlocal * pitch);
-    HIP_TRY(h, hipMemcpy(raw.data(), h->nb.neigh, sizeof(int) * raw.size(), hipMemcpyDeviceToHost));
-    long long w = 0;
-    for (int i = 0; i < nlocal; i++) {
-        std::memcpy(neigh + w, raw.data() + (size_t)i * pitch, sizeof(int) * (size_t)numneigh[i]);
-        w += numneigh[i];
+    int rc;
+    if ((rc = ensure_list_staging(h))) return rc;
+    std::vector<long long> offs;
+    const long long *off = first;
+    if (!off) {
+        offs.resize((size_t)nlocal + 1);
+        long long t = 0;
+        for (int i = 0; i < nlocal; i++) { offs[i] = t; t += numneigh[i]; }
+        offs[nlocal] = t;
+        off = offs.data();
     }
+    const int rows_per_chunk = (int)std::max<size_t>(1, annp_hip_handle::kListChunk / std::max<size_t>(pitch, 1));
+    if (pitch > annp_hip_handle::kListChunk) return fail(h, ANNP_HIP_ENEIGHCAP, "a list row has %zu entries", pitch);
+    hipStream_t s = h->stream;
+    const int nchunks = (nlocal + rows_per_chunk - 1) / rows_per_chunk;
+    auto pack = [&](int c) -> int {
+        const int b = c % annp_hip_handle::kListBufs;
+        HIP_TRY(h, hipEventSynchronize(h->ev_list[b]));
+        const int i0 = c * rows_per_chunk, i1 = std::min(nlocal, i0 + rows_per_chunk);
+        const int *src = h->pin_list[b];
+        h->pool->run([=](int part, int nparts) {
+            const int span = i1 - i0, lo = i0 + (int)((long long)span * part / nparts), hi = i0 + (int)((long long)span * (part + 1) / nparts);
+            for (int i = lo; i < hi; i++)
+                if (numneigh[i] > 0) std::memcpy(neigh + off[i], src + (size_t)(i - i0) * pitch, sizeof(int) * (size_t)numneigh[i]);
+        });
+        return 0;
+    };
+    for (int c = 0; c < nchunks; c++) {
+        const int b = c % annp_hip_handle::kListBufs;
+        const int i0 = c * rows_per_chunk, i1 = std::min(nlocal, i0 + rows_per_chunk);
+        HIP_TRY(h, hipMemcpyAsync(h->pin_list[b], h->nb.neigh + (size_t)i0 * pitch, sizeof(int) * (size_t)(i1 - i0) * pitch, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipEventRecord(h->ev_list[b], s));
+        if (c > 0 && (rc = pack(c - 1))) return rc;     // chunk c is in flight while chunk c-1 is packed; with 3 buffers chunk c+1 never lands on one still being read
+    }
+    if (nchunks > 0 && (rc = pack(nchunks - 1))) return rc;
+    return 0;
+}
+
+// ---- the step around the evaluation (step_kernels.hpp): device pointers, asynchronous on `stream` -------------------
+int annp_hip_halo_pack(annp_hip_handle *h, int n, const int *d_idx, const double *d_shift, const double *d_x, double *d_out, void *stream)
+{
+    if (!h || n < 0 || (n > 0 && (!d_idx || !d_shift || !d_x || !d_out))) return h ? fail(h, ANNP_HIP_EARG, "halo_pack: bad argument") : ANNP_HIP_EARG;
+    if (n == 0) return 0;
+    DEVICE_GUARD(h);
+    hipLaunchKernelGGL(annp_gather_shift, dim3((3 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, d_idx, d_shift, d_x, d_out);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int annp_hip_halo_unpack_images(annp_hip_handle *h, int nimg, const int *d_root, const double *d_shift, double *d_x, int first_image_row,
+                                double *d_f_clear, long long n_clear, double *d_eng_clear, void *stream)
+{
+    if (!h || nimg < 0 || first_image_row < 0 || n_clear < 0 || (nimg > 0 && (!d_root || !d_shift || !d_x)))
+        return h ? fail(h, ANNP_HIP_EARG, "halo_unpack_images: bad argument") : ANNP_HIP_EARG;
+    const long long work = std::max<long long>(std::max<long long>(3ll * nimg, d_f_clear ? n_clear : 0), d_eng_clear ? 1 : 0);
+    if (work == 0) return 0;
+    DEVICE_GUARD(h);
+    hipLaunchKernelGGL(annp_images_clear, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nimg, d_root, d_shift, d_x,
+                       (long long)first_image_row, d_f_clear, n_clear, d_eng_clear);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int annp_hip_reverse_fold(annp_hip_handle *h, int nseg, const int *d_seg_dst, const int *d_seg_start, const int *d_perm,
+                          const double *d_src, double *d_f, void *stream)
+{
+    if (!h || nseg < 0 || (nseg > 0 && (!d_seg_dst || !d_seg_start || !d_perm || !d_src || !d_f)))
+        return h ? fail(h, ANNP_HIP_EARG, "reverse_fold: bad argument") : ANNP_HIP_EARG;
+    if (nseg == 0) return 0;
+    DEVICE_GUARD(h);
+    hipLaunchKernelGGL(annp_segment_add, dim3((3 * nseg + 255) / 256), dim3(256), 0, (hipStream_t)stream, nseg, d_seg_dst, d_seg_start, d_perm, d_src, d_f);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int annp_hip_verlet_half(annp_hip_handle *h, int n, double *d_x, double *d_v, const double *d_f, double dtf, double dt, void *stream)
+{
+    if (!h || n < 0 || (n > 0 && (!d_v || !d_f || (dt != 0.0 && !d_x)))) return h ? fail(h, ANNP_HIP_EARG, "verlet_half: bad argument") : ANNP_HIP_EARG;
+    if (n == 0) return 0;
+    DEVICE_GUARD(h);
+    const long long n3 = 3ll * n;
+    hipLaunchKernelGGL(annp_verlet_half, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n3, d_x, d_v, d_f, dtf, dt);
+    HIP_TRY(h, hipGetLastError());
     return 0;
 }
 
@@ -1063,13 +1241,67 @@ static int ensure_pinned(annp_hip_handle *h, double *&p, size_t &cap, size_t n)
     return 0;
 }
 
-static int host_finish(annp_hip_handle *h, int inum, int nall, int eflag, int vflag, int eatom_flag,
+// The caller's arrays (LAMMPS atom->x[0], atom->f[0]) are page-locked where they lie, once: LAMMPS reallocates them only
+// when nmax grows, so the registration is cached by address and length and redone when either changes.  A registered array
+// is read and written by the copy engine directly (no bounce through a pinned buffer, no host loop over it).  When the
+// runtime refuses (or ANNP_HIP_REGISTER=0) the pinned staging buffers of the handle are used instead.
+static bool host_register(annp_hip_handle *h, annp_hip_handle::HostReg &r, const void *ptr, size_t bytes)
+{
+    if (!h->use_register || !ptr || bytes == 0) return false;
+    if (r.ptr == ptr && r.bytes >= bytes) return r.ok;
+    if (r.ok) { (void)hipHostUnregister(const_cast<void *>(r.ptr)); r.ok = false; }
+    r.ptr = ptr; r.bytes = bytes;
+    const hipError_t e = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) (void)hipGetLastError();
+    r.ok = e == hipSuccess;
+    return r.ok;
+}
+
+// dst[k] += src[k] (or dst[k] = src[k]) over n doubles, split over the copy threads
+static void host_fold(annp_hip_handle *h, double *dst, const double *src, size_t n, bool add)
+{
+    auto job = [=](int part, int nparts) {
+        const size_t lo = n * (size_t)part / (size_t)nparts, hi = n * (size_t)(part + 1) / (size_t)nparts;
+        if (add) for (size_t k = lo; k < hi; k++) dst[k] += src[k];
+        else std::memcpy(dst + lo, src + lo, sizeof(double) * (hi - lo));
+    };
+    if (h->pool && n >= (size_t)1 << 16) h->pool->run(job); else job(0, 1);
+}
+
+// positions -> h->x
+static int upload_x(annp_hip_handle *h, const double *host_x, int nall, hipStream_t s)
+{
+    int rc;
+    const size_t n = (size_t)nall * 3;
+    if ((rc = ensure(h, h->x, n))) return rc;
+    if (n == 0) return 0;
+    if (host_register(h, h->reg_x, host_x, n * sizeof(double))) {
+        HIP_TRY(h, hipMemcpyAsync(h->x.p, host_x, n * sizeof(double), hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    if ((rc = ensure_pool(h)) || (rc = ensure_pinned(h, h->pin_x, h->pin_x_cap, n))) return rc;
+    host_fold(h, h->pin_x, host_x, n, false);
+    HIP_TRY(h, hipMemcpyAsync(h->x.p, h->pin_x, n * sizeof(double), hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+// Results of the evaluation on h->stream -> the caller's arrays (+= semantics, fe:185-211).  Nothing of the caller's is
+// touched before the evaluation is known to be complete (a Behler capacity error makes the caller re-issue it).
+static int host_finish(annp_hip_handle *h, int inum, int nall, int eflag, int vflag, int eatom_flag, bool f_on_device,
                        double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom)
 {
     hipStream_t s = h->stream;
     int rc;
-    if ((rc = ensure_pinned(h, h->pin_f, h->pin_f_cap, (size_t)nall * 3))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->pin_f, h->f.p, sizeof(double) * nall * 3, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->h_scalars, h->d_scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (int rcf = poll_flags(h, true)) return rcf;
+    const size_t nf = (size_t)nall * 3;
+    if (f_on_device) {          // h->f started from the caller's f: the sum comes back into place
+        HIP_TRY(h, hipMemcpyAsync(f, h->f.p, sizeof(double) * nf, hipMemcpyDeviceToHost, s));
+    } else {
+        if ((rc = ensure_pinned(h, h->pin_f, h->pin_f_cap, nf))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->pin_f, h->f.p, sizeof(double) * nf, hipMemcpyDeviceToHost, s));
+    }
     const bool want_e = eflag && eatom_flag && eatom;
     if (want_e) {
         if ((rc = ensure_pinned(h, h->pin_e, h->pin_e_cap, (size_t)nall))) return rc;
@@ -1079,13 +1311,11 @@ static int host_finish(annp_hip_handle *h, int inum, int nall, int eflag, int vf
         if ((rc = ensure_pinned(h, h->pin_v, h->pin_v_cap, (size_t)nall * 6))) return rc;
         HIP_TRY(h, hipMemcpyAsync(h->pin_v, h->vatom.p, sizeof(double) * nall * 6, hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(h, hipMemcpyAsync(h->h_scalars, h->d_scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
-    if (int rcf = poll_flags(h, true)) return rcf;
-    if (vatom) { const double *hv = h->pin_v; for (size_t k = 0; k < (size_t)nall * 6; k++) vatom[k] += hv[k]; }
-    { const double *hf = h->pin_f; for (size_t k = 0; k < (size_t)nall * 3; k++) f[k] += hf[k]; }     // fe:199,211: += / -=
-    if (eflag && eng_vdwl) *eng_vdwl += h->h_scalars[0];                          // fe:185
-    if (want_e) { const double *he = h->pin_e; for (int k = 0; k < nall; k++) eatom[k] += he[k]; }   // fe:186
+    if (!f_on_device) host_fold(h, f, h->pin_f, nf, true);                         // fe:199,211: += / -=
+    if (vatom) host_fold(h, vatom, h->pin_v, (size_t)nall * 6, true);
+    if (want_e) host_fold(h, eatom, h->pin_e, (size_t)nall, true);                 // fe:186
+    if (eflag && eng_vdwl) *eng_vdwl += h->h_scalars[0];                           // fe:185
     if (vflag && virial) for (int k = 0; k < 6; k++) virial[k] += h->h_scalars[1 + k];
     (void)inum;
     return 0;
@@ -1101,25 +1331,44 @@ static int host_evaluate(annp_hip_handle *h, int inum, int nall, const int *host
 {
     hipStream_t s = h->stream;
     int rc;
+    if ((rc = ensure_pool(h))) return rc;
     if ((rc = ensure(h, h->f, (size_t)nall * 3)) || (rc = ensure(h, h->eatom, (size_t)nall))) return rc;
     if (vatom && (rc = ensure(h, h->vatom, (size_t)nall * 6))) return rc;
     const int *d_type = nullptr;
     if (h->multi) {             // atom types select the element's network (and drop atoms of unmapped types)
         if (!host_type) return fail(h, ANNP_HIP_EARG, "this potential distinguishes atom types: host_type is required");
+        for (int k = 0; k < nall; k++)          // map[type] and the type's bit of `active` are indexed with it on the device
+            if (host_type[k] < 1 || host_type[k] > h->ntypes)
+                return fail(h, ANNP_HIP_EARG, "type[%d] = %d is outside 1..%d", k, host_type[k], h->ntypes);
         if ((rc = ensure(h, h->type, (size_t)nall))) return rc;
         HIP_TRY(h, hipMemcpyAsync(h->type.p, host_type, sizeof(int) * (size_t)nall, hipMemcpyHostToDevice, s));
         d_type = h->type.p;
     }
     const bool want_eatom = eflag && eatom_flag && eatom;
+    const size_t nf = (size_t)nall * 3;
+    // f: the device accumulates on top of the caller's values, uploaded on a second stream while the descriptor and
+    // network passes run (the force pass waits for it), and the sum is copied back into place -- no host loop over f
+    const bool f_on_device = nall > 0 && host_register(h, h->reg_f, f, nf * sizeof(double));
     for (int attempt = 0;; attempt++) {
-        HIP_TRY(h, hipMemsetAsync(h->f.p, 0, sizeof(double) * (size_t)nall * 3, s));
+        if (f_on_device) {
+            HIP_TRY(h, hipMemcpyAsync(h->f.p, f, nf * sizeof(double), hipMemcpyHostToDevice, h->stream2));
+            HIP_TRY(h, hipEventRecord(h->ev_f_up, h->stream2));
+            h->pre_force_wait = h->ev_f_up;
+        } else {
+            HIP_TRY(h, hipMemsetAsync(h->f.p, 0, sizeof(double) * nf, s));
+        }
         HIP_TRY(h, hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), s));
         if (want_eatom) HIP_TRY(h, hipMemsetAsync(h->eatom.p, 0, sizeof(double) * (size_t)nall, s));
         if (vatom) HIP_TRY(h, hipMemsetAsync(h->vatom.p, 0, sizeof(double) * (size_t)nall * 6, s));
         rc = compute_device_impl(h, inum, nall, h->x.p, d_type, d_ilist, d_numneigh, d_first, d_neigh, max_numneigh,
                                  h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr,
                                  vatom ? h->vatom.p : nullptr, s);
-        if (!rc) rc = host_finish(h, inum, nall, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, vatom);
+        if (h->pre_force_wait) {        // the evaluation returned before its force pass (error, inum == 0): the upload still has to land
+            (void)hipStreamWaitEvent(s, h->pre_force_wait, 0);
+            h->pre_force_wait = nullptr;
+        }
+        if (!rc) rc = host_finish(h, inum, nall, eflag, vflag, eatom_flag, f_on_device, f, eng_vdwl, eatom, virial, vatom);
+        else (void)hipStreamSynchronize(s);
         if (rc == ANNP_HIP_ENEIGHCAP && attempt == 0 && h->descriptor == ANNP_HIP_DESC_BEHLER && !h->ni_primed) continue;
         return rc;
     }
@@ -1141,17 +1390,7 @@ static int upload_host_list(annp_hip_handle *h, int inum, int nall, const int *i
         HIP_TRY(h, hipHostMalloc((void **)&h->pin_num, want * sizeof(int)));
         h->pin_hdr_cap = want;
     }
-    for (int b = 0; b < annp_hip_handle::kListBufs; b++) {
-        if (!h->pin_list[b]) HIP_TRY(h, hipHostMalloc((void **)&h->pin_list[b], annp_hip_handle::kListChunk * sizeof(int)));
-        if (!h->ev_list[b]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_list[b], hipEventDisableTiming));
-    }
-    if (!h->pool) {
-        const unsigned hc = std::thread::hardware_concurrency();
-        int nthr = (int)std::min<unsigned>(hc ? hc : 4u, 16u);
-        if (const char *e = std::getenv("ANNP_HIP_COPY_THREADS")) nthr = std::max(1, std::atoi(e));
-        h->pool = new (std::nothrow) CopyPool(nthr - 1);
-        if (!h->pool) return fail(h, ANNP_HIP_ENOMEM, "host allocation failed");
-    }
+    if ((rc = ensure_list_staging(h))) return rc;
     // headers: offsets in ilist order
     std::memset(h->pin_first, 0, sizeof(long long) * ((size_t)nall + 1));
     std::memset(h->pin_num, 0, sizeof(int) * (size_t)nall);
@@ -1219,8 +1458,7 @@ int annp_hip_compute(annp_hip_handle *h, int ago, int inum, int nall, int nghost
     if (ago == 0 || !h->list_valid) {
         if ((rc = upload_host_list(h, inum, nall, ilist, numj, firstneigh, s))) return rc;
     }
-    if ((rc = ensure(h, h->x, (size_t)nall * 3))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->x.p, host_x, sizeof(double) * (size_t)nall * 3, hipMemcpyHostToDevice, s));
+    if ((rc = upload_x(h, host_x, nall, s))) return rc;
     return host_evaluate(h, inum, nall, host_type, h->ilist.p, h->numneigh.p, h->first.p, h->neigh.p, h->list_max,
                          eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial, want_vatom ? vatom : nullptr);
 }
@@ -1239,12 +1477,12 @@ int annp_hip_compute_n(annp_hip_handle *h, int ago, int inum, int nall, int ngho
     DEVICE_GUARD(h);
     hipStream_t s = h->stream;
     int rc;
-    if ((rc = ensure(h, h->x, (size_t)nall * 3))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->x.p, host_x, sizeof(double) * (size_t)nall * 3, hipMemcpyHostToDevice, s));
+    if ((rc = upload_x(h, host_x, nall, s))) return rc;
     if (ago == 0 || !h->nb.valid || h->nb.nlocal != inum || h->nb.nall != nall) {
         std::string msg;
         size_t before = h->nb.bytes;
-        rc = neigh_build(h->nb, inum, nall, h->x.p, cutneigh, s, msg);
+        rc = neigh_build(h->nb, inum, nall, h->x.p, list_cutoff(h, cutneigh), s, msg);
+        h->ni_primed = false;
         h->bytes += h->nb.bytes - before;
         if (rc) return fail(h, rc, "%s", msg.c_str());
     }

@@ -345,7 +345,7 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     NB_TRY(hipGetLastError());
     learn_pitch();
     nb.nlocal = nlocal; nb.nall = nall; nb.valid = true; nb.pitched = false; nb.pitch_used = 0;
-    nb.mean_exact = (double)total / (double)nlocal;
+    nb.mean_exact = nlocal > 0 ? (double)total / (double)nlocal : 0.0;      // 0 = unknown
     return 0;
 #undef NB_TRY
 }

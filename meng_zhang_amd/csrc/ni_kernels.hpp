@@ -615,7 +615,8 @@ __device__ __forceinline__ int ni_prepass(const NiLds &L, const NiConst &c, NiWa
 
 // ---------------------------------------------------------------------------------
 template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM>
-__global__ __launch_bounds__(256, NI_WAVES_PER_SIMD) void annp_ni_desc(NiArgs p)
+// (the table-driven instantiation keeps NI_MAXP + NI_MAXT = 40 accumulators per lane: 128 VGPRs would spill 39 of them)
+__global__ __launch_bounds__(256, NL > 0 ? NI_WAVES_PER_SIMD : 3) void annp_ni_desc(NiArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
@@ -741,7 +742,6 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     const double *T = kc.T;
     unsigned char *wbase = lds_raw + NI_TABLE_DOUBLES * 8 + (size_t)wave * ni_lds_per_wave(cap, true, nsf);
     const NiLds L = ni_carve<true>(wbase, cap, cstride);
-    const int g = lane >> 4, l = lane & 15;
     for (int sl = lane; sl < NI_TSLOTS; sl += 64) { L.tkey[sl] = -1; L.tacc[3 * sl] = 0.0; L.tacc[3 * sl + 1] = 0.0; L.tacc[3 * sl + 2] = 0.0; }
     // add a force to atom j's entry of the run's table; after NI_TPROBE occupied slots it goes straight to global memory
     auto table_add = [&](int j, double fx, double fy, double fz) {
@@ -762,16 +762,22 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     const int ii0 = uniform((run * NI_RUN + gk) * NI_GA);
     if (ii0 >= p.inum) break;
     ni_forget_lds();            // nothing read from the LDS tables is carried from one group to the next in registers
+    // The lane number is made opaque per group: otherwise every per-lane LDS address of the staging loops below (7 record
+    // arrays x a few offsets) is computed once before the run, kept live across the pair loops and spilled to scratch
+    // (24 VGPRs, 100 B per lane before this); recomputing them costs a handful of integer adds per group.
+    int lane_q = lane;
+    asm volatile("" : "+v"(lane_q));
+    const int g = lane_q >> 4, l = lane_q & 15;
     // this wave's coefficient rows: radial as they are, angular in visit order
-    for (int idx = lane; idx < NI_GA * nsf; idx += 64) {
+    for (int idx = lane_q; idx < NI_GA * nsf; idx += 64) {
         const int gq = idx / nsf, k = idx % nsf;
         double v = 0.0;
         if (ii0 + gq < p.inum) v = p.coef[(size_t)(ii0 + gq) * ANNP_CPAD + (k < p.npsf ? k : p.npsf + tab.perm[k - p.npsf])];
         L.coef[gq * cstride + k] = v;
     }
     int nl;
-    const int nmax = ni_stage_compact(p, ii0, L, T, lane, nl);
-    if (nmax > cap) { if (lane == 0) atomicMax(p.errflag, nmax); wave_lds_sync(); continue; }
+    const int nmax = ni_stage_compact(p, ii0, L, T, lane_q, nl);
+    if (nmax > cap) { if (lane_q == 0) atomicMax(p.errflag, nmax); wave_lds_sync(); continue; }
     wave_lds_sync();
     const double *cr = L.coef + g * cstride;        // radial weights of this lane's atom
     const double *cw = cr + p.npsf;                 // angular, visit order

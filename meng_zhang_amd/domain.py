@@ -89,7 +89,7 @@ class SlabDomain:
     the slab neighbours, then the local periodic images.  ``ids`` (global atom id) and every tensor in ``extra``
     (e.g. velocities) belong to the owned atoms and migrate with them."""
 
-    def __init__(self, box, periodic, rc_halo, device, transport=None, x_own=None, ids=None, extra=None):
+    def __init__(self, box, periodic, rc_halo, device, transport=None, x_own=None, ids=None, extra=None, hip=None):
         import torch
         self.torch = torch
         self.tp = transport if transport is not None else NoTransport()
@@ -118,10 +118,11 @@ class SlabDomain:
         self.nghost = self.nall = 0
         self.n_replans = 0
         self.migrated_last = 0
+        self.hip = hip                  # (lib, handle): the per-step jobs run as libannp_hip.so kernels (else torch ops)
         self.replan()
 
     @classmethod
-    def from_global(cls, x_global, box, periodic, rc_halo, device, transport=None, extra=None):
+    def from_global(cls, x_global, box, periodic, rc_halo, device, transport=None, extra=None, hip=None):
         """Every rank holds the same global configuration (synthetic inputs) and keeps the atoms of its slab."""
         tp = transport if transport is not None else NoTransport()
         box = np.asarray(box, dtype=np.float64)
@@ -133,7 +134,7 @@ class SlabDomain:
         owner = np.clip(np.floor((xw[:, 0] - box[0]) / L[0] * tp.world).astype(np.int64), 0, tp.world - 1)
         mine = np.nonzero(owner == tp.rank)[0]
         ex = {k: np.asarray(v)[mine] for k, v in (extra or {}).items()}
-        return cls(box, periodic, rc_halo, device, tp, x_global[mine], mine, ex)
+        return cls(box, periodic, rc_halo, device, tp, x_global[mine], mine, ex, hip)
 
     # ------------------------------------------------------------------ wire helpers
     def _route(self, send, n_l, n_r, recv, m_r, m_l):
@@ -298,6 +299,35 @@ class SlabDomain:
         self._fwd = self._route(self.sendbuf, n_l, n_r, self.x[n:n + nxg], m_r, m_l)
         self._rev = self._route_back(self.f[n:n + nxg], m_r, m_l, self.backbuf, n_l, n_r)
         self.bytes_per_exchange = (n_l + n_r) * 24
+        if self.hip is not None:
+            self._plan_hip()
+
+    # ------------------------------------------------------------------ the per-step jobs as HIP kernels
+    def _segments(self, targets):
+        """rows k of a source array are added to row targets[k] of f: group them by target, in a fixed order
+        (annp_hip_reverse_fold's seg_dst / seg_start / perm, int32)"""
+        t = self.torch
+        order = t.argsort(targets, stable=True)
+        dst, counts = t.unique_consecutive(targets[order], return_counts=True)
+        start = t.zeros(dst.numel() + 1, dtype=t.int32, device=self.device)
+        if dst.numel():
+            start[1:] = t.cumsum(counts, 0).to(t.int32)
+        return dst.to(t.int32).contiguous(), start, order.to(t.int32).contiguous()
+
+    def _plan_hip(self):
+        t = self.torch
+        self.send_idx32 = self.send_idx.to(t.int32).contiguous()
+        self.img_root32 = self.img_root.to(t.int32).contiguous()
+        self._img_seg = self._segments(self.img_root)
+        self._back_seg = self._segments(self.send_idx)
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def _hip_check(self, rc, what):
+        if rc != 0:
+            lib, h = self.hip
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, lib.annp_hip_last_error(h).decode()))
 
     def replan(self):
         """Comm::exchange + Comm::borders: call whenever the neighbour list is rebuilt."""
@@ -306,27 +336,70 @@ class SlabDomain:
         self.n_replans += 1
 
     # ------------------------------------------------------------------ per step
-    def forward(self):
-        """Comm::forward_comm: positions owners -> ghosts"""
+    def forward(self, clear_forces=False, eng=None):
+        """Comm::forward_comm: positions owners -> ghosts.  clear_forces: also zero f (and the energy word `eng`) for the
+        evaluation that follows -- Verlet::force_clear, fused into the image-fill launch on the HIP path."""
         t = self.torch
         n = self.nlocal
+        np0 = n + self.nxg
+        if self.hip is not None:
+            lib, h = self.hip
+            st = self._stream()
+            if self._fwd:
+                self._hip_check(lib.annp_hip_halo_pack(h, self.n_l + self.n_r, self.send_idx32.data_ptr(), self.send_shift.data_ptr(),
+                                                       self.x.data_ptr(), self.sendbuf.data_ptr(), st), "halo_pack")
+                self.tp.route(self._fwd)
+            if self.nimg or clear_forces:
+                self._hip_check(lib.annp_hip_halo_unpack_images(
+                    h, self.nimg, self.img_root32.data_ptr(), self.img_shift.data_ptr(), self.x.data_ptr(), np0,
+                    self.f.data_ptr() if clear_forces else None, 3 * self.nall if clear_forces else 0,
+                    eng.data_ptr() if (clear_forces and eng is not None) else None, self._stream()), "halo_unpack_images")
+            return
         if self._fwd:
             t.index_select(self.x[:n], 0, self.send_idx, out=self.sendbuf)
             self.sendbuf += self.send_shift
             self.tp.route(self._fwd)
         if self.nimg:
-            np0 = n + self.nxg
             t.index_select(self.x[:np0], 0, self.img_root, out=self.x[np0:])      # roots are owned atoms or wire ghosts
             self.x[np0:] += self.img_shift
+        if clear_forces:
+            self.f.zero_()
+            if eng is not None:
+                eng.zero_()
 
     def reverse(self):
         """Comm::reverse_comm: ghost forces -> owners (newton_pair on, fe_v2/src/pair_annp.cpp:199)"""
         n = self.nlocal
-        if self.nimg:       # images first: their roots may be wire ghosts, whose total then travels
-            self.f[: n + self.nxg].index_add_(0, self.img_root, self.f[n + self.nxg:])
+        np0 = n + self.nxg
+        if self.hip is not None:
+            lib, h = self.hip
+            if self.nimg:       # images first: their roots may be wire ghosts, whose total then travels
+                dst, start, perm = self._img_seg
+                self._hip_check(lib.annp_hip_reverse_fold(h, int(dst.numel()), dst.data_ptr(), start.data_ptr(), perm.data_ptr(),
+                                                          self.f.data_ptr() + 24 * np0, self.f.data_ptr(), self._stream()), "reverse_fold")
+            if self._rev:
+                self.tp.route(self._rev)
+                dst, start, perm = self._back_seg
+                self._hip_check(lib.annp_hip_reverse_fold(h, int(dst.numel()), dst.data_ptr(), start.data_ptr(), perm.data_ptr(),
+                                                          self.backbuf.data_ptr(), self.f.data_ptr(), self._stream()), "reverse_fold")
+            return
+        if self.nimg:
+            self.f[:np0].index_add_(0, self.img_root, self.f[np0:])
         if self._rev:
             self.tp.route(self._rev)
             self.f.index_add_(0, self.send_idx, self.backbuf)
+
+    def verlet_half(self, v, dtf, dt=0.0):
+        """FixNVE: v += dtf f, then x += dt v when dt != 0 (initial_integrate); dt = 0 is final_integrate"""
+        n = self.nlocal
+        if self.hip is not None:
+            lib, h = self.hip
+            self._hip_check(lib.annp_hip_verlet_half(h, n, self.x.data_ptr(), v.data_ptr(), self.f.data_ptr(), float(dtf), float(dt),
+                                                     self._stream()), "verlet_half")
+            return
+        v.add_(self.f[:n], alpha=dtf)
+        if dt != 0.0:
+            self.x[:n].add_(v, alpha=dt)
 
     def max_displacement(self):
         """largest distance an owned atom has moved since the last replan, over all ranks

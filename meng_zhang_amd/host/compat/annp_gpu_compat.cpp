@@ -208,9 +208,11 @@ int **annp_gpu_compute_n(double *eatom_annp, double &eng_vdwl_annp, double **f, 
                       return annp_hip_compute_n(S.h, ago, inum, nall, nghost, x, host_type, sublo, subhi, S.cutneigh,
                                                 eflag ? 1 : 0, 0, ea ? 1 : 0, vv ? 1 : 0, ff, e, ea, nullptr, vv);
                   });
-    // Hand the list back as lal_base_annp.cpp:159-175 does (ilist, jnum, firstneigh on the host).  The reference
-    // caller does not read it (host_start == inum); it costs one device-to-host copy of the list per rebuild, which
-    // ANNP_HIP_RETURN_LIST=0 skips (firstneigh rows are then null, ilist / jnum still valid).
+    // What lal_base_annp.cpp:159-175 hands back is ilist, jnum and firstneigh on the host.  The reference caller reads none
+    // of it (host_start == inum: nothing is left for the CPU), and the reference library itself fills host rows only for
+    // the host_inum atoms it leaves to the CPU, so by default only ilist and jnum come back (4 bytes per atom, once per
+    // rebuild) and the firstneigh rows stay null.  ANNP_HIP_RETURN_LIST=1 copies the rows too (one device-to-host copy of
+    // the whole list per rebuild, chunked through pinned staging: ~0.9 GB at 1 M atoms).
     if (success && (ago == 0 || !S.list_current || (int)S.ilist.size() != inum)) {
         S.ilist.resize((size_t)inum);
         for (int i = 0; i < inum; i++) S.ilist[i] = i;
@@ -218,7 +220,7 @@ int **annp_gpu_compute_n(double *eatom_annp, double &eng_vdwl_annp, double **f, 
         S.first.assign((size_t)inum + 1, 0);
         S.firstneigh.assign((size_t)inum + 1, nullptr);
         const char *rl = std::getenv("ANNP_HIP_RETURN_LIST");
-        const bool rows = !(rl && std::strcmp(rl, "0") == 0);
+        const bool rows = rl && std::strcmp(rl, "1") == 0;
         long long total = 0;
         int rc = inum > 0 ? annp_hip_neigh_to_host(S.h, inum, S.jnum.data(), S.first.data(), nullptr, 0, &total) : 0;
         if (rc == 0 && rows && inum > 0) {

@@ -4,10 +4,10 @@
 // after init, LAMMPS-style row-pointer arrays for x, f, vatom and the paged firstneigh.  TEST DRIVER: built on the
 // CPU (g++), run on the GPU box by tests/test_gpu_compat.py, which compares what it writes with the oracle.
 //
-//   annp_gpu_driver <potential.ann> <in.bin> <out.bin> host|device [scattered] El1 [El2 ...]
+//   annp_gpu_driver <potential.ann> <in.bin> <out.bin> host|device [scattered] [reverse|half] El1 [El2 ...]
 // in.bin : int32 nlocal nall ntypes ; f64 x[nall*3] ; i32 type[nall] ; i32 numneigh[nlocal] ; i32 neigh[sum]
 // out.bin: f64 energy ; f64 f[nall*3] ; f64 eatom[nall] ; f64 vatom[nall*6] ; f64 bytes ; i32 gpu_mode host_start ;
-//          device mode: i32 jnum[nlocal] ; i32 rows[sum jnum]  (the list annp_gpu_compute_n handed back)
+//          device mode: i32 have_rows ; i32 jnum[nlocal] ; i32 rows[sum jnum] if have_rows  (the list annp_gpu_compute_n handed back)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -46,6 +46,11 @@ int main(int argc, char **argv)
     int a = 5;
     const bool scattered = std::strcmp(argv[a], "scattered") == 0;
     if (scattered) a++;
+    // host mode only: the list LAMMPS hands over need not be 0..nlocal-1 (a `pair hybrid` skip list has inum < nlocal,
+    // any sort order is allowed): "reverse" = every owned atom, last first; "half" = every second owned atom, descending
+    int sublist = 0;
+    if (a < argc && std::strcmp(argv[a], "reverse") == 0) { sublist = 1; a++; }
+    else if (a < argc && std::strcmp(argv[a], "half") == 0) { sublist = 2; a++; }
     std::vector<std::string> type_elem(argv + a, argv + argc);      // element of LAMMPS type 1, 2, ...
     const int ntypes = (int)type_elem.size();
 
@@ -149,6 +154,13 @@ int main(int argc, char **argv)
     std::vector<int *> firstneigh((size_t)nall, nullptr);
     size_t off = 0;
     for (int i = 0; i < nlocal; i++) { ilist[i] = i; firstneigh[i] = neigh.data() + off; off += (size_t)numneigh[i]; }
+    int inum = nlocal;
+    if (sublist) {
+        if (mode != "host") die(1, "reverse / half: host mode only");
+        ilist.clear();
+        for (int i = nlocal - 1; i >= 0; i -= sublist) ilist.push_back(i);
+        inum = (int)ilist.size();
+    }
 
     // ---- PairANNPGPU::compute, twice: the second call (ago = 1) reuses the list; forces accumulate, so halve
     double eng = 0.0;
@@ -159,7 +171,7 @@ int main(int argc, char **argv)
     for (int ago = 0; ago < 2; ago++) {
         double e = 0.0;
         if (mode == "host")
-            annp_gpu_compute(eatom.data(), e, f, ago, nlocal, nall, nall - nlocal, x, type.data(), ilist.data(), numneigh.data(),
+            annp_gpu_compute(eatom.data(), e, f, ago, inum, nall, nall - nlocal, x, type.data(), ilist.data(), numneigh.data(),
                              firstneigh.data(), true, true, true, true, host_start, 0.0, success, vatom);
         else
             fn_back = annp_gpu_compute_n(eatom.data(), e, f, ago, nlocal, nall, nall - nlocal, x, type.data(), sublo, subhi, nullptr,
@@ -186,8 +198,14 @@ int main(int argc, char **argv)
     if (mode != "host") {
         if (!fn_back || !ilist_back || !jnum_back) die(7, "annp_gpu_compute_n returned no list");
         for (int i = 0; i < nlocal; i++) if (ilist_back[i] != i) die(7, "ilist is not the identity");
+        // rows only when the library was asked for them (ANNP_HIP_RETURN_LIST=1); all of them or none
+        int have_rows = 0;
+        for (int i = 0; i < nlocal; i++) if (fn_back[i]) have_rows++;
+        if (have_rows != 0 && have_rows != nlocal) die(7, "some firstneigh rows are null");
+        const int flag = have_rows ? 1 : 0;
+        wr(fo_, &flag, 1);
         wr(fo_, jnum_back, (size_t)nlocal);
-        for (int i = 0; i < nlocal; i++) wr(fo_, fn_back[i], (size_t)jnum_back[i]);
+        if (flag) for (int i = 0; i < nlocal; i++) wr(fo_, fn_back[i], (size_t)jnum_back[i]);
     }
     std::fclose(fo_);
     annp_gpu_clear();

@@ -59,16 +59,20 @@ def read_output(path, s, device):
                vatom=take(np.float64, s.nall * 6).reshape(-1, 6), bytes=float(take(np.float64, 1)[0]))
     out["gpu_mode"], out["host_start"] = [int(v) for v in take(np.int32, 2)]
     if device:
+        out["have_rows"] = int(take(np.int32, 1)[0])
         out["jnum"] = take(np.int32, s.nlocal)
-        out["rows"] = take(np.int32, int(out["jnum"].sum()))
+        out["rows"] = take(np.int32, int(out["jnum"].sum())) if out["have_rows"] else None
     return out
 
 
-def run_driver(tmp_path, potfile, s, types, mode, elems, scattered=False):
+def run_driver(tmp_path, potfile, s, types, mode, elems, scattered=False, return_list=None):
     build_driver()
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     write_input(fin, s, types)
     env = dict(os.environ, ANNP_HIP_NEIGH="host" if mode == "host" else "device")
+    env.pop("ANNP_HIP_RETURN_LIST", None)
+    if return_list is not None:
+        env["ANNP_HIP_RETURN_LIST"] = return_list
     cmd = [DRIVER, potfile, fin, fout, mode] + (["scattered"] if scattered else []) + list(elems)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -106,7 +110,7 @@ def test_reference_boundary_matches_the_oracle(tmp_path, which, mode):
     pot = read_pot(potfile)
     o = oracle_compute(pot, s, kind, FAST)
     types = np.ones(s.nall, dtype=np.int32)
-    got = run_driver(tmp_path, potfile, s, types, mode, [elem], scattered=(mode == "host" and which == "ni"))
+    got = run_driver(tmp_path, potfile, s, types, mode, [elem], scattered=(mode == "host" and which == "ni"), return_list="1")
     assert got["gpu_mode"] == (0 if mode == "host" else 1) and got["host_start"] == s.nlocal and got["bytes"] > 0
     assert abs(got["energy"] - o["energy"]) < 1e-6 * s.nlocal
     assert np.abs(got["eatom"][: s.nlocal] - o["eatom"]).max() < 1e-6
@@ -114,12 +118,45 @@ def test_reference_boundary_matches_the_oracle(tmp_path, which, mode):
     v_ref = oracle_vatom(pot, s, kind)
     assert np.abs(got["vatom"] - v_ref).max() < 1e-8 * max(1.0, np.abs(v_ref).max())
     if mode == "device":            # the list handed back: same rows as the harness list, as sets (device order differs)
-        assert np.array_equal(got["jnum"], s.numneigh[: s.nlocal])
+        ref_sys = s
+        if which == "ni":           # Behler: the library cuts its own list at the descriptor cutoff + the same skin
+            rc_eff = pot.sym_ang[0][3] / 1.889726 * (1.0 + 1e-9) + (s.rc_list - pot.cut)     # annp_hip_list_cutoff
+            assert 5.8 < rc_eff < 6.0
+            ref_sys = System(s.x[: s.nlocal], box, rc_list=s.rc_list)
+            ref_sys = _relist(ref_sys, rc_eff)
+        assert got["have_rows"] == 1
+        assert np.array_equal(got["jnum"], ref_sys.numneigh[: s.nlocal])
         starts = np.concatenate([[0], np.cumsum(got["jnum"])])
         for i in range(0, s.nlocal, 29):
             mine = np.sort(got["rows"][starts[i]: starts[i + 1]])
-            ref = np.sort(s.neigh[s.first[i]: s.first[i] + s.numneigh[i]])
+            ref = np.sort(ref_sys.neigh[ref_sys.first[i]: ref_sys.first[i] + ref_sys.numneigh[i]])
             assert np.array_equal(mine, ref), i
+
+
+def _relist(s, rc):
+    """the same atoms and ghosts with the full list cut at rc (<= the cutoff the ghosts were made for)"""
+    from annp_testlib import _dp, _ip, _lp, oracle_lib
+    ol = oracle_lib()
+    s.numneigh = np.zeros(s.nall, dtype=np.int32)
+    tot = ol.harness_neigh(s.nlocal, s.nall, _dp(s.x), rc, _ip(s.numneigh), None, None)
+    s.first = np.zeros(s.nall + 1, dtype=np.int64)
+    np.cumsum(s.numneigh, out=s.first[1:])
+    s.neigh = np.empty(max(int(tot), 1), dtype=np.int32)
+    ol.harness_neigh(s.nlocal, s.nall, _dp(s.x), rc, _ip(s.numneigh), _lp(s.first), _ip(s.neigh))
+    s.rc_list = rc
+    return s
+
+
+@pytest.mark.gpu
+def test_device_mode_returns_counts_only_by_default(tmp_path):
+    """annp_gpu_compute_n hands back ilist and jnum; the firstneigh rows (which the reference caller never reads,
+    host_start == inum) are copied from the device only when ANNP_HIP_RETURN_LIST=1"""
+    x, box = bcc(5, 5, 5, A_FE)
+    s = System(perturb(x, 63, 0.05), box)
+    got = run_driver(tmp_path, FE_POT, s, np.ones(s.nall, dtype=np.int32), "device", ["Fe"])
+    assert got["have_rows"] == 0 and np.array_equal(got["jnum"], s.numneigh[: s.nlocal])
+    o = oracle_compute(read_pot(FE_POT), s, KIND_FE, FAST)
+    assert np.abs(got["f"] - o["f_all"]).max() < 1e-8
 
 
 @pytest.mark.gpu

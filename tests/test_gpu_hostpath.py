@@ -1,0 +1,182 @@
+"""The entry points LAMMPS really calls (annp_hip_compute / annp_hip_compute_n: host pointers): the two transfer routes
+-- the caller's x and f page-locked in place, or pinned staging + host folds (ANNP_HIP_REGISTER=0) -- must give the same
+numbers and the same `+=` semantics; library-built lists: the Behler cutoff rule (annp_hip_list_cutoff), the pitched
+layout a rebuild takes, its fall-back to the exact layout, and the list hand-back from either layout."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from annp_testlib import (A_FE, A_NI, FAST, FE_POT, KIND_FE, KIND_NI_COMPAT, KIND_NI_FIXED, NI_POT, System, bcc, fcc, oracle_compute,
+                          perturb)
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(potfile, elem, env=None, ni_compat=False):
+    from meng_zhang_amd import PairANNP
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        p = PairANNP(1, device=0)
+        p.settings([])
+        p.coeff(["*", "*", potfile, elem])
+        p.set_ni_compat(ni_compat)
+        p.init_style()               # the handle reads its switches here
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return p
+
+
+def attach(p, s):
+    from meng_zhang_amd import AtomData, NeighList
+    p.atom = AtomData(s.x, s.nlocal, s.type)
+    p.list = NeighList(s.ilist, s.numneigh, s.first, s.neigh)
+    p.ago = 0
+
+
+@pytest.mark.parametrize("register", ["1", "0"])
+def test_both_transfer_routes(fe_pot, register):
+    x, box = bcc(9, 9, 9, A_FE)
+    s = System(perturb(x, 7, 0.05), box)
+    o = oracle_compute(fe_pot, s, KIND_FE, FAST)
+    p = make_pair(FE_POT, "Fe", env={"ANNP_HIP_REGISTER": register})
+    attach(p, s)
+    base = np.random.default_rng(3).normal(0, 1, p.atom.f.shape)
+    for call in range(3):           # ago = 0, 1, 2: f accumulates on top of what the caller left in it (fe:199,211)
+        p.atom.f[:] = base
+        p.eatom = None
+        e = p.compute(eflag=1, vflag=1, eflag_atom=True, vflag_atom=True)
+        assert abs(e - o["energy"]) < 1e-9 * abs(o["energy"])
+        assert np.abs((p.atom.f - base) - o["f_all"]).max() < 1e-9
+        assert np.abs(p.eatom[: s.nlocal] - o["eatom"]).max() < 1e-9
+    # device-built list, same routes; then the array moves (LAMMPS grew nmax): the registration must follow it
+    for call in range(2):
+        p.atom.f[:] = base
+        p.ago = 0 if call == 0 else p.ago
+        e = p.compute_n(cutneigh=s.rc_list, eflag=1, vflag=0, eflag_atom=False)
+        assert abs(e - o["energy"]) < 1e-9 * abs(o["energy"])
+        assert np.abs((p.atom.f - base) - o["f_all"]).max() < 1e-9
+    from meng_zhang_amd import AtomData
+    grown = AtomData(np.vstack([s.x, np.zeros((0, 3))]).copy(), s.nlocal, s.type)      # new addresses for x and f
+    p.atom = grown
+    p.atom.f[:] = 2.0
+    p.ago = 5
+    p.compute_n(cutneigh=s.rc_list, eflag=1, vflag=0, eflag_atom=False)
+    assert np.abs((p.atom.f - 2.0) - o["f_all"]).max() < 1e-9
+    p.close()
+
+
+def test_list_cutoff_rule():
+    from meng_zhang_amd.lib import load_library
+    lib = load_library()
+    fe = make_pair(FE_POT, "Fe")
+    assert lib.annp_hip_list_cutoff(fe.handle, 8.5) == 8.5
+    ni = make_pair(NI_POT, "Ni")
+    c = lib.annp_hip_list_cutoff(ni.handle, 8.5)
+    assert abs(c - (7.3699319 / 1.889726 + 2.0)) < 1e-6                 # descriptor cutoff 3.9 A + the caller's 2 A skin
+    assert abs(lib.annp_hip_list_cutoff(ni.handle, 6.5) - 7.3699319 / 1.889726) < 1e-6        # no skin
+    assert lib.annp_hip_list_cutoff(ni.handle, 3.0) == 3.0             # never longer than asked for
+    compat = make_pair(NI_POT, "Ni", ni_compat=True)
+    assert lib.annp_hip_list_cutoff(compat.handle, 8.5) == 8.5         # ni:737-738 depends on list order: list as asked for
+    full = make_pair(NI_POT, "Ni", env={"ANNP_HIP_FULL_LIST": "1"})
+    assert lib.annp_hip_list_cutoff(full.handle, 8.5) == 8.5
+    for p in (fe, ni, compat, full):
+        p.close()
+
+
+def test_ni_short_list_equals_long_list(ni_pot):
+    """Behler potential, list built by the library: cut at 5.9 A instead of the 8.5 A asked for, same forces -- also after
+    the atoms have moved by up to skin / 2 without a rebuild (what the caller's rebuild criterion allows)"""
+    x, box = fcc(6, 6, 6, A_NI)
+    xg = perturb(x, 11, 0.05)
+    s = System(xg, box)
+    o = oracle_compute(ni_pot, s, KIND_NI_FIXED, FAST)
+    from meng_zhang_amd import AtomData
+    short, full = make_pair(NI_POT, "Ni"), make_pair(NI_POT, "Ni", env={"ANNP_HIP_FULL_LIST": "1"})
+    res = []
+    for p in (short, full):
+        p.atom = AtomData(s.x, s.nlocal, s.type)
+        p.ago = 0
+        e = p.compute_n(cutneigh=8.5, eflag=1, vflag=0, eflag_atom=True)
+        assert abs(e - o["energy"]) < 1e-9 * s.nlocal
+        assert np.abs(p.atom.f - o["f_all"]).max() < 1e-9
+        res.append(p.atom.f.copy())
+    assert np.abs(res[0] - res[1]).max() < 1e-12
+    # drift without rebuild: every atom moves 0.99 A (< skin / 2 = 1 A) in a random direction
+    rng = np.random.default_rng(8)
+    d = rng.normal(0, 1, (s.nlocal, 3))
+    d *= 0.99 / np.linalg.norm(d, axis=1)[:, None]
+    s2 = System(xg, box)
+    s2.refresh_ghosts(xg + d)
+    s3 = System(xg + d, box)             # fresh list at the new positions: the truth
+    o3 = oracle_compute(ni_pot, s3, KIND_NI_FIXED, FAST)
+    for p in (short, full):
+        p.atom.x[:] = s2.x
+        p.atom.f[:] = 0.0
+        p.compute_n(cutneigh=8.5, eflag=1, vflag=0, eflag_atom=False)        # ago > 0: the old list
+        assert np.abs(s2.fold(p.atom.f) - o3["f"]).max() < 1e-8
+        p.close()
+
+
+def test_pitched_rebuild_falls_back_for_uneven_rows(fe_pot):
+    """A rebuild tries the previous build's row pitch (one pass).  A free cluster has its longest row far above the mean:
+    pitch > 1.5 mean + 8 makes the build keep the exact two-pass layout; a bulk box takes the pitched one.  Either way the
+    rows handed back are the harness list's, and the evaluation is right."""
+    from meng_zhang_amd import AtomData
+    from meng_zhang_amd.lib import load_library
+    lib = load_library()
+    xb, box = bcc(7, 7, 7, A_FE)
+    bulk = System(perturb(xb, 21, 0.05), box)
+    xc, _ = bcc(5, 5, 5, A_FE)
+    cluster = System(perturb(xc, 22, 0.05) + 20.0, np.array([0, 0, 0, 60.0, 60.0, 60.0]), periodic=(0, 0, 0))
+    assert cluster.numneigh[: cluster.nlocal].max() > 1.5 * cluster.numneigh[: cluster.nlocal].mean() + 8
+    for s, want_pitched in ((bulk, True), (cluster, False)):
+        o = oracle_compute(fe_pot, s, KIND_FE, FAST)
+        p = make_pair(FE_POT, "Fe")
+        p.atom = AtomData(s.x, s.nlocal, s.type)
+        for build in range(3):      # 0: exact (nothing learned yet), 1 and 2: rebuilds
+            p.atom.f[:] = 0.0
+            p.ago = 0
+            e = p.compute_n(cutneigh=8.5, eflag=1, vflag=0, eflag_atom=False)
+            assert abs(e - o["energy"]) < 1e-9 * abs(o["energy"]) and np.abs(p.atom.f - o["f_all"]).max() < 1e-9
+            num = np.zeros(s.nlocal, dtype=np.int32)
+            first = np.zeros(s.nlocal + 1, dtype=np.int64)
+            tot = C.c_longlong(0)
+            ip, lp = C.POINTER(C.c_int), C.POINTER(C.c_longlong)
+            assert lib.annp_hip_neigh_to_host(p.handle, s.nlocal, num.ctypes.data_as(ip), first.ctypes.data_as(lp), None, 0, C.byref(tot)) == 0
+            assert np.array_equal(num, s.numneigh[: s.nlocal]) and tot.value == int(num.sum())
+            rows = np.full(tot.value, -1, dtype=np.int32)
+            assert lib.annp_hip_neigh_to_host(p.handle, s.nlocal, num.ctypes.data_as(ip), first.ctypes.data_as(lp), rows.ctypes.data_as(ip),
+                                              tot.value, C.byref(tot)) == 0
+            for i in range(0, s.nlocal, 17):
+                assert np.array_equal(np.sort(rows[first[i]: first[i + 1]]), np.sort(s.neigh[s.first[i]: s.first[i] + s.numneigh[i]])), (build, i)
+            info = (C.c_int * 4)()
+            assert lib.annp_hip_list_layout(p.handle, info) == 0
+            assert bool(info[0]) == (want_pitched and build > 0), (build, list(info))
+        p.close()
+
+
+def test_types_out_of_range_are_refused(tmp_path):
+    """potentials that read atom types index map[type] on the device: a type outside 1..ntypes is an argument error"""
+    from annp_testlib import write_ann
+    from meng_zhang_amd import AtomData, NeighList, PairANNP
+    path = write_ann(str(tmp_path / "two.ann"), nnod=10, seed=3, elements=["Fe", "Cr"])
+    x, box = bcc(4, 4, 4, A_FE)
+    s = System(perturb(x, 2, 0.05), box)
+    p = PairANNP(2, device=0)
+    p.settings([])
+    p.coeff(["*", "*", path, "Fe", "Cr"])
+    p.init_style()
+    types = np.ones(s.nall, dtype=np.int32)
+    types[5] = 3
+    p.atom = AtomData(s.x, s.nlocal, types)
+    p.list = NeighList(s.ilist, s.numneigh, s.first, s.neigh)
+    with pytest.raises(RuntimeError, match="outside 1..2"):
+        p.compute(eflag=1, vflag=0)
+    p.close()

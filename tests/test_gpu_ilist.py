@@ -1,0 +1,141 @@
+"""`i = ilist[ii]` (fe_v2/src/pair_annp.cpp:110-112): the list of central atoms LAMMPS hands over need not be
+0..nlocal-1.  A `pair hybrid` sub-style gets a skip list with inum < nlocal, and nothing promises an order.  The kernels
+index G / coef / ncount by the list slot ii and rows, positions, eatom by the atom i; here every entry point is driven
+with (i) a permuted list of all owned atoms and (ii) every second owned atom in shuffled order, for the three kernel
+families, against the oracle run on that same list: energy, eatom, forces (ghost shares included), per-atom virial."""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from annp_testlib import (A_FE, A_NI, ANNA_POT, FAST, FE_POT, KIND_FE, KIND_NI_FIXED, NI_POT, System, anna_compute, bcc, fcc,
+                          oracle_compute, oracle_vatom, perturb, read_anna, read_pot)
+from test_compat_boundary import run_driver
+
+pytestmark = pytest.mark.gpu
+
+CASES = {"fe": (FE_POT, "Fe", "annp", 8.5), "ni": (NI_POT, "Ni", "annp", 8.5), "anna": (ANNA_POT, "Fe", "anna_adp", 7.055)}
+
+
+def system(which, seed):
+    if which == "ni":
+        x, box = fcc(5, 5, 5, A_NI)
+    else:
+        x, box = bcc(6, 6, 6, A_FE)
+    return System(perturb(x, seed, 0.05), box, rc_list=CASES[which][3])
+
+
+def sublist(s, kind, seed=4):
+    rng = np.random.default_rng(seed)
+    ilist = rng.permutation(s.nlocal).astype(np.int32)
+    if kind == "half":
+        ilist = rng.permutation(np.arange(0, s.nlocal, 2)).astype(np.int32)
+    t = copy.copy(s)
+    t.ilist, t.inum = np.ascontiguousarray(ilist), len(ilist)
+    return t
+
+
+def reference(which, s):
+    """oracle on the list s.ilist: dict(energy, eatom[nall] (zero off the list), f_all, vatom)"""
+    if which == "anna":
+        o = anna_compute(read_anna(ANNA_POT), s, want_vatom=True)
+        e_at = np.zeros(s.nall)
+        # anna_compute returns eatom[:nlocal] indexed by atom
+        e_at[: s.nlocal] = o["eatom"]
+        return dict(energy=o["energy"], eatom=e_at, f_all=o["f_all"], vatom=o["vatom"])
+    pot = read_pot(CASES[which][0])
+    kind = KIND_FE if which == "fe" else KIND_NI_FIXED
+    o = oracle_compute(pot, s, kind, FAST)
+    e_at = np.zeros(s.nall)
+    e_at[: s.nlocal] = o["eatom"]
+    return dict(energy=o["energy"], eatom=e_at, f_all=o["f_all"], vatom=oracle_vatom(pot, s, kind))
+
+
+def compare(got, ref, s):
+    fs = max(1.0, np.abs(ref["f_all"]).max())
+    assert abs(got["energy"] - ref["energy"]) < 1e-9 * max(1.0, abs(ref["energy"]))
+    assert np.abs(got["eatom"] - ref["eatom"]).max() < 1e-6
+    off = np.setdiff1d(np.arange(s.nall), s.ilist)
+    assert np.all(got["eatom"][off] == 0.0)                     # atoms that are not on the list get no energy
+    assert np.abs(got["f_all"] - ref["f_all"]).max() < 1e-8 * fs
+    assert np.abs(got["vatom"] - ref["vatom"]).max() < 1e-8 * max(1.0, np.abs(ref["vatom"]).max())
+
+
+def make_pair(which):
+    from meng_zhang_amd import PairANNP
+    potfile, elem, style, _ = CASES[which]
+    p = PairANNP(1, device=0, style=style)
+    p.settings([])
+    p.coeff(["*", "*", potfile, elem])
+    p.init_style()
+    return p
+
+
+@pytest.mark.parametrize("kind", ["perm", "half"])
+@pytest.mark.parametrize("which", ["fe", "ni", "anna"])
+def test_host_entry(which, kind):
+    """annp_hip_compute through the pair-style mirror"""
+    from meng_zhang_amd import AtomData, NeighList
+    s = sublist(system(which, 71), kind)
+    ref = reference(which, s)
+    p = make_pair(which)
+    p.atom = AtomData(s.x, s.nlocal, s.type)
+    p.list = NeighList(s.ilist, s.numneigh, s.first, s.neigh)
+    e = p.compute(eflag=1, vflag=0, eflag_atom=True, vflag_atom=True)
+    compare(dict(energy=e, eatom=p.eatom.copy(), f_all=p.atom.f.copy(), vatom=p.vatom.copy()), ref, s)
+    # the list is kept on the device while ago > 0: a second call with the same list gives the same again
+    p.atom.f[:] = 0.0
+    p.eatom[:] = 0.0
+    p.vatom[:] = 0.0
+    e2 = p.compute(eflag=1, vflag=0, eflag_atom=True, vflag_atom=True)
+    compare(dict(energy=e2, eatom=p.eatom.copy(), f_all=p.atom.f.copy(), vatom=p.vatom.copy()), ref, s)
+    p.close()
+
+
+@pytest.mark.parametrize("kind", ["perm", "half"])
+@pytest.mark.parametrize("which", ["fe", "ni", "anna"])
+def test_device_entry(which, kind):
+    """annp_hip_compute_device with d_ilist"""
+    import torch
+    from meng_zhang_amd.lib import load_library
+    lib = load_library()
+    dev = torch.device("cuda", 0)
+    s = sublist(system(which, 72), kind)
+    ref = reference(which, s)
+    p = make_pair(which)
+    h = p.handle
+
+    def T(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x, il, nn, fi, ng = T(s.x), T(s.ilist), T(s.numneigh), T(s.first), T(s.neigh)
+    f = torch.zeros((s.nall, 3), dtype=torch.float64, device=dev)
+    ea = torch.zeros(s.nall, dtype=torch.float64, device=dev)
+    va = torch.zeros((s.nall, 6), dtype=torch.float64, device=dev)
+    eng = torch.zeros(1, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(2):          # the second evaluation runs with capacities learned from the first
+        f.zero_(); ea.zero_(); va.zero_(); eng.zero_()
+        rc = lib.annp_hip_compute_device(h, s.inum, s.nall, x.data_ptr(), None, il.data_ptr(), nn.data_ptr(), fi.data_ptr(), ng.data_ptr(),
+                                         int(s.numneigh.max()), f.data_ptr(), ea.data_ptr(), eng.data_ptr(), None, va.data_ptr(), st)
+        assert rc == 0, lib.annp_hip_last_error(h)
+        assert lib.annp_hip_sync(h) == 0
+        compare(dict(energy=float(eng.item()), eatom=ea.cpu().numpy(), f_all=f.cpu().numpy(), vatom=va.cpu().numpy()), ref, s)
+    counts = np.zeros(s.inum, dtype=np.int32)
+    assert lib.annp_hip_last_counts(h, counts.ctypes.data_as(C.POINTER(C.c_int)), s.inum) == 0
+    assert counts.min() > 0          # one count per list slot
+    p.close()
+
+
+@pytest.mark.parametrize("order,step", [("reverse", 1), ("half", 2)])
+@pytest.mark.parametrize("which", ["fe", "ni"])
+def test_reference_boundary(tmp_path, which, order, step):
+    """annp_gpu_compute (the reference's own signature) with ilist = nlocal-1, nlocal-1-step, ..."""
+    s = system(which, 73)
+    t = copy.copy(s)
+    t.ilist = np.ascontiguousarray(np.arange(s.nlocal - 1, -1, -step, dtype=np.int32))
+    t.inum = len(t.ilist)
+    ref = reference(which, t)
+    got = run_driver(tmp_path, CASES[which][0], s, np.ones(s.nall, dtype=np.int32), "host", [order, CASES[which][1]])
+    assert got["host_start"] == t.inum
+    compare(dict(energy=got["energy"], eatom=got["eatom"], f_all=got["f"], vatom=got["vatom"]), ref, t)

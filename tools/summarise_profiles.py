@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: fold what tools/collect_profiles.sh left under gpurun_out/<tag>prof/ into profiles/.
-    python tools/summarise_profiles.py r02
-Writes profiles/<tag>_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the bench command),
+    python tools/summarise_profiles.py r03 [ni|anna]
+Writes profiles/<tag>[_<workload>]_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the bench command),
 profiles/<tag>_bench_under_rocprof.json (the line bench.py printed in that run) and
 profiles/<tag>_pmc_counters.json (per-kernel means of the counter passes, HBM bytes per launch from FETCH_SIZE and
 WRITE_SIZE as MI355X_MICROARCH.md prescribes: separate passes, KB units, FETCH_SIZE doubled on gfx950 = upper bound)."""
@@ -14,8 +14,11 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-src = os.path.join(ROOT, "gpurun_out", tag + "prof")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+wl = sys.argv[2] if len(sys.argv) > 2 else "fe"
+suffix = "" if wl == "fe" else "_" + wl
+src = os.path.join(ROOT, "gpurun_out", tag + "prof" + suffix)
+natoms = {"fe": 1024000, "anna": 1024000, "ni": 512000}[wl]
 res = collections.defaultdict(dict)
 for f in sorted(glob.glob(os.path.join(src, "pmc*", "*counter_collection.csv"))):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -30,23 +33,26 @@ for k, e in res.items():
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
         e["hbm_bytes_lower"] = (e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024
         e["hbm_bytes_upper"] = (2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024
-out = {"command": "rocprofv3 --pmc <one counter group per pass> --output-format csv -- python3 bench.py --steps 2 --warmup 1 "
-                  "--cpu-sample 0 --rebuild-every 0   (tools/collect_profiles.sh)",
-       "workload": "1024000-atom bcc-Fe", "per_launch_mean": res}
+out = {"command": "rocprofv3 --pmc <one counter group per pass> --output-format csv -- python3 bench.py%s --steps 2 --warmup 1 "
+                  "--cpu-sample 0 --rebuild-every 0 --secondary 0   (tools/collect_profiles.sh)" % ("" if wl == "fe" else " --workload " + wl),
+       "workload": {"fe": "1024000-atom bcc-Fe", "ni": "512000-atom fcc-Ni", "anna": "1024000-atom bcc-Fe, pair_style anna_adp"}[wl],
+       "per_launch_mean": res}
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_pmc_counters.json"), "w"), indent=1, sort_keys=True)
+json.dump(out, open(os.path.join(ROOT, "profiles", tag + suffix + "_pmc_counters.json"), "w"), indent=1, sort_keys=True)
 ks = glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))
 if ks:
-    shutil.copy(ks[0], os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.csv"))
+    shutil.copy(ks[0], os.path.join(ROOT, "profiles", tag + suffix + "_bench_kernel_stats.csv"))
 bj = os.path.join(src, "bench_under_rocprof.json")
 if os.path.exists(bj):
-    shutil.copy(bj, os.path.join(ROOT, "profiles", tag + "_bench_under_rocprof.json"))
+    shutil.copy(bj, os.path.join(ROOT, "profiles", tag + suffix + "_bench_under_rocprof.json"))
 for k in sorted(res):
-    if "fe_" in k or "mlp" in k:
+    if any(t in k for t in ("fe_", "mlp", "ni_", "anna")):
         e = res[k]
         cyc = e.get("GRBM_GUI_ACTIVE", 0) / 8
-        print("%-44s valu/atom %6.0f  valu-busy %.2f  lds-busy %.2f  hbm %.2f-%.2f GB  atomics %.3g  mfma_busy_cycles %.3g" % (
-            k, e.get("SQ_INSTS_VALU", 0) / 1.024e6, e.get("SQ_ACTIVE_INST_VALU", 0) * 4 / 1024 / cyc if cyc else 0,
+        # SQ_WAVE_CYCLES counts quad-cycles summed over waves: / (cycles / 4) / 1024 SIMDs = resident waves per SIMD
+        print("%-60s valu/atom %6.0f  valu-busy %.2f  waves/SIMD %.2f  lds-busy %.2f  hbm %.2f-%.2f GB  atomics %.3g  mfma_busy_cycles %.3g" % (
+            k[:60], e.get("SQ_INSTS_VALU", 0) / natoms, e.get("SQ_ACTIVE_INST_VALU", 0) * 4 / 1024 / cyc if cyc else 0,
+            e.get("SQ_WAVE_CYCLES", 0) * 4 / 1024 / cyc if cyc else 0,
             e.get("SQ_LDS_IDX_ACTIVE", 0) / 256 / cyc if cyc else 0,     # the LDS pipe is per CU
             e.get("hbm_bytes_lower", 0) / 1e9, e.get("hbm_bytes_upper", 0) / 1e9, e.get("TCC_EA0_ATOMIC_sum", 0),
             e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)))
