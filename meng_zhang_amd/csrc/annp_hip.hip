@@ -107,6 +107,7 @@ struct annp_hip_handle {
     int descriptor = 0, ntypes = 1, ntl = 0, nhl = 0, nnod = 0, nsf = 0, npsf = 0, ntsf = 0, nl = 0;
     int nsf_dev = 0;                    // features in the device layout (Chebyshev: always 9 + 19 slots, unused ones carry zero weights)
     int ni_compat = 0;
+    bool ni_no_pairs = false;           // ANNP_HIP_NI_PAIRS=0: the Behler force pass finds its pairs itself (no lists through memory)
     bool full_list = false;             // ANNP_HIP_FULL_LIST=1: library-built lists are cut where the caller says (list_cutoff)
     // pair_style anna_adp
     int nout = 1;
@@ -129,11 +130,13 @@ struct annp_hip_handle {
     int *d_map = nullptr;               // device copy of map[0..ntypes]
     double *d_sym = nullptr;            // BEHLER: function tables (ni_kernels.hpp, "per-function tables")
     int *d_isym = nullptr;
+    unsigned long long ni_rad_em = 0;   // NiArgs::rad_em
     NiShape ni_shape = {0, 0, 0};       // {lambda} x {eta} x {zeta} product shape of the angular set (0 = none)
     std::vector<double> sym_rad, sym_ang;
     // work buffers
     DevBuf<double> G, coef, x, f, eatom, vatom;
-    DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ovf;
+    DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ni_npair, ovf;
+    DevBuf<unsigned short> ni_pairs;    // Behler: in-range (j,k) pairs per atom, descriptor pass -> force pass
     DevBuf<long long> first;
     double *d_scalars = nullptr;        // [0] energy, [1..6] virial
     int *d_flags = nullptr;             // [0] capacity error: max n of the atoms that were skipped (stays set until the host has
@@ -179,6 +182,7 @@ struct annp_hip_handle {
     long long ev_count = 0;               // evaluations recorded since timing was enabled
     bool flags_pending = false;         // a copy of d_flags into h_flags is in flight or not yet looked at
     bool mlp_attr_done = false;
+    int mlp_blocks_per_cu = 0;          // resident workgroups of the network kernel per CU (occupancy query, once)
 };
 
 namespace {
@@ -232,9 +236,19 @@ int launch_mlp(annp_hip_handle *h, const MlpArgs &a, hipStream_t s)
         h->mlp_attr_done = true;
     }
     const int ntiles = (a.inum + 15) / 16;
-    int blocks = (ntiles + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK;
-    blocks = std::max(1, std::min(blocks, 256 * 4));
-    hipLaunchKernelGGL((annp_mlp_mfma<KS0, MT, NL>), dim3(blocks), dim3(256), lds, s, a);
+    int blocks = (ntiles + MLP_WAVES_PER_BLOCK - 1) / MLP_WAVES_PER_BLOCK;
+    // waves walk over the tiles: one resident round of workgroups (as many per CU as the operand image in LDS and the
+    // 32-wave limit allow).  More than that only queues behind it.
+    if (h->mlp_blocks_per_cu == 0) {        // what really fits: LDS, registers and the 32-wave limit together
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)annp_mlp_mfma<KS0, MT, NL>, 64 * MLP_WAVES_PER_BLOCK, lds) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = (int)std::max<size_t>(1, std::min<size_t>(32 / MLP_WAVES_PER_BLOCK, (160 * 1024) / lds));
+        }
+        h->mlp_blocks_per_cu = nb;
+    }
+    blocks = std::max(1, std::min(blocks, 256 * h->mlp_blocks_per_cu));
+    hipLaunchKernelGGL((annp_mlp_mfma<KS0, MT, NL>), dim3(blocks), dim3(64 * MLP_WAVES_PER_BLOCK), lds, s, a);
     HIP_TRY(h, hipGetLastError());
     return 0;
 }
@@ -295,7 +309,9 @@ int fe_next_cap(int mx)
 }
 // Behler kernels: nothing stands behind an overflow (it is reported and the evaluation has to be re-issued), so the
 // slack is generous: an eighth of the count, at least 2.
-int ni_next_cap(int mx) { return std::max(16, round_up(mx + std::max(2, mx / 8), 4)); }
+// (in steps of 2: the force pass's LDS decides how many workgroups a CU holds -- 18 in-range neighbours of fcc Ni: capacity 20
+// = three workgroups, 24 = two)
+int ni_next_cap(int mx) { return std::max(8, round_up(mx + std::max(2, mx / 8), 2)); }
 
 // Look at the flag words an evaluation copied back.  Updates the capacities for the next evaluation and turns a
 // device-side capacity error into sticky_rc.
@@ -438,6 +454,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     MlpArgs m{};
     m.type = types; m.map = h->d_map; m.elem = 0;
     m.inum = inum; m.ilist = d_ilist; m.nsf = h->nsf_dev; m.nnod = h->nnod; m.nl = h->nl;
+    m.ncoef = h->descriptor == ANNP_HIP_DESC_CHEBYSHEV ? FE_NP + 2 * FE_NT - 1 : h->nsf_dev;
     for (int l = 0; l < std::min(h->nl, (int)MLP_MAXL); l++) m.act[l] = h->flagact[l];      // (anna_adp may have more layers; it does not use m)
     m.nmul = h->d_norm; m.nsub = h->d_norm + ANNP_GPAD; m.nden = h->d_norm + 2 * ANNP_GPAD; m.img = h->d_mlp_img;
     m.e_scale = h->e_scale; m.e_shift = h->e_shift; m.e_atom = h->e_atom;
@@ -538,16 +555,28 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.npsf = h->npsf; a.ntsf = h->ntsf; a.sym = h->d_sym; a.isym = h->d_isym; a.compat = h->ni_compat;
         a.type = types; a.active = h->active;
         a.rc_rad = h->sym_rad[2]; a.rc_ang = h->sym_ang[3];
+        a.rad_em = h->ni_rad_em;
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.vatom = d_vatom; a.ncount = h->ncount.p; a.errflag = h->d_flags;
         if (a.npsf > NI_MAXP || a.ntsf > NI_MAXT)
             return fail(h, ANNP_HIP_ESHAPE, "Behler kernels support npsf<=%d ntsf<=%d", NI_MAXP, NI_MAXT);
         const int cap_max = ni_max_cap(true, h->nsf);
         int cap_force;
+        // room for the pair lists the descriptor pass hands to the force pass: n_cap (n_cap - 1) / 2 entries of 2 bytes per
+        // atom (190 at capacity 20).  Not for very long records (the force pass then finds its pairs itself).
+        auto pair_room = [&](NiArgs &q) -> int {
+            q.pairs = nullptr; q.npair = nullptr; q.pstride = 0;
+            const long long ps = round_up(q.n_cap * (q.n_cap - 1) / 2, 8);
+            if (h->ni_no_pairs || ps > 2048 || (long long)inum * ps * 2 > (3ll << 30)) return 0;
+            int r;
+            if ((r = ensure(h, h->ni_pairs, (size_t)inum * ps)) || (r = ensure(h, h->ni_npair, (size_t)inum))) return r;
+            q.pairs = h->ni_pairs.p; q.npair = h->ni_npair.p; q.pstride = (int)ps;
+            return 0;
+        };
         if (!h->ni_primed) {
             // first evaluation (or the one after a capacity error): size the records synchronously, retry once
             for (int attempt = 0;; attempt++) {
                 a.n_cap = std::min(h->ni_cap, cap_max);
-                if ((rc = ensure(h, h->ni_nbr, (size_t)inum * a.n_cap))) return rc;
+                if ((rc = ensure(h, h->ni_nbr, (size_t)inum * a.n_cap)) || (rc = pair_room(a))) return rc;
                 a.nbr = h->ni_nbr.p; a.nbr_stride = a.n_cap;
                 ni_launch_desc(a, h->ni_shape, s);
                 HIP_TRY(h, hipGetLastError());
@@ -564,10 +593,10 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             }
             h->ni_cap = ni_next_cap(h->h_flags[1]);
             h->ni_primed = true;
-            cap_force = std::max(8, round_up(h->h_flags[1], 8));
+            cap_force = std::max(8, round_up(h->h_flags[1], 2));
         } else {
             a.n_cap = std::min(h->ni_cap, cap_max);
-            if ((rc = ensure(h, h->ni_nbr, (size_t)inum * a.n_cap))) return rc;
+            if ((rc = ensure(h, h->ni_nbr, (size_t)inum * a.n_cap)) || (rc = pair_room(a))) return rc;
             a.nbr = h->ni_nbr.p; a.nbr_stride = a.n_cap;
             ni_launch_desc(a, h->ni_shape, s);
             HIP_TRY(h, hipGetLastError());
@@ -664,15 +693,15 @@ void annp_hip_clear(annp_hip_handle *h)
     if (h->d_map) (void)hipFree(h->d_map);
     if (h->d_net) (void)hipFree(h->d_net);
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom); release(h, h->vatom);
-    release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr); release(h, h->ovf);
+    release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr); release(h, h->ni_npair); release(h, h->ni_pairs); release(h, h->ovf);
     release(h, h->first);
     neigh_release(h->nb);
     if (h->d_scalars) (void)hipFree(h->d_scalars);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     if (h->ev_flags) (void)hipEventDestroy(h->ev_flags);
-    if (h->reg_x.ok) (void)hipHostUnregister(const_cast<void *>(h->reg_x.ptr));
-    if (h->reg_f.ok) (void)hipHostUnregister(const_cast<void *>(h->reg_f.ptr));
+    if (h->reg_x.ok && hipHostUnregister(const_cast<void *>(h->reg_x.ptr)) != hipSuccess) (void)hipGetLastError();
+    if (h->reg_f.ok && hipHostUnregister(const_cast<void *>(h->reg_f.ptr)) != hipSuccess) (void)hipGetLastError();
     if (h->pin_x) (void)hipHostFree(h->pin_x);
     if (h->ev_f_up) (void)hipEventDestroy(h->ev_f_up);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -770,6 +799,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     h->nsf = p->nsf; h->npsf = p->npsf; h->ntsf = p->ntsf; h->nl = nl; h->ni_compat = p->ni_compat;
     h->e_scale = p->e_scale; h->e_shift = p->e_shift; h->e_atom = p->e_atom; h->cut = p->cut;
     if (const char *e = std::getenv("ANNP_HIP_FULL_LIST")) h->full_list = std::atoi(e) != 0;
+    if (const char *e = std::getenv("ANNP_HIP_NI_PAIRS")) h->ni_no_pairs = std::atoi(e) == 0;
     h->cutsq = cutsq_all;
     h->nelem = ne; h->multi = multi; h->active = active;
     if (multi) {
@@ -939,6 +969,12 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         }
         h->ni_shape.em = 1u;
         for (size_t e = 1; e < etas.size() && e < 4; e++) h->ni_shape.em |= (unsigned)emult[e] << (8 * e);
+        h->ni_rad_em = p->npsf > 0 ? 1ull : 0ull;
+        for (int m = 1; m < p->npsf && m < 8; m++) {
+            const double e0 = p->cofsymrad[0], em_ = p->cofsymrad[3 * m];
+            const double kr = e0 > 0.0 ? std::floor(em_ / e0 + 0.5) : 0.0;
+            if (kr >= 1.0 && kr <= 64.0 && std::fabs(kr * e0 - em_) <= 4e-16 * std::fabs(em_)) h->ni_rad_em |= (unsigned long long)kr << (8 * m);
+        }
         std::vector<double> t(h->sym_rad);
         t.insert(t.end(), h->sym_ang.begin(), h->sym_ang.end());
         for (int pos = 0; pos < nt; pos++) {
@@ -1249,7 +1285,9 @@ static bool host_register(annp_hip_handle *h, annp_hip_handle::HostReg &r, const
 {
     if (!h->use_register || !ptr || bytes == 0) return false;
     if (r.ptr == ptr && r.bytes >= bytes) return r.ok;
-    if (r.ok) { (void)hipHostUnregister(const_cast<void *>(r.ptr)); r.ok = false; }
+    // (the old array may be gone already -- LAMMPS reallocated it, which is why the address changed -- and the runtime then
+    // answers "not registered": nothing to undo, but the per-thread last-error word must not keep it)
+    if (r.ok) { if (hipHostUnregister(const_cast<void *>(r.ptr)) != hipSuccess) (void)hipGetLastError(); r.ok = false; }
     r.ptr = ptr; r.bytes = bytes;
     const hipError_t e = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault);
     if (e != hipSuccess) (void)hipGetLastError();

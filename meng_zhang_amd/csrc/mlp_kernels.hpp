@@ -31,6 +31,10 @@ namespace annp {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int MLP_MAXL = 4;   // weight layers supported by the MFMA path (ntl-1)
+// Waves of a workgroup share one copy of the operand image in LDS, and that copy (51 KB for the 27-24-24-1 network) is what
+// limits residency: with 4 waves per workgroup a CU held 12 waves of that network, with 8 it holds 16 -- and the pass is a
+// chain of dependent MFMAs and tanh evaluations per tile, i.e. it lives on the other waves of its SIMD.
+constexpr int MLP_WAVES_PER_BLOCK = 8;
 constexpr int MLP_CROW = ANNP_CPAD + 1;   // row pitch of the coefficient staging buffer: an even pitch of 48 puts the 16
                                           // atoms of a fragment column on two banks (8-way conflict on every write)
 
@@ -38,6 +42,7 @@ struct MlpArgs {
     int inum;
     const int *ilist;             // nullable
     int nsf, nnod, nl;            // nl = ntl-1 weight layers
+    int ncoef;                    // rows of coef the force pass reads (Behler: nsf; Chebyshev: 9 + 19 + 18)
     int act[MLP_MAXL];
     int act_plain;                // ni: activations 3,4 are plain tanh
     const double *img;            // device: the MFMA operand image, [MlpSlots::total][64] (mlp_build_image)
@@ -79,7 +84,15 @@ __device__ __forceinline__ double tanh_fast(double y)
     q = q * r;
     const int k = (int)kf;
     const double em1 = (k == 0) ? q : __builtin_ldexp(1.0 + q, k) - 1.0;
-    const double t = -em1 / (2.0 + em1);
+    // -em1 / (2 + em1) without the division sequence (v_div_scale / v_div_fmas / v_div_fixup and their special cases: ~30
+    // instructions, half of this function): the denominator lies in (1, 2], so the hardware reciprocal, two Newton steps and
+    // one correction of the quotient give the same result to within an ulp
+    const double d = 2.0 + em1;
+    double rc = __builtin_amdgcn_rcp(d);
+    rc = fma(rc, fma(-d, rc, 1.0), rc);
+    rc = fma(rc, fma(-d, rc, 1.0), rc);
+    double t = -em1 * rc;
+    t = fma(fma(-d, t, -em1), rc, t);
     return copysign(t, y);
 }
 
@@ -178,7 +191,7 @@ inline void mlp_build_image(double *img, const double *const *W, const double *c
 }
 
 template <int KS0, int MT, int NL>
-__global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
+__global__ __launch_bounds__(64 * MLP_WAVES_PER_BLOCK) void annp_mlp_mfma(MlpArgs p)
 {
     using S = MlpSlots<KS0, MT, NL>;
     constexpr int KSH = S::KSH, MT0 = S::MT0;
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
     {
         const double2 *src = reinterpret_cast<const double2 *>(p.img);
         double2 *dst = reinterpret_cast<double2 *>(opnd);
-        for (int idx = threadIdx.x; idx < S::total * 32; idx += 256) dst[idx] = src[idx];
+        for (int idx = threadIdx.x; idx < S::total * 32; idx += 64 * MLP_WAVES_PER_BLOCK) dst[idx] = src[idx];
     }
     __syncthreads();
     double *cbuf = cbuf_all + (size_t)wave * 16 * MLP_CROW;
@@ -203,30 +216,47 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
 #pragma unroll
     for (int l = 0; l < NL; l++) ap[l] = act_param(p.act[l], p.act_plain);
 
+    // The fragments are sized for the compiled maximum (MT tiles of 16 nodes); a network with fewer nodes leaves whole
+    // k-steps and whole accumulator registers empty.  Those are skipped (wave-uniform tests): the 24 nodes of the Ni
+    // network need 6 of 8 k-steps per hidden product, 2 of 3 coefficient tiles and no activation for rows 24..31;
+    // the 10 nodes of the Fe network 3 of 4 k-steps and 3 of 4 registers.
+    const int ksh = uniform((p.nnod + 3) >> 2);           // k-steps that meet a non-zero operand
+    const int mt0 = uniform((p.ncoef + 15) >> 4);         // coefficient tiles that are read downstream
+    const int nnod_u = uniform(p.nnod);
     double e_wave = 0.0;
     const int ntiles = (p.inum + 15) / 16;
-    const int wave_global = blockIdx.x * ANNP_WAVES_PER_BLOCK + wave;
-    const int wave_stride = gridDim.x * ANNP_WAVES_PER_BLOCK;
+    const int wave_global = blockIdx.x * MLP_WAVES_PER_BLOCK + wave;
+    const int wave_stride = gridDim.x * MLP_WAVES_PER_BLOCK;
+    // raw descriptor sums of a tile's 16 atoms, fragment order (k = 4s + lq, atom = lr); the next tile's are requested
+    // while this one is worked on: a tile is one long chain of dependent MFMAs, so nothing else would hide the read
+    double raw[KS0];
+    auto request = [&](int tile) {
+        const int ia = tile * 16 + lr;
+#pragma unroll
+        for (int s = 0; s < KS0; s++) {
+            const int k = 4 * s + lq;
+            raw[s] = (tile < ntiles && ia < p.inum && k < nsf) ? p.G[(size_t)ia * ANNP_GPAD + k] : 0.0;
+        }
+    };
+    request(wave_global);
     for (int tile = wave_global; tile < ntiles; tile += wave_stride) {
         const int ia = tile * 16 + lr;            // this lane's atom (column)
         bool aval = ia < p.inum;
-        if (p.type) {
-            if (aval) aval = p.map[p.type[p.ilist ? p.ilist[ia] : ia]] == p.elem;
-            if (__ballot(aval) == 0ull) continue;                            // no atom of this element in the tile
-        }
-        const unsigned rowmask = (unsigned)(__ballot(aval) & 0xffffull);     // lanes 0..15 speak for the 16 atoms
         // ---- input fragment: Ghat[k = 4s+lq][atom]
         double hin[KS0];
 #pragma unroll
         for (int s = 0; s < KS0; s++) {
             const int k = 4 * s + lq;
-            double g = 0.0;
-            if (aval && k < nsf) {
-                const double raw = p.G[(size_t)ia * ANNP_GPAD + k];
-                g = fma(raw, p.nmul[k], -p.nsub[k]) * p.nden[k];
-            }
-            hin[s] = g;
+            hin[s] = (aval && k < nsf) ? fma(raw[s], p.nmul[k], -p.nsub[k]) * p.nden[k] : 0.0;
         }
+        request(tile + wave_stride);
+        if (p.type) {
+            if (aval) aval = p.map[p.type[p.ilist ? p.ilist[ia] : ia]] == p.elem;
+            if (__ballot(aval) == 0ull) continue;                            // no atom of this element in the tile
+#pragma unroll
+            for (int s = 0; s < KS0; s++) hin[s] = aval ? hin[s] : 0.0;
+        }
+        const unsigned rowmask = (unsigned)(__ballot(aval) & 0xffffull);     // lanes 0..15 speak for the 16 atoms
         // ---- forward
         double4_t H[NL][MT], D[NL][MT];
 #pragma unroll
@@ -237,7 +267,11 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
 #pragma unroll
             for (int s = 0; s < KS0; s++) acc = mfma_f64(opnd[(size_t)(S::fwd0 + mt * KS0 + s) * 64 + lane], hin[s], acc);
 #pragma unroll
-            for (int r = 0; r < 4; r++) { double h, d; activation(ap[0], acc[r], h, d); H[0][mt][r] = h; D[0][mt][r] = d; }
+            for (int r = 0; r < 4; r++) {
+                double h = 0.0, d = 0.0;
+                if (16 * mt + 4 * r < nnod_u) activation(ap[0], acc[r], h, d);
+                H[0][mt][r] = h; D[0][mt][r] = d;
+            }
         }
 #pragma unroll
         for (int l = 1; l < NL - 1; l++) {
@@ -248,9 +282,13 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
                 for (int r = 0; r < 4; r++) acc[r] = opnd[(size_t)(S::bias + (l * MT + mt) * 4 + r) * 64 + lane];
 #pragma unroll
                 for (int s = 0; s < KSH; s++)
-                    acc = mfma_f64(opnd[(size_t)(S::fwdh + ((l - 1) * MT + mt) * KSH + s) * 64 + lane], H[l - 1][s / 4][s % 4], acc);
+                    if (s < ksh) acc = mfma_f64(opnd[(size_t)(S::fwdh + ((l - 1) * MT + mt) * KSH + s) * 64 + lane], H[l - 1][s / 4][s % 4], acc);
 #pragma unroll
-                for (int r = 0; r < 4; r++) { double h, d; activation(ap[l], acc[r], h, d); H[l][mt][r] = h; D[l][mt][r] = d; }
+                for (int r = 0; r < 4; r++) {
+                    double h = 0.0, d = 0.0;
+                    if (16 * mt + 4 * r < nnod_u) activation(ap[l], acc[r], h, d);
+                    H[l][mt][r] = h; D[l][mt][r] = d;
+                }
             }
         }
         double4_t zo;
@@ -258,7 +296,8 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
 #pragma unroll
             for (int r = 0; r < 4; r++) zo[r] = opnd[(size_t)(S::bias + (NL - 1) * MT * 4 + r) * 64 + lane];
 #pragma unroll
-            for (int s = 0; s < KSH; s++) zo = mfma_f64(opnd[(size_t)(S::fwdo + s) * 64 + lane], H[NL - 2][s / 4][s % 4], zo);
+            for (int s = 0; s < KSH; s++)
+                if (s < ksh) zo = mfma_f64(opnd[(size_t)(S::fwdo + s) * 64 + lane], H[NL - 2][s / 4][s % 4], zo);
         }
         double out, dout;
         activation(ap[NL - 1], zo[0], out, dout);   // row 0 lives in reg 0 of lanes 0..15
@@ -292,7 +331,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int s = 0; s < KSH; s++)
-                    acc = mfma_f64(opnd[(size_t)(S::bwdh + (((NL - 2) - l) * MT + mt) * KSH + s) * 64 + lane], dl[s / 4][s % 4], acc);
+                    if (s < ksh) acc = mfma_f64(opnd[(size_t)(S::bwdh + (((NL - 2) - l) * MT + mt) * KSH + s) * 64 + lane], dl[s / 4][s % 4], acc);
 #pragma unroll
                 for (int r = 0; r < 4; r++) nx[mt][r] = acc[r] * D[l - 1][mt][r];
             }
@@ -305,7 +344,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < KSH; s++)
-                acc = mfma_f64(opnd[(size_t)(S::bwd0 + mt * KSH + s) * 64 + lane], dl[s / 4][s % 4], acc);
+                if (mt < mt0 && s < ksh) acc = mfma_f64(opnd[(size_t)(S::bwd0 + mt * KSH + s) * 64 + lane], dl[s / 4][s % 4], acc);
 #pragma unroll
             for (int r = 0; r < 4; r++) cbuf[lr * MLP_CROW + 16 * mt + lq + 4 * r] = acc[r];
         }
@@ -327,7 +366,7 @@ __global__ __launch_bounds__(256) void annp_mlp_mfma(MlpArgs p)
 template <int KS0, int MT, int NL>
 inline size_t mlp_lds_bytes()
 {
-    return ((size_t)MlpSlots<KS0, MT, NL>::total * 64 + (size_t)ANNP_WAVES_PER_BLOCK * 16 * MLP_CROW) * sizeof(double);
+    return ((size_t)MlpSlots<KS0, MT, NL>::total * 64 + (size_t)MLP_WAVES_PER_BLOCK * 16 * MLP_CROW) * sizeof(double);
 }
 
 }  // namespace annp

@@ -62,6 +62,8 @@ struct NiArgs {
     const double *sym;          // see "per-function tables" below
     const int *isym;
     double rc_rad, rc_ang;      // Bohr
+    unsigned long long rad_em;  // byte m: eta_m / eta_0 of radial function m when that is a small integer (then
+                                // exp(-eta_m r^2) = exp(-eta_0 r^2)^k: one exp per neighbour instead of npsf), else 0
     double *G;
     const double *coef;         // [inum][ANNP_CPAD]: c_k = dE/dGhat_k / (sf_max-sf_min)_k
     double *f;
@@ -70,17 +72,22 @@ struct NiArgs {
     int *ncount;                // [inum] in-range neighbours found by the descriptor pass
     int *nbr;                   // [inum][nbr_stride] their indices, in list order (written by pass 1, read by pass 3)
     int nbr_stride;
+    // in-range (j,k) pairs of every atom, left by the descriptor pass for the force pass (nullable: the force pass then
+    // finds them again with its own pre-pass): entry = a | b << 8, record slots in list order, a < b
+    unsigned short *pairs;      // [inum][pstride]
+    int pstride;                // >= n_cap (n_cap - 1) / 2 of the descriptor pass
+    int *npair;                 // [inum]
     int *errflag;
 };
 
 // per-wave LDS: records of NI_GA atoms (7 doubles + index; the force pass adds 3 accumulators and the
 // atoms' coefficient rows), or the reduction scratch of the descriptor pass, whichever is larger
 __host__ __device__ inline int ni_coef_stride(int nsf) { return nsf | 1; }
-__host__ __device__ inline size_t ni_lds_per_wave(int cap, bool force, int nsf)
+__host__ __device__ inline size_t ni_lds_per_wave(int cap, bool force, int nsf, bool gpairs = false)
 {
     const size_t R = (size_t)NI_GA * cap + 2;          // + two dummy records for idle lanes
     size_t b = R * 7 * 8 + (force ? R * 3 * 8 + (size_t)NI_GA * ni_coef_stride(nsf) * 8 + (size_t)NI_TSLOTS * (3 * 8 + 4) : 0) + R * 4 + NI_GA * 4 +
-               (size_t)NI_GA * ni_plist(force) * 2;
+               ((force && gpairs) ? 0 : (size_t)NI_GA * ni_plist(force) * 2);     // (pair lists read from memory need no room here)
     const size_t scratch = (size_t)NI_GA * NI_RED * NI_REDROW * 8;
     if (!force && b < scratch) b = scratch;
     return (b + 15) / 16 * 16;
@@ -211,9 +218,9 @@ __device__ __forceinline__ void ni_visit_functions(const NiTab &t, int ntsf, dou
 //   K[KP + z]        2^(1-zeta_z)
 //   K[KD + 8 l + z]  2^(1-zeta_z) zeta_z lambda_l
 //   K[KE + e]        distinct eta values
-//   K[KM ..]         pi/Rc_ang, Rc_ang, CFLENGTH, 1/CFLENGTH
+//   K[KM ..]         pi/Rc_ang, Rc_ang, CFLENGTH, 1/CFLENGTH, (Rc_ang / CFLENGTH)^2 (1 + 1e-12)
 //   S[...]           copy of the sorted per-function table + etas (generic shape)
-constexpr int NI_KL = 0, NI_KP = 4, NI_KD = 12, NI_KE = 44, NI_KM = 48, NI_KTAB = 52;
+constexpr int NI_KL = 0, NI_KP = 4, NI_KD = 12, NI_KE = 44, NI_KM = 48, NI_KTAB = 56;
 constexpr int NI_TABLE_DOUBLES = ANNP_MTAB + NI_KTAB + 4 * NI_MAXT + NI_MAXE;
 
 struct NiConst {
@@ -243,6 +250,7 @@ __device__ __forceinline__ NiConst ni_tables_fill(double *lds, const NiArgs &p, 
         if (lane == NI_KM + 1) v = p.rc_ang;
         if (lane == NI_KM + 2) v = ANNP_CFLENGTH;
         if (lane == NI_KM + 3) v = 1.0 / ANNP_CFLENGTH;
+        if (lane == NI_KM + 4) v = (p.rc_ang / ANNP_CFLENGTH) * (p.rc_ang / ANNP_CFLENGTH) * (1.0 + 1e-12);
         K[lane] = v;
     }
     for (int idx = lane; idx < 4 * p.ntsf + NI_MAXE; idx += 64) S[idx] = t.sorted[idx];
@@ -416,6 +424,62 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
     // gathers, in flight together (only ~18 of ~224 candidates survive: this sweep is memory latency).
     int nmax = 0;
     nl = 0;
+    // Short rows (the library's own list: ~75 entries): the index loads of all four rows go out together, then all the
+    // coordinate gathers -- two dependent memory round trips for the wave instead of two per row.
+    const int jn_all = max(max(__builtin_amdgcn_readlane(hjn, 0), __builtin_amdgcn_readlane(hjn, 1)),
+                           max(__builtin_amdgcn_readlane(hjn, 2), __builtin_amdgcn_readlane(hjn, 3)));
+    if (jn_all <= 128) {
+        int j[NI_GA][2];
+        bool valid[NI_GA][2];
+#pragma unroll
+        for (int ga = 0; ga < NI_GA; ga++) {
+            const int jn = __builtin_amdgcn_readlane(hjn, ga);
+            const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)(hbase & 0xffffffffll), ga);
+            const int bhi = __builtin_amdgcn_readlane((int)(hbase >> 32), ga);
+            const int *row = p.neigh + (((long long)bhi << 32) | (long long)blo);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int jj = 64 * u + lane;
+                valid[ga][u] = jj < jn;
+                j[ga][u] = valid[ga][u] ? (row[jj] & ANNP_NEIGHMASK) : 0;
+            }
+        }
+        if (p.type) {
+#pragma unroll
+            for (int ga = 0; ga < NI_GA; ga++)
+#pragma unroll
+                for (int u = 0; u < 2; u++) valid[ga][u] = valid[ga][u] && ((p.active >> p.type[j[ga][u]]) & 1u);
+        }
+        double qx[NI_GA][2], qy[NI_GA][2], qz[NI_GA][2];
+#pragma unroll
+        for (int ga = 0; ga < NI_GA; ga++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                qx[ga][u] = p.x[3 * (size_t)j[ga][u]]; qy[ga][u] = p.x[3 * (size_t)j[ga][u] + 1]; qz[ga][u] = p.x[3 * (size_t)j[ga][u] + 2];
+            }
+#pragma unroll
+        for (int ga = 0; ga < NI_GA; ga++) {
+            const double xi = readlane_f64(hx, ga), yi = readlane_f64(hy, ga), zi = readlane_f64(hz, ga);
+            const int sb = ga * cap;
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const double dx = xi - qx[ga][u], dy = yi - qy[ga][u], dz = zi - qz[ga][u];
+                const double rsq = dx * dx + dy * dy + dz * dz;
+                const bool in = valid[ga][u] && rsq < rc2 && rsq > 0.0;
+                const unsigned long long m = __ballot(in);
+                const int pos = n + __popcll(m & lt);
+                if (in && pos < cap) {
+                    const int s = sb + pos;
+                    L.dx[s] = dx; L.dy[s] = dy; L.dz[s] = dz; L.r[s] = rsq; L.j[s] = j[ga][u];
+                }
+                n += __popcll(m);
+            }
+            n = uniform(n);
+            if (g == ga) nl = n;
+            nmax = max(nmax, n);
+        }
+    } else
     for (int ga = 0; ga < NI_GA; ga++) {
         const int jn = __builtin_amdgcn_readlane(hjn, ga);
         const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)(hbase & 0xffffffffll), ga);
@@ -425,13 +489,19 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
         const int sb = ga * cap;
         int n = 0;
         for (int c0 = 0; c0 < jn; c0 += 256) {
+            // groups of 64 candidates this trip really has (wave-uniform: jn sits in a scalar register).  A row of the
+            // library's own list (~75 entries, annp_hip_list_cutoff) fills two; the other two are branched over.
+            const int ngr = min(4, (jn - c0 + 63) >> 6);
             int j[4];
             bool valid[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int jj = c0 + 64 * u + lane;
-                valid[u] = jj < jn;
-                j[u] = valid[u] ? (row[jj] & ANNP_NEIGHMASK) : 0;
+                valid[u] = false; j[u] = 0;
+                if (u < ngr) {
+                    const int jj = c0 + 64 * u + lane;
+                    valid[u] = jj < jn;
+                    j[u] = valid[u] ? (row[jj] & ANNP_NEIGHMASK) : 0;
+                }
             }
             if (p.type) {
 #pragma unroll
@@ -440,10 +510,12 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
             double dx[4], dy[4], dz[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                dx[u] = xi - p.x[3 * (size_t)j[u]]; dy[u] = yi - p.x[3 * (size_t)j[u] + 1]; dz[u] = zi - p.x[3 * (size_t)j[u] + 2];
+                dx[u] = dy[u] = dz[u] = 0.0;
+                if (u < ngr) { dx[u] = xi - p.x[3 * (size_t)j[u]]; dy[u] = yi - p.x[3 * (size_t)j[u] + 1]; dz[u] = zi - p.x[3 * (size_t)j[u] + 2]; }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
+                if (u >= ngr) continue;
                 const double rsq = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
                 const bool in = valid[u] && rsq < rc2 && rsq > 0.0;
                 const unsigned long long m = __ballot(in);
@@ -490,22 +562,24 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
 }
 
 // Force pass: rebuild the records from the compact lists the descriptor pass left (same entries, same order).
-__device__ __forceinline__ int ni_stage_compact(const NiArgs &p, int ii0, const NiLds &L, const double *T, int lane, int &nl)
+__device__ __forceinline__ int ni_stage_compact(const NiArgs &p, int ii0, const NiLds &L, const double *T, int lane, int &nl, int &npairs)
 {
     const int cap = p.n_cap;
-    int hi = -1, hn = 0;
+    int hi = -1, hn = 0, hp = 0;
     double hx = 0.0, hy = 0.0, hz = 0.0;
     if (lane < NI_GA) {
         const int ii = ii0 + lane;
         if (ii < p.inum) {
             hi = p.ilist ? p.ilist[ii] : ii;
             hn = p.ncount[ii];
+            if (p.npair) hp = p.npair[ii];
             hx = p.x[3 * (size_t)hi]; hy = p.x[3 * (size_t)hi + 1]; hz = p.x[3 * (size_t)hi + 2];
         }
         L.ci[lane] = hi;
     }
     const int g = lane >> 4, l = lane & 15;
     nl = __shfl(hn, g, 64);
+    npairs = __shfl(hp, g, 64);
     const double xi = __shfl(hx, g, 64), yi = __shfl(hy, g, 64), zi = __shfl(hz, g, 64);
     int nmax = 0;
 #pragma unroll
@@ -588,12 +662,14 @@ __device__ __forceinline__ void ni_forget_lds() { asm volatile("" ::: "memory");
 // an fcc-Ni atom -- but which ones is scattered over the enumeration, so every trip of the full visit would carry
 // ~60 % idle lanes.  A cheap sweep over a chunk of trips (distances only) writes the in-range pairs of each atom as
 // a dense list; the expensive part (cutoff function of r_jk, exponential, 24 functions) then runs over ceil(60/16)
-// = 4 trips instead of 10.  The test is computed exactly as ni_pair computes it, so the list and the visit agree.
+// = 4 trips instead of 10.  The visit applies the exact test again (ni_pair's `ok`).
 // Returns this lane's atom's count for the chunk (same value in the 16 lanes of a group).
 __device__ __forceinline__ int ni_prepass(const NiLds &L, const NiConst &c, NiWalk &walk, int g, int l, int sbase, int cap,
                                           int npl, int t0, int t1, const int plist)
 {
-    const double cfl = c.K[NI_KM + 2], rc = c.K[NI_KM + 1];
+    // r_jk by its square against a bound a hair above the cutoff: the pre-pass may let a pair through that the visit's own
+    // test (ni_pair: the reference's r * CFLENGTH < Rc) then rejects, never the other way round
+    const double cfl = c.K[NI_KM + 2], rc = c.K[NI_KM + 1], rc2a = c.K[NI_KM + 4];
     int cnt = 0;
     for (int t = t0; t < t1; t++) {
         const int pp = t * NI_GL + l;
@@ -603,8 +679,7 @@ __device__ __forceinline__ int ni_prepass(const NiLds &L, const NiConst &c, NiWa
         const int sa = live ? sbase + a : NI_GA * cap, sb = live ? sbase + b : NI_GA * cap + 1;
         const double g0 = L.dx[sb] - L.dx[sa], g1 = L.dy[sb] - L.dy[sa], g2 = L.dz[sb] - L.dz[sa];
         const double gsq = g0 * g0 + g1 * g1 + g2 * g2;
-        const double rgm = (gsq * fast_rsqrt_ic(gsq)) * cfl;
-        const bool ok = live && (L.r[sa] * cfl < rc) && (L.r[sb] * cfl < rc) && (rgm < rc);
+        const bool ok = live && (L.r[sa] * cfl < rc) && (L.r[sb] * cfl < rc) && (gsq < rc2a);
         const unsigned long long m = __ballot(ok);
         const unsigned m16 = (unsigned)(m >> (NI_GL * g)) & 0xffffu;
         if (ok) L.pl[g * plist + cnt + __popc(m16 & ((1u << l) - 1u))] = (unsigned short)(a | (b << 8));
@@ -639,6 +714,7 @@ __global__ __launch_bounds__(256, NL > 0 ? NI_WAVES_PER_SIMD : 3) void annp_ni_d
     // a group whose records overflowed is skipped by both passes: its count is left at 0 so that the force pass, which
     // runs without the host having looked at the error word, finds nothing to do for it (its list rows are not written)
     if (p.ncount && lane < NI_GA && ii0 + lane < p.inum) p.ncount[ii0 + lane] = nmax > cap ? 0 : ncl;
+    if (p.npair && nmax > cap && lane < NI_GA && ii0 + lane < p.inum) p.npair[ii0 + lane] = 0;
     if (nmax > cap) {
         if (lane == 0) atomicMax(p.errflag, nmax);
         for (int idx = lane; idx < NI_GA * ANNP_GPAD; idx += 64)
@@ -662,9 +738,14 @@ __global__ __launch_bounds__(256, NL > 0 ? NI_WAVES_PER_SIMD : 3) void annp_ni_d
             double sn, cs;
             sincos_0_pi_tab(ANNP_MY_PI / p.rc_rad * rm, T, sn, cs);
             const double fc = 0.5 * (cs + 1.0);
+            const double e0 = exp_neg_tab(-srad[0] * rm * rm, T);
 #pragma unroll
             for (int m = 0; m < NP; m++)
-                if (m < p.npsf) gr[m] += exp_neg_tab(-srad[3 * m] * rm * rm, T) * fc;
+                if (m < p.npsf) {
+                    // (the compiled-in shape has its radial etas in the ratios EM too: ni_is_shipped_shape)
+                    const int km = NL > 0 ? NI_BYTE(EM, m & 3) : (int)((p.rad_em >> (8 * m)) & 255ull);
+                    gr[m] += (km > 0 ? ni_powi(e0, km) : exp_neg_tab(-srad[3 * m] * rm * rm, T)) * fc;
+                }
         }
     }
     // G4 (ni:713-767): the atom's pairs over its 16 lanes
@@ -672,6 +753,7 @@ __global__ __launch_bounds__(256, NL > 0 ? NI_WAVES_PER_SIMD : 3) void annp_ni_d
     const int trips = (nmax * (nmax - 1) / 2 + NI_GL - 1) / NI_GL;
     NiWalk walk = ni_walk_init(l, nl);
     constexpr int CH = ni_ch(false), PLIST = ni_plist(false);
+    int poff = 0;               // pairs of this lane's atom written to p.pairs so far
     for (int t0 = 0; t0 < trips; t0 += CH) {
         const int cnt = ni_prepass(L, kc, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST);
         wave_lds_sync();
@@ -690,8 +772,16 @@ __global__ __launch_bounds__(256, NL > 0 ? NI_WAVES_PER_SIMD : 3) void annp_ni_d
                 ni_visit_functions<NT, false>(tab, p.ntsf, q.ct, r2sum,
                                               [&](int pos, double val, double) { ga[pos] = fma(val, tfc, ga[pos]); });
         }
+        if (p.pairs) {          // the chunk's list, for the force pass (an atom has at most n (n - 1) / 2 <= pstride entries in all)
+            int gq = g;         // (opaque: the row's address is formed here, once per chunk, not kept in registers across the visit)
+            asm volatile("" : "+v"(gq));
+            unsigned short *gp = p.pairs + (size_t)(ii0 + gq) * p.pstride + poff;
+            for (int idx = l; idx < cnt; idx += NI_GL) gp[idx] = L.pl[gq * PLIST + idx];
+            poff += cnt;
+        }
         wave_lds_sync();        // the list is rewritten by the next chunk
     }
+    if (p.npair && l == 0 && ii0 + g < p.inum) p.npair[ii0 + g] = poff;
     wave_lds_sync();
     // sum the 16 lane partials of every atom through LDS, NI_RED sums per round (records are dead now)
     constexpr int NS = NP + NT;
@@ -725,7 +815,10 @@ __global__ __launch_bounds__(256, NL > 0 ? NI_WAVES_PER_SIMD : 3) void annp_ni_d
 }
 
 // ---------------------------------------------------------------------------------
-template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM, bool VIRIAL>
+// GPAIRS: the in-range pairs of an atom are read from the list the descriptor pass left in memory (p.pairs) instead of
+// being found again by a pre-pass over all n (n - 1) / 2 candidates: 88 of the pass's 730 vector instructions per atom,
+// a sixth of its LDS traffic and the 1 KB of LDS per wave that held the chunk's list.
+template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM, bool VIRIAL, bool GPAIRS>
 __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(NiArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -740,7 +833,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     const double *srad = tab.rad;
     const NiConst kc = ni_tables_fill<NL, NE, NZ>(reinterpret_cast<double *>(lds_raw), p, tab, lane);
     const double *T = kc.T;
-    unsigned char *wbase = lds_raw + NI_TABLE_DOUBLES * 8 + (size_t)wave * ni_lds_per_wave(cap, true, nsf);
+    unsigned char *wbase = lds_raw + NI_TABLE_DOUBLES * 8 + (size_t)wave * ni_lds_per_wave(cap, true, nsf, GPAIRS);
     const NiLds L = ni_carve<true>(wbase, cap, cstride);
     for (int sl = lane; sl < NI_TSLOTS; sl += 64) { L.tkey[sl] = -1; L.tacc[3 * sl] = 0.0; L.tacc[3 * sl + 1] = 0.0; L.tacc[3 * sl + 2] = 0.0; }
     // add a force to atom j's entry of the run's table; after NI_TPROBE occupied slots it goes straight to global memory
@@ -775,8 +868,8 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
         if (ii0 + gq < p.inum) v = p.coef[(size_t)(ii0 + gq) * ANNP_CPAD + (k < p.npsf ? k : p.npsf + tab.perm[k - p.npsf])];
         L.coef[gq * cstride + k] = v;
     }
-    int nl;
-    const int nmax = ni_stage_compact(p, ii0, L, T, lane_q, nl);
+    int nl, npg;
+    const int nmax = ni_stage_compact(p, ii0, L, T, lane_q, nl, npg);
     if (nmax > cap) { if (lane_q == 0) atomicMax(p.errflag, nmax); wave_lds_sync(); continue; }
     wave_lds_sync();
     const double *cr = L.coef + g * cstride;        // radial weights of this lane's atom
@@ -787,15 +880,20 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     const int trips = (nmax * (nmax - 1) / 2 + NI_GL - 1) / NI_GL;
     NiWalk walk = ni_walk_init(l, nl);
     constexpr int CH = ni_ch(true), PLIST = ni_plist(true);
-    for (int t0 = 0; t0 < trips; t0 += CH) {
-    const int cnt = ni_prepass(L, kc, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST);
-    wave_lds_sync();
+    const unsigned short *gpl = GPAIRS ? p.pairs + (size_t)(ii0 + g) * p.pstride : nullptr;
+    int pv_next = (GPAIRS && l < npg) ? gpl[l] : 0;         // the entry of the coming trip is in flight while this one is visited
+    for (int t0 = 0; t0 < (GPAIRS ? 1 : trips); t0 += CH) {
+    int cnt;
+    if (GPAIRS) cnt = npg;          // one "chunk": the whole list
+    else { cnt = ni_prepass(L, kc, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST); wave_lds_sync(); }
     const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
                          max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
     for (int t2 = 0; t2 * NI_GL < cmax; t2++) {
         const int idx = t2 * NI_GL + l;
         const bool lv = idx < cnt;
-        const int pv = lv ? L.pl[g * PLIST + idx] : 0;
+        int pv;
+        if (GPAIRS) { pv = pv_next; pv_next = (idx + NI_GL < cnt) ? gpl[idx + NI_GL] : 0; }
+        else pv = lv ? L.pl[g * PLIST + idx] : 0;
         const int sa = lv ? sbase + (pv & 255) : NI_GA * cap, sb = lv ? sbase + (pv >> 8) : NI_GA * cap + 1;
         const NiPairS q = ni_pair(L, kc, sa, sb);
         const double r2sum = q.rjm * q.rjm + q.rkm * q.rkm + q.rgm * q.rgm;
@@ -837,7 +935,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
             atomicAdd(&L.a0[sb], fk[0]); atomicAdd(&L.a1[sb], fk[1]); atomicAdd(&L.a2[sb], fk[2]);
         }
     }
-    wave_lds_sync();            // the list is rewritten by the next chunk
+    if (!GPAIRS) wave_lds_sync();            // the list is rewritten by the next chunk
     }
     double fi0 = 0.0, fi1 = 0.0, fi2 = 0.0;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
@@ -853,11 +951,14 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
                 sincos_0_pi_tab(por * rm, T, sn, cs);
                 const double fc = 0.5 * (cs + 1.0), dfc = -0.5 * por * sn;
                 double R = 0.0;
+                const double e0 = exp_neg_tab(-srad[0] * rm * rm, T);
 #pragma unroll
                 for (int m = 0; m < NP; m++)
                     if (m < p.npsf) {
                         const double eta = srad[3 * m];
-                        R = fma(cr[m], exp_neg_tab(-eta * rm * rm, T) * (-fc * 2.0 * eta * rm + dfc), R);
+                        const int km = NL > 0 ? NI_BYTE(EM, m & 3) : (int)((p.rad_em >> (8 * m)) & 255ull);
+                        const double em = km > 0 ? ni_powi(e0, km) : exp_neg_tab(-eta * rm * rm, T);
+                        R = fma(cr[m], em * (-fc * 2.0 * eta * rm + dfc), R);
                     }
                 const double sc = -R * L.rinv[s];                     // dr_dj = -xij/rij
                 g0 = fma(sc, d0, g0); g1 = fma(sc, d1, g1); g2 = fma(sc, d2, g2);
@@ -928,11 +1029,16 @@ struct NiShape { int nl, ne, nz; unsigned zp, em; };
 #define NI_GENERIC NI_MAXP, NI_MAXT, 0, 0, 0, 0u, 0u
 inline bool ni_is_shipped_shape(const NiArgs &a, NiShape sh)
 {
-    return a.npsf <= 3 && a.ntsf == 24 && sh.nl == 2 && sh.ne == 3 && sh.nz == 4 &&
+    unsigned long long want = 0;        // radial etas in the same ratios 1 : 2 : 5 (as many as there are)
+    for (int m = 0; m < a.npsf && m < 3; m++) want |= (unsigned long long)((m == 0) ? 1 : (m == 1) ? 2 : 5) << (8 * m);
+    return a.npsf <= 3 && a.rad_em == want && a.ntsf == 24 && sh.nl == 2 && sh.ne == 3 && sh.nz == 4 &&
            sh.zp == (1u | 2u << 8 | 4u << 16 | 16u << 24) && sh.em == (1u | 2u << 8 | 5u << 16);
 }
 
-inline size_t ni_lds_block(int cap, bool force, int nsf) { return NI_TABLE_DOUBLES * 8 + ni_lds_per_wave(cap, force, nsf) * ANNP_WAVES_PER_BLOCK; }
+inline size_t ni_lds_block(int cap, bool force, int nsf, bool gpairs = false)
+{
+    return NI_TABLE_DOUBLES * 8 + ni_lds_per_wave(cap, force, nsf, gpairs) * ANNP_WAVES_PER_BLOCK;
+}
 
 // largest record capacity whose 4-wave block still fits the 160 KB of a CU
 inline int ni_max_cap(bool force, int nsf)
@@ -956,33 +1062,39 @@ inline int ni_launch_desc(const NiArgs &a, NiShape sh, hipStream_t s)
     return 0;
 }
 
-inline void ni_launch_force(const NiArgs &a, NiShape sh, bool virial, hipStream_t s)
+template <bool VIR, bool GP>
+inline void ni_launch_force_t(const NiArgs &a, NiShape sh, hipStream_t s)
 {
-    const size_t lds = ni_lds_block(a.n_cap, true, a.npsf + a.ntsf);
+    const size_t lds = ni_lds_block(a.n_cap, true, a.npsf + a.ntsf, GP);
     const int per_block = ANNP_WAVES_PER_BLOCK * NI_GA * NI_RUN;
     const int blocks = (a.inum + per_block - 1) / per_block;
-    if (ni_is_shipped_shape(a, sh)) {
-        if (virial) hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, true>), dim3(blocks), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, false>), dim3(blocks), dim3(256), lds, s, a);
-    } else {
-        if (virial) hipLaunchKernelGGL((annp_ni_force<NI_GENERIC, true>), dim3(blocks), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((annp_ni_force<NI_GENERIC, false>), dim3(blocks), dim3(256), lds, s, a);
-    }
+    if (ni_is_shipped_shape(a, sh)) hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, VIR, GP>), dim3(blocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((annp_ni_force<NI_GENERIC, VIR, GP>), dim3(blocks), dim3(256), lds, s, a);
 }
 
+// a.pairs != nullptr: the descriptor pass of this evaluation left the pair lists
+inline void ni_launch_force(const NiArgs &a, NiShape sh, bool virial, hipStream_t s)
+{
+    if (a.pairs) { if (virial) ni_launch_force_t<true, true>(a, sh, s); else ni_launch_force_t<false, true>(a, sh, s); }
+    else { if (virial) ni_launch_force_t<true, false>(a, sh, s); else ni_launch_force_t<false, false>(a, sh, s); }
+}
 
 // the kernels may ask for more than the default 64 KB of dynamic LDS
 inline hipError_t ni_set_lds_attributes()
 {
     const int full = 160 * 1024;
     hipError_t e;
-#define NI_ATTR(k) if ((e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, full)) != hipSuccess) return e
-    NI_ATTR((annp_ni_desc<NI_SHIPPED>));
-    NI_ATTR((annp_ni_desc<NI_GENERIC>));
-    NI_ATTR((annp_ni_force<NI_SHIPPED, true>));
-    NI_ATTR((annp_ni_force<NI_SHIPPED, false>));
-    NI_ATTR((annp_ni_force<NI_GENERIC, true>));
-    NI_ATTR((annp_ni_force<NI_GENERIC, false>));
+#define NI_ATTR(...) if ((e = hipFuncSetAttribute((const void *)__VA_ARGS__, hipFuncAttributeMaxDynamicSharedMemorySize, full)) != hipSuccess) return e
+    NI_ATTR(annp_ni_desc<NI_SHIPPED>);
+    NI_ATTR(annp_ni_desc<NI_GENERIC>);
+    NI_ATTR(annp_ni_force<NI_SHIPPED, true, true>);
+    NI_ATTR(annp_ni_force<NI_SHIPPED, false, true>);
+    NI_ATTR(annp_ni_force<NI_GENERIC, true, true>);
+    NI_ATTR(annp_ni_force<NI_GENERIC, false, true>);
+    NI_ATTR(annp_ni_force<NI_SHIPPED, true, false>);
+    NI_ATTR(annp_ni_force<NI_SHIPPED, false, false>);
+    NI_ATTR(annp_ni_force<NI_GENERIC, true, false>);
+    NI_ATTR(annp_ni_force<NI_GENERIC, false, false>);
 #undef NI_ATTR
     return hipSuccess;
 }

@@ -89,7 +89,7 @@ class SlabDomain:
     the slab neighbours, then the local periodic images.  ``ids`` (global atom id) and every tensor in ``extra``
     (e.g. velocities) belong to the owned atoms and migrate with them."""
 
-    def __init__(self, box, periodic, rc_halo, device, transport=None, x_own=None, ids=None, extra=None, hip=None):
+    def __init__(self, box, periodic, rc_halo, device, transport=None, x_own=None, ids=None, extra=None, hip=None, wire_self=False):
         import torch
         self.torch = torch
         self.tp = transport if transport is not None else NoTransport()
@@ -99,14 +99,18 @@ class SlabDomain:
         self.rc = float(rc_halo)
         self.device = device
         L = self.box[3:] - self.box[:3]
-        if self.world > 1 and L[0] / self.world < self.rc:
+        if (self.world > 1 or wire_self) and L[0] / self.world < self.rc:
             raise ValueError("slab thinner than the halo: %g < %g" % (L[0] / self.world, self.rc))
         self.lo, self.hi = slab_bounds(self.box, self.world, self.rank)
         w = self.world
         self.left = (self.rank - 1) % w if (self.rank > 0 or self.periodic[0]) else None
         self.right = (self.rank + 1) % w if (self.rank < w - 1 or self.periodic[0]) else None
         if w == 1:
-            self.left = self.right = None
+            # one rank: every periodic image is a local copy -- unless wire_self asks for the x images to travel through
+            # the transport to this same rank (the wire path of a slab whose two neighbours are itself: lets a single GPU
+            # run ncclSend / ncclRecv on device buffers)
+            self.left = self.right = (0 if (wire_self and self.periodic[0]) else None)
+        self.wired = self.left is not None or self.right is not None
         x_own = torch.as_tensor(x_own, dtype=torch.float64, device=device).reshape(-1, 3).contiguous()
         self.nlocal = int(x_own.shape[0])
         self.x = x_own.clone()
@@ -122,7 +126,7 @@ class SlabDomain:
         self.replan()
 
     @classmethod
-    def from_global(cls, x_global, box, periodic, rc_halo, device, transport=None, extra=None, hip=None):
+    def from_global(cls, x_global, box, periodic, rc_halo, device, transport=None, extra=None, hip=None, wire_self=False):
         """Every rank holds the same global configuration (synthetic inputs) and keeps the atoms of its slab."""
         tp = transport if transport is not None else NoTransport()
         box = np.asarray(box, dtype=np.float64)
@@ -134,7 +138,7 @@ class SlabDomain:
         owner = np.clip(np.floor((xw[:, 0] - box[0]) / L[0] * tp.world).astype(np.int64), 0, tp.world - 1)
         mine = np.nonzero(owner == tp.rank)[0]
         ex = {k: np.asarray(v)[mine] for k, v in (extra or {}).items()}
-        return cls(box, periodic, rc_halo, device, tp, x_global[mine], mine, ex, hip)
+        return cls(box, periodic, rc_halo, device, tp, x_global[mine], mine, ex, hip, wire_self)
 
     # ------------------------------------------------------------------ wire helpers
     def _route(self, send, n_l, n_r, recv, m_r, m_l):
@@ -237,7 +241,7 @@ class SlabDomain:
         xo = self.x[:n]
         L = self.box[3:] - self.box[:3]
         # (1) across the slab faces
-        if self.world > 1:
+        if self.wired:
             sel_l = t.nonzero(xo[:, 0] < self.lo + self.rc).flatten() if self.left is not None else t.zeros(0, dtype=t.int64, device=dev)
             sel_r = t.nonzero(xo[:, 0] >= self.hi - self.rc).flatten() if self.right is not None else t.zeros(0, dtype=t.int64, device=dev)
             n_l, n_r = int(sel_l.numel()), int(sel_r.numel())
@@ -258,7 +262,7 @@ class SlabDomain:
         prim = t.empty((n + nxg, 3), dtype=t.float64, device=dev)
         prim[:n] = xo
         self.sendbuf = t.empty((n_l + n_r, 3), dtype=t.float64, device=dev)
-        if self.world > 1:
+        if self.wired:
             t.index_select(xo, 0, self.send_idx, out=self.sendbuf)
             self.sendbuf += self.send_shift
             self.tp.route(self._route(self.sendbuf, n_l, n_r, prim[n:], m_r, m_l))
@@ -266,7 +270,7 @@ class SlabDomain:
         root = t.arange(n + nxg, dtype=t.int64, device=dev)
         shift = t.zeros((n + nxg, 3), dtype=t.float64, device=dev)
         pos = prim
-        dims = (0, 1, 2) if self.world == 1 else (1, 2)
+        dims = (1, 2) if self.wired else (0, 1, 2)
         for d in dims:
             if not self.periodic[d]:
                 continue

@@ -364,3 +364,46 @@ def test_fold_segments_restate_index_add():
     t = torch.from_numpy(f.copy())
     t[:n].index_add_(0, dom.img_root, t[n:])
     assert np.allclose(t.numpy(), ref, rtol=0, atol=1e-14)
+
+
+def test_one_rank_with_its_x_images_on_the_wire():
+    """wire_self: a single slab whose two neighbours are itself sends its boundary atoms through the transport (to itself)
+    instead of copying them locally -- the wire path of forward / reverse / replan on one rank (bench.py uses it to run
+    RCCL send/recv on a single GPU).  Same ghosts, same forces as the local-copy domain and as the oracle."""
+    import torch
+    from meng_zhang_amd.domain import SlabDomain
+    x0, box = bcc(7, 4, 4, A_FE)                   # 20 A along x >= 8.5 A halo, < 2 x 8.5: some atoms go out on both faces
+    xg = perturb(x0, 41, 0.05)
+    pot = read_pot(FE_POT)
+    dev = torch.device("cpu")
+
+    def program(rank, tp):
+        out = []
+        for wire in (False, True):
+            dom = SlabDomain.from_global(xg, box, (1, 1, 1), RC_LIST, dev, tp if wire else None, wire_self=wire)
+            assert dom.wired == wire and (dom.nxg > 0) == wire
+            for phase in range(2):
+                if phase == 1:
+                    drift = (2.0 * uniform_counter(xg.size, 5).reshape(xg.shape) - 1.0) * 0.8
+                    dom.x[: dom.nlocal] += torch.from_numpy(drift[dom.ids.numpy()])
+                    dom.replan()
+                else:
+                    dom.forward()
+                s = local_system(dom.x.numpy(), dom.nlocal)
+                o = oracle_compute(pot, s, KIND_FE, FAST)
+                dom.f += torch.from_numpy(o["f_all"])
+                dom.reverse()
+                out.append((dom.nall, dom.ids.numpy().copy(), dom.f[: dom.nlocal].numpy().copy(), dom.x[: dom.nlocal].numpy().copy()))
+        return out
+
+    res = ThreadFabric(1).run(program)[0]
+    for k in range(2):
+        (na, ia, fa, xa), (nb, ib, fb, xb) = res[k], res[2 + k]
+        assert na == nb and np.array_equal(ia, ib) and np.array_equal(xa, xb)
+        assert np.abs(fa - fb).max() < 1e-12
+        full = np.empty_like(xg)
+        full[ia] = xa
+        o = oracle_compute(pot, System(full, box), KIND_FE, FAST)
+        f = np.empty_like(xg)
+        f[ia] = fa
+        assert np.abs(f - o["f"]).max() < 1e-9
