@@ -52,14 +52,15 @@ SURVEY_FLOP_PAIR, SURVEY_FLOP_NBR, SURVEY_FLOP_MLP = 350.0, 175.0, 1600.0
 BYTES_ATOM_STEP = 9960.0                          # gathered bytes per atom-step
 PEAK_FP64_VECTOR = 78.6                           # TFLOP/s, MI355X (MI355X_MICROARCH.md: half of FP32 vector 157.3)
 PEAK_HBM = 8000.0                                 # GB/s spec
-# Ni (Behler G2/G4), counted from the kernels: per candidate (j,k) pair the distance pre-pass of both passes
-# (2 x 20); per pair that survives r_ij, r_ik, r_jk < Rc (39 % of them in fcc Ni, the figure used here) geometry + cutoff
-# function of r_jk 75, one exp and its powers 44, squaring ladders 10, the 8 (lambda, zeta) steps 64 (descriptor) / 136 (force),
-# force assembly 57: 195 + 320; per in-range neighbour sincos + 3 exp in each pass 380; network 27-24-24-1 forward + reverse 5 k.
-# (SURVEY.md 8d's 24 x 40 + 150 per candidate pair priced a pow() per function and every candidate pair.)
+# Ni (Behler G2/G4), counted from the kernels: per candidate (j,k) pair the distance pre-pass of the descriptor
+# pass (squared distance and three compares: 12; the force pass reads the surviving pairs from the list that pass leaves);
+# per pair that survives r_ij, r_ik, r_jk < Rc (39 % of them in fcc Ni, the figure used here) geometry + cutoff function of
+# r_jk 75, one exp and its powers 44, squaring ladders 10, the 8 (lambda, zeta) steps 64 (descriptor) / 136 (force), force
+# assembly 57: 195 + 320; per in-range neighbour sincos + one exp and its powers in each pass 300; network 27-24-24-1 forward +
+# reverse 5 k.  (SURVEY.md 8d's 24 x 40 + 150 per candidate pair priced a pow() per function and every candidate pair.)
 NI_IN_RANGE_PAIR_FRACTION = 0.39
-NI_FLOP_PAIR = 40.0 + NI_IN_RANGE_PAIR_FRACTION * (195.0 + 320.0)
-NI_FLOP_NBR, NI_FLOP_MLP = 380.0, 5000.0
+NI_FLOP_PAIR = 12.0 + NI_IN_RANGE_PAIR_FRACTION * (195.0 + 320.0)
+NI_FLOP_NBR, NI_FLOP_MLP = 300.0, 5000.0
 
 
 def parse_args():

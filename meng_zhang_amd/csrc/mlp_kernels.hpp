@@ -37,6 +37,7 @@ constexpr int MLP_MAXL = 4;   // weight layers supported by the MFMA path (ntl-1
 constexpr int MLP_WAVES_PER_BLOCK = 8;
 constexpr int MLP_CROW = ANNP_CPAD + 1;   // row pitch of the coefficient staging buffer: an even pitch of 48 puts the 16
                                           // atoms of a fragment column on two banks (8-way conflict on every write)
+__host__ __device__ constexpr bool MLP_STAGED(int mt) { return mt == 1; }
 
 struct MlpArgs {
     int inum;
@@ -197,10 +198,10 @@ __global__ __launch_bounds__(64 * MLP_WAVES_PER_BLOCK) void annp_mlp_mfma(MlpArg
     constexpr int KSH = S::KSH, MT0 = S::MT0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *opnd = reinterpret_cast<double *>(lds_raw);                 // [S::total][64]
-    double *cbuf_all = opnd + (size_t)S::total * 64;                    // [4 waves][16][MLP_CROW]
 
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
+    double *cbuf = opnd + (size_t)S::total * 64 + (size_t)wave * 16 * MLP_CROW;      // [16][MLP_CROW] per wave (MLP_STAGED only)
     const int lr = lane & 15, lq = lane >> 4;
     const int nsf = p.nsf;
 
@@ -211,7 +212,6 @@ __global__ __launch_bounds__(64 * MLP_WAVES_PER_BLOCK) void annp_mlp_mfma(MlpArg
         for (int idx = threadIdx.x; idx < S::total * 32; idx += 64 * MLP_WAVES_PER_BLOCK) dst[idx] = src[idx];
     }
     __syncthreads();
-    double *cbuf = cbuf_all + (size_t)wave * 16 * MLP_CROW;
     ActParam ap[NL];
 #pragma unroll
     for (int l = 0; l < NL; l++) ap[l] = act_param(p.act[l], p.act_plain);
@@ -256,7 +256,6 @@ __global__ __launch_bounds__(64 * MLP_WAVES_PER_BLOCK) void annp_mlp_mfma(MlpArg
 #pragma unroll
             for (int s = 0; s < KS0; s++) hin[s] = aval ? hin[s] : 0.0;
         }
-        const unsigned rowmask = (unsigned)(__ballot(aval) & 0xffffull);     // lanes 0..15 speak for the 16 atoms
         // ---- forward
         double4_t H[NL][MT], D[NL][MT];
 #pragma unroll
@@ -338,24 +337,34 @@ __global__ __launch_bounds__(64 * MLP_WAVES_PER_BLOCK) void annp_mlp_mfma(MlpArg
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) dl[mt] = nx[mt];
         }
-        // coef[k = 16mt+lq+4r][atom] = coefmat . delta_0  -> LDS [atom][48] -> coalesced rows
+        // coef[k = 16mt+lq+4r][atom] = coefmat . delta_0.  Small networks (MT = 1: the operand image is ~22 KB) stage the tile
+        // through LDS [atom][48] and store whole rows; for the wide ones (MT = 2: 51 KB) those 6.3 KB per wave would halve the
+        // resident waves, so they store straight from the fragment: the four registers of an M-tile are 16 consecutive doubles
+        // of the atom's row, one 128-byte line completed by four store instructions in a row.
 #pragma unroll
         for (int mt = 0; mt < MT0; mt++) {
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < KSH; s++)
                 if (mt < mt0 && s < ksh) acc = mfma_f64(opnd[(size_t)(S::bwd0 + mt * KSH + s) * 64 + lane], dl[s / 4][s % 4], acc);
+            if (MLP_STAGED(MT)) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) cbuf[lr * MLP_CROW + 16 * mt + lq + 4 * r] = acc[r];
+                for (int r = 0; r < 4; r++) cbuf[lr * MLP_CROW + 16 * mt + lq + 4 * r] = acc[r];
+            } else if (aval) {
+                double *dst = p.coef + (size_t)ia * ANNP_CPAD + 16 * mt + lq;
+#pragma unroll
+                for (int r = 0; r < 4; r++) dst[4 * r] = acc[r];
+            }
         }
-        wave_lds_sync();
-        {
+        if (MLP_STAGED(MT)) {
+            wave_lds_sync();
+            const unsigned rowmask = (unsigned)(__ballot(aval) & 0xffffull);     // lanes 0..15 speak for the 16 atoms
             const int nrow = min(16, p.inum - tile * 16);
             double *dst = p.coef + (size_t)tile * 16 * ANNP_CPAD;
             for (int idx = lane; idx < nrow * ANNP_CPAD; idx += 64)
                 if ((rowmask >> (idx / ANNP_CPAD)) & 1u) dst[idx] = cbuf[idx + idx / ANNP_CPAD];
+            wave_lds_sync();
         }
-        wave_lds_sync();
     }
     if (p.eng) {
         e_wave = wave_sum(e_wave);
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES_PER_BLOCK) void annp_mlp_mfma(MlpArg
 template <int KS0, int MT, int NL>
 inline size_t mlp_lds_bytes()
 {
-    return ((size_t)MlpSlots<KS0, MT, NL>::total * 64 + (size_t)MLP_WAVES_PER_BLOCK * 16 * MLP_CROW) * sizeof(double);
+    return ((size_t)MlpSlots<KS0, MT, NL>::total * 64 + (MLP_STAGED(MT) ? (size_t)MLP_WAVES_PER_BLOCK * 16 * MLP_CROW : 0)) * sizeof(double);
 }
 
 }  // namespace annp
