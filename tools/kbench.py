@@ -6,6 +6,7 @@
 import ctypes as C
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -47,6 +48,15 @@ def main():
     st = torch.cuda.current_stream(dev).cuda_stream
     pn, pf, pg, mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
     assert lib.annp_hip_neigh_build_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), rc_list, C.byref(pn), C.byref(pf), C.byref(pg), C.byref(mx), st) == 0
+    # rebuilds of the same list (the second and later ones take the pitched one-pass layout)
+    tb = []
+    for _ in range(4):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        assert lib.annp_hip_neigh_build_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), rc_list, C.byref(pn), C.byref(pf), C.byref(pg), C.byref(mx), st) == 0
+        torch.cuda.synchronize(dev)
+        tb.append((time.perf_counter() - t0) * 1e3)
+    print("list builds (host clock, ms): first %.2f, rebuilds %s" % (tb[0], " ".join("%.2f" % v for v in tb[1:])))
     eng = torch.zeros(1, dtype=torch.float64, device=dev)
     lib.annp_hip_set_timing(h, 1)
     for _ in range(reps + 1):
