@@ -152,7 +152,7 @@ class Leg:
     force clear, ghost-force fold) are the library's kernels (annp_hip_verlet_half / _halo_pack / _halo_unpack_images /
     _reverse_fold); torch only owns the buffers and the RCCL point-to-point group."""
 
-    def __init__(self, args, wl, cells, dev, tp, dry, local_rank, wire_self=False):
+    def __init__(self, args, wl, cells, dev, tp, dry, local_rank, wire_self=False, wire_lib=False):
         import torch
         from annp_testlib import A_FE, A_NI, ANNA_POT, FE_POT, NI_POT, bcc, fcc, perturb
         from meng_zhang_amd.domain import SlabDomain
@@ -177,6 +177,9 @@ class Leg:
             self.pair.init_style()
             self.h = self.pair.handle
         hip = None if (dry or os.environ.get("ANNP_BENCH_TORCH_STEP") == "1") else (self.lib, self.h)
+        if wire_lib:
+            from meng_zhang_amd.domain import LibTransport
+            tp = LibTransport(self.lib, self.h, tp, dev)
         self.dom = SlabDomain.from_global(xg, box, (1, 1, 1), self.rc_list, dev, tp, extra={"v": np.zeros_like(xg)}, hip=hip, wire_self=wire_self)
         self.p_num, self.p_first, self.p_neigh, self.mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
         self.eng = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -343,7 +346,10 @@ def run_rank(args):
         if not dry:
             torch.cuda.synchronize(dev)
 
-    leg = Leg(args, args.workload, args.cells, dev, tp, dry, local_rank, wire_self)
+    # ANNP_BENCH_WIRE=lib: the point-to-point groups of the halo are issued by the library itself (annp_hip_comm_route: RCCL from
+    # C++ on the compute stream) instead of torch.distributed's batch_isend_irecv.  Opt-in: the default wire is torch's.
+    wire_lib = os.environ.get("ANNP_BENCH_WIRE") == "lib" and use_dist and not dry and not staged and (world > 1 or wire_self)
+    leg = Leg(args, args.workload, args.cells, dev, tp, dry, local_rank, wire_self, wire_lib)
     dom, lib, h = leg.dom, leg.lib, leg.h
     wl, natoms, rc_list, potfile, mx = leg.wl, leg.natoms, leg.rc_list, leg.potfile, leg.mx
     check, step, force_eval = leg.check, leg.step, leg.force_eval
@@ -466,7 +472,7 @@ def run_rank(args):
             "atoms": natoms,
             "world_size": dist.get_world_size() if use_dist else 1,
             "backend": ("gloo (rehearsal)" if (dry or staged) else "nccl (RCCL)") if use_dist else "none (single rank)",
-            "wire_self": bool(wire_self),
+            "wire_self": bool(wire_self), "wire": "libannp_hip (annp_hip_comm_route: RCCL from C++)" if wire_lib else ("torch.distributed" if use_dist else "none"),
             "atoms_rank": [int(v) for v in per_rank[:, 0]], "ghosts_rank": [int(v) for v in per_rank[:, 1]],
             "halo_bytes_per_step": int(per_rank[:, 2].sum()),
             "neighbors_in_cutoff_mean": float(n.mean()) if not dry else None, "list_neighbors_max": int(mx.value),

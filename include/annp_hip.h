@@ -218,6 +218,23 @@ int annp_hip_reverse_fold(annp_hip_handle *handle, int nseg, const int *d_seg_ds
 int annp_hip_verlet_half(annp_hip_handle *handle, int n, double *d_x, double *d_v, const double *d_f, double dtf, double dt,
                          void *stream);
 
+/* ---- the halo wire --------------------------------------------------------------------------------------------------
+ * RCCL point-to-point between the ranks of a spatial decomposition (one process per GPU, one handle per process), called
+ * from C++ on the caller's compute stream: what LAMMPS' Comm does over MPI for the reference (`processors 2 1 1` +
+ * `package gpu 2`, annp-gpu-lammps/fe_v2/performance test.zip -> in.st_test:3-4).  librccl.so.1 is opened at run time
+ * (dlopen): no link-time dependency, and a process that has it loaded already (torch) shares that copy.
+ *   annp_hip_comm_unique_id  128 bytes (ncclUniqueId) made on one rank; the caller brings them to every rank (MPI_Bcast, ...)
+ *   annp_hip_comm_init       ncclCommInitRank on the handle's device; collective over the `world` ranks
+ *   annp_hip_comm_route      one ncclGroupStart .. ncclGroupEnd of nmsg transfers: message k sends (is_send[k] != 0) or
+ *                            receives ndoubles[k] doubles at device pointer d_buf[k] to / from rank peer[k] (peer == own rank
+ *                            is allowed: a slab that is its own periodic neighbour); asynchronous on `stream`
+ *   annp_hip_comm_destroy    also done by annp_hip_clear */
+int annp_hip_comm_unique_id(char *id128);
+int annp_hip_comm_init(annp_hip_handle *handle, const char *id128, int world, int rank);
+int annp_hip_comm_route(annp_hip_handle *handle, int nmsg, const int *is_send, double *const *d_buf, const long long *ndoubles,
+                        const int *peer, void *stream);
+int annp_hip_comm_destroy(annp_hip_handle *handle);
+
 /* Blocks until the handle's enqueued work is done and reports deferred device-side
  * errors (e.g. ANNP_HIP_ENEIGHCAP). */
 int annp_hip_sync(annp_hip_handle *handle);

@@ -7,7 +7,9 @@
 // Per call: descriptor pass -> network pass (FP64 MFMA) -> force pass, all on one
 // stream, buffers owned by the handle.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <sched.h>
+#include <rccl/rccl.h>       // types only: the library is opened at run time (annp_hip_comm_init), there is no link-time dependency
 
 #include <algorithm>
 #include <atomic>
@@ -159,6 +161,9 @@ struct annp_hip_handle {
     HostReg reg_x, reg_f;
     bool use_register = true;           // ANNP_HIP_REGISTER=0 turns it off (pinned staging + host folds instead)
     hipStream_t stream2 = nullptr;      // uploads that overlap the first passes of an evaluation
+    // RCCL communicator for the halo wire (annp_hip_comm_*): one rank per handle
+    ncclComm_t comm = nullptr;
+    int comm_world = 0, comm_rank = -1;
     hipEvent_t ev_f_up = nullptr;
     hipEvent_t pre_force_wait = nullptr;    // set by the host path: the force pass must not start before this event
     // host-list upload (annp_hip_compute, ago == 0): CSR headers and the rows go through pinned staging; the rows in
@@ -623,6 +628,45 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     return 0;
 }
 
+// ---- the halo wire: RCCL point-to-point, called from here --------------------------------------------------------------
+// librccl is opened at run time, so a build of LAMMPS that never asks for the wire does not need it; a process that has
+// torch loaded gets torch's copy (same soname), which keeps one RCCL per process.
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) { r.err = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); return; }
+#define RCCL_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, sym)); if (!r.field) { r.err = std::string("librccl lacks ") + sym; return; }
+        RCCL_SYM(GetUniqueId, "ncclGetUniqueId") RCCL_SYM(CommInitRank, "ncclCommInitRank") RCCL_SYM(CommDestroy, "ncclCommDestroy")
+        RCCL_SYM(GroupStart, "ncclGroupStart") RCCL_SYM(GroupEnd, "ncclGroupEnd") RCCL_SYM(Send, "ncclSend") RCCL_SYM(Recv, "ncclRecv")
+        RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+    });
+    return r;
+}
+#define RCCL_TRY(h, call)                                                                                        \
+    do {                                                                                                         \
+        ncclResult_t r_ = (call);                                                                                \
+        if (r_ != ncclSuccess) return fail(h, ANNP_HIP_EDEVICE, "%s failed: %s", #call, rccl().GetErrorString(r_)); \
+    } while (0)
+
 // CPUs this process may use: the affinity mask capped by the cgroup quota (hardware_concurrency() knows neither, and
 // under the usual one-core-per-rank MPI binding sixteen copy threads would time-share that one core)
 int usable_cpus()
@@ -686,6 +730,7 @@ void annp_hip_clear(annp_hip_handle *h)
     if (!h) return;
     DeviceGuard guard_(h->device);
     (void)hipDeviceSynchronize();           // evaluations may still be running on the caller's streams
+    if (h->comm) { (void)rccl().CommDestroy(h->comm); h->comm = nullptr; }
     if (h->d_norm) (void)hipFree(h->d_norm);
     if (h->d_sym) (void)hipFree(h->d_sym);
     if (h->d_isym) (void)hipFree(h->d_isym);
@@ -1213,6 +1258,68 @@ int annp_hip_neigh_to_host(annp_hip_handle *h, int nlocal, int *numneigh, long l
         if (c > 0 && (rc = pack(c - 1))) return rc;     // chunk c is in flight while chunk c-1 is packed; with 3 buffers chunk c+1 never lands on one still being read
     }
     if (nchunks > 0 && (rc = pack(nchunks - 1))) return rc;
+    return 0;
+}
+
+// ---- the halo wire: RCCL point-to-point, called from here (loader: see rccl() above) ---------------------------------
+int annp_hip_comm_unique_id(char *id128)
+{
+    if (!id128) return ANNP_HIP_EARG;
+    Rccl &r = rccl();
+    if (!r.err.empty()) return fail(nullptr, ANNP_HIP_EDEVICE, "%s", r.err.c_str());
+    ncclUniqueId id;
+    if (r.GetUniqueId(&id) != ncclSuccess) return fail(nullptr, ANNP_HIP_EDEVICE, "ncclGetUniqueId failed");
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int annp_hip_comm_init(annp_hip_handle *h, const char *id128, int world, int rank)
+{
+    if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return h ? fail(h, ANNP_HIP_EARG, "comm_init: bad argument") : ANNP_HIP_EARG;
+    Rccl &r = rccl();
+    if (!r.err.empty()) return fail(h, ANNP_HIP_EDEVICE, "%s", r.err.c_str());
+    DEVICE_GUARD(h);
+    if (h->comm) { (void)r.CommDestroy(h->comm); h->comm = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    RCCL_TRY(h, r.CommInitRank(&h->comm, world, id, rank));
+    h->comm_world = world; h->comm_rank = rank;
+    return 0;
+}
+
+int annp_hip_comm_route(annp_hip_handle *h, int nmsg, const int *is_send, double *const *d_buf, const long long *ndoubles,
+                        const int *peer, void *stream)
+{
+    if (!h || nmsg < 0 || (nmsg > 0 && (!is_send || !d_buf || !ndoubles || !peer))) return h ? fail(h, ANNP_HIP_EARG, "comm_route: bad argument") : ANNP_HIP_EARG;
+    if (!h->comm) return fail(h, ANNP_HIP_EARG, "comm_route: annp_hip_comm_init has not been called on this handle");
+    if (nmsg == 0) return 0;
+    for (int k = 0; k < nmsg; k++)
+        if (peer[k] < 0 || peer[k] >= h->comm_world || ndoubles[k] < 0 || (ndoubles[k] > 0 && !d_buf[k]))
+            return fail(h, ANNP_HIP_EARG, "comm_route: message %d: peer %d, %lld doubles", k, peer[k], ndoubles[k]);
+    Rccl &r = rccl();
+    DEVICE_GUARD(h);
+    hipStream_t s = (hipStream_t)stream;
+    RCCL_TRY(h, r.GroupStart());
+    for (int k = 0; k < nmsg; k++) {
+        if (ndoubles[k] == 0) continue;
+        const ncclResult_t e = is_send[k] ? r.Send(d_buf[k], (size_t)ndoubles[k], ncclDouble, peer[k], h->comm, s)
+                                          : r.Recv(d_buf[k], (size_t)ndoubles[k], ncclDouble, peer[k], h->comm, s);
+        if (e != ncclSuccess) { (void)r.GroupEnd(); return fail(h, ANNP_HIP_EDEVICE, "ncclSend/ncclRecv failed: %s", r.GetErrorString(e)); }
+    }
+    RCCL_TRY(h, r.GroupEnd());
+    return 0;
+}
+
+int annp_hip_comm_destroy(annp_hip_handle *h)
+{
+    if (!h) return ANNP_HIP_EARG;
+    if (h->comm) {
+        DeviceGuard guard_(h->device);
+        (void)hipDeviceSynchronize();
+        (void)rccl().CommDestroy(h->comm);
+        h->comm = nullptr; h->comm_world = 0; h->comm_rank = -1;
+    }
     return 0;
 }
 

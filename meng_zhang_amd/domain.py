@@ -79,6 +79,53 @@ class TorchTransport:
         return t
 
 
+class LibTransport:
+    """The halo wire in the library: point-to-point groups are issued by libannp_hip.so itself (annp_hip_comm_route: ncclGroupStart
+    / ncclSend / ncclRecv / ncclGroupEnd on the caller's compute stream, no hop through torch's communication stream).  The small
+    collectives of a re-planning (message sizes) and the scalars stay with `collectives` (a TorchTransport).
+    The RCCL communicator is created here: rank 0 makes the unique id, `collectives` broadcasts its 128 bytes."""
+
+    def __init__(self, lib, handle, collectives, device):
+        import ctypes as C
+        import torch
+        self.lib, self.h, self.col, self.device, self.C, self.torch = lib, handle, collectives, device, C, torch
+        self.world, self.rank = collectives.world, collectives.rank
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            self._check(lib.annp_hip_comm_unique_id(buf), "comm_unique_id")
+        ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(device)
+        collectives.dist.broadcast(ident, 0)
+        self._check(lib.annp_hip_comm_init(handle, bytes(ident.cpu().numpy().tobytes()), self.world, self.rank), "comm_init")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.annp_hip_last_error(self.h if what != "comm_unique_id" else None).decode()))
+
+    def route(self, msgs):
+        C = self.C
+        msgs = [m for m in msgs if m[1].numel()]
+        n = len(msgs)
+        if n == 0:
+            return
+        for _, t, _ in msgs:
+            assert t.is_contiguous() and t.dtype == self.torch.float64
+        kinds = (C.c_int * n)(*[1 if k == "send" else 0 for k, _, _ in msgs])
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for _, t, _ in msgs])
+        cnts = (C.c_longlong * n)(*[t.numel() for _, t, _ in msgs])
+        peers = (C.c_int * n)(*[p for _, _, p in msgs])
+        st = self.torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.annp_hip_comm_route(self.h, n, kinds, ptrs, cnts, peers, st), "comm_route")
+
+    def allgather(self, t):
+        return self.col.allgather(t)
+
+    def allreduce_max(self, v):
+        return self.col.allreduce_max(v)
+
+    def allreduce_sum_(self, t):
+        return self.col.allreduce_sum_(t)
+
+
 def slab_bounds(box, world, rank):
     lx = box[3] - box[0]
     return box[0] + lx * rank / world, box[0] + lx * (rank + 1) / world

@@ -165,3 +165,32 @@ def test_domain_on_hip_kernels_equals_domain_on_torch_ops(ctx, fe_pot, world):
     f = np.empty_like(xg)
     f[ids] = np.concatenate([r[1]["f"] for r in a])
     assert np.abs(f - o["f"]).max() < 1e-8 * max(1.0, np.abs(o["f"]).max())
+
+
+def test_library_wire_sends_to_itself(ctx):
+    """annp_hip_comm_*: the library's own RCCL caller (librccl opened at run time).  One rank is a whole communicator;
+    a grouped send + receive with peer == own rank is what a slab that is its own periodic neighbour does."""
+    torch, lib, _, dev = ctx
+    from meng_zhang_amd import PairANNP
+    pair = PairANNP(1, device=0)
+    pair.settings([])
+    pair.coeff(["*", "*", FE_POT, "Fe"])
+    pair.init_style()
+    h = pair.handle
+    st = torch.cuda.current_stream(dev).cuda_stream
+    a = torch.arange(3000, dtype=torch.float64, device=dev).reshape(1000, 3) * 0.25
+    b = torch.zeros_like(a)
+    kinds, cnts, peers = (C.c_int * 2)(1, 0), (C.c_longlong * 2)(3000, 3000), (C.c_int * 2)(0, 0)
+    ptrs = (C.c_void_p * 2)(a.data_ptr(), b.data_ptr())
+    assert lib.annp_hip_comm_route(h, 2, kinds, ptrs, cnts, peers, st) == -1            # no communicator yet
+    assert b"annp_hip_comm_init" in lib.annp_hip_last_error(h)
+    ident = C.create_string_buffer(128)
+    assert lib.annp_hip_comm_unique_id(ident) == 0
+    assert lib.annp_hip_comm_init(h, ident.raw, 1, 0) == 0, lib.annp_hip_last_error(h)
+    assert lib.annp_hip_comm_route(h, 2, kinds, ptrs, cnts, peers, st) == 0, lib.annp_hip_last_error(h)
+    torch.cuda.synchronize(dev)
+    assert torch.equal(a, b)
+    peers_bad = (C.c_int * 2)(0, 1)
+    assert lib.annp_hip_comm_route(h, 2, kinds, ptrs, cnts, peers_bad, st) == -1          # peer outside the communicator
+    assert lib.annp_hip_comm_destroy(h) == 0
+    pair.close()

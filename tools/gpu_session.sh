@@ -16,6 +16,7 @@ for step in "$@"; do
     bench)    timeout -k 10 600 python bench.py > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }; cat $out/bench.json ;;
     hostpath) timeout -k 10 600 python tools/hostpath_bench.py 80 > $out/hostpath.log 2>&1 || { tail -20 $out/hostpath.log; exit 1; }; cat $out/hostpath.log ;;
     selfwire) ANNP_FORCE_DIST=1 ANNP_BENCH_WIRE_SELF=1 timeout -k 10 300 python bench.py --cells 40 --steps 10 --secondary 0 --cpu-sample 0 > $out/selfwire.json 2> $out/selfwire.err; echo "selfwire rc=$?"; tail -5 $out/selfwire.err; cat $out/selfwire.json
+              ANNP_FORCE_DIST=1 ANNP_BENCH_WIRE_SELF=1 ANNP_BENCH_WIRE=lib timeout -k 10 300 python bench.py --cells 40 --steps 10 --secondary 0 --cpu-sample 0 > $out/selfwire_lib.json 2> $out/selfwire_lib.err; echo "selfwire_lib rc=$?"; tail -5 $out/selfwire_lib.err; cat $out/selfwire_lib.json
               timeout -k 10 300 python bench.py --cells 40 --steps 10 --secondary 0 --cpu-sample 0 > $out/selfwire_ref.json 2> $out/selfwire_ref.err; cat $out/selfwire_ref.json ;;
     prof)     timeout -k 10 1100 bash tools/collect_profiles.sh $name || exit 1 ;;
     profni)   timeout -k 10 900 bash tools/collect_profiles.sh $name ni || exit 1 ;;
