@@ -42,6 +42,11 @@ __device__ __forceinline__ int xcd_block()
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Is LAMMPS type t mapped to an element?  `active` has bit t set for the mapped types 1..ntypes (<= 30).  A type outside that
+// range (a caller's mistake the device-resident entry points cannot check on the host) reads as "not mapped": the atom is
+// dropped, nothing is indexed with it.
+__device__ __forceinline__ bool type_mapped(unsigned active, int t) { return (unsigned)t < 32u && ((active >> t) & 1u); }
+
 // cutoff function and derivative, fe_v2/src/pair_annp.cpp:590-594
 __device__ __forceinline__ void cutoff_fc(double r, double pi_over_rc, double &fc, double &dfc)
 {

@@ -457,7 +457,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         return fail(h, ANNP_HIP_EARG, "this potential distinguishes atom types (several elements or an unmapped type): d_type is required");
     const int *types = h->multi ? d_type : nullptr;
     MlpArgs m{};
-    m.type = types; m.map = h->d_map; m.elem = 0;
+    m.type = types; m.map = h->d_map; m.elem = 0; m.active = h->active;
     m.inum = inum; m.ilist = d_ilist; m.nsf = h->nsf_dev; m.nnod = h->nnod; m.nl = h->nl;
     m.ncoef = h->descriptor == ANNP_HIP_DESC_CHEBYSHEV ? FE_NP + 2 * FE_NT - 1 : h->nsf_dev;
     for (int l = 0; l < std::min(h->nl, (int)MLP_MAXL); l++) m.act[l] = h->flagact[l];      // (anna_adp may have more layers; it does not use m)

@@ -109,7 +109,7 @@ __device__ __forceinline__ int fe_compact(const FeArgs &p, int i, int lane, doub
         }
         if (p.type) {          // wave-uniform: only potentials with an unmapped type pay for the gather
 #pragma unroll
-            for (int u = 0; u < 4; u++) valid[u] = valid[u] && ((p.active >> p.type[j[u]]) & 1u);
+            for (int u = 0; u < 4; u++) valid[u] = valid[u] && type_mapped(p.active, p.type[j[u]]);
         }
         double dx[4], dy[4], dz[4];
 #pragma unroll
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
     const double two_over_rcp = 2.0 / p.rc_par;
 
-    if (p.type && !((p.active >> p.type[i]) & 1u)) {      // centre of an unmapped type: no neighbours, no energy
+    if (p.type && !type_mapped(p.active, p.type[i])) {      // centre of an unmapped type: no neighbours, no energy
         if (p.ncount && lane == 0) p.ncount[ii] = 0;
         if (lane < ANNP_GPAD) p.G[(size_t)ii * ANNP_GPAD + lane] = 0.0;
         return;
@@ -389,7 +389,7 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
     const double two_over_rcp = 2.0 / p.rc_par;
     const double *cf = p.coef + (size_t)ii * ANNP_CPAD;
 
-    if (p.type && !((p.active >> p.type[i]) & 1u)) return;
+    if (p.type && !type_mapped(p.active, p.type[i])) return;
     const int n = fe_compact<true>(p, i, lane, recA, recB, auxJ, n_cap);
     if (n > n_cap) {            // does not fit this launch's records: hand the atom to the fix-up launch
         if (lane == 0) {

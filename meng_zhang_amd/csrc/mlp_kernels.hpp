@@ -58,6 +58,7 @@ struct MlpArgs {
     // type maps to `elem` and leaving every other row of coef alone (fe_v2/src/pair_annp.cpp:767-768)
     const int *type;              // nullable [nall]
     const int *map;               // device [ntypes+1]
+    unsigned active;              // bit t: type t is mapped (annp_common.hpp type_mapped)
     int elem;
 };
 
@@ -251,7 +252,10 @@ __global__ __launch_bounds__(64 * MLP_WAVES_PER_BLOCK) void annp_mlp_mfma(MlpArg
         }
         request(tile + wave_stride);
         if (p.type) {
-            if (aval) aval = p.map[p.type[p.ilist ? p.ilist[ia] : ia]] == p.elem;
+            if (aval) {
+                const int t = p.type[p.ilist ? p.ilist[ia] : ia];
+                aval = type_mapped(p.active, t) && p.map[t] == p.elem;
+            }
             if (__ballot(aval) == 0ull) continue;                            // no atom of this element in the tile
 #pragma unroll
             for (int s = 0; s < KS0; s++) hin[s] = aval ? hin[s] : 0.0;

@@ -408,7 +408,7 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
         if (ii < p.inum) {
             hi = p.ilist ? p.ilist[ii] : ii;
             hjn = p.numneigh[hi];
-            if (p.type && !((p.active >> p.type[hi]) & 1u)) hjn = 0;      // centre of an unmapped type: nothing in range
+            if (p.type && !type_mapped(p.active, p.type[hi])) hjn = 0;      // centre of an unmapped type: nothing in range
             hbase = p.first[hi];
             hx = p.x[3 * (size_t)hi]; hy = p.x[3 * (size_t)hi + 1]; hz = p.x[3 * (size_t)hi + 2];
         }
@@ -448,7 +448,7 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
 #pragma unroll
             for (int ga = 0; ga < NI_GA; ga++)
 #pragma unroll
-                for (int u = 0; u < 2; u++) valid[ga][u] = valid[ga][u] && ((p.active >> p.type[j[ga][u]]) & 1u);
+                for (int u = 0; u < 2; u++) valid[ga][u] = valid[ga][u] && type_mapped(p.active, p.type[j[ga][u]]);
         }
         double qx[NI_GA][2], qy[NI_GA][2], qz[NI_GA][2];
 #pragma unroll
@@ -505,7 +505,7 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
             }
             if (p.type) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) valid[u] = valid[u] && ((p.active >> p.type[j[u]]) & 1u);
+                for (int u = 0; u < 4; u++) valid[u] = valid[u] && type_mapped(p.active, p.type[j[u]]);
             }
             double dx[4], dy[4], dz[4];
 #pragma unroll
