@@ -148,12 +148,12 @@ int annp_hip_compute_n(annp_hip_handle *handle, int ago, int inum, int nall, int
  * Asynchronous: every kernel and copy is enqueued on `stream` and the call returns without waiting for
  * the device (the calling thread's current device is left as it was).  The LDS record capacity of the
  * force pass comes from the in-cutoff maximum of the PREVIOUS evaluation on the handle, read back
- * without blocking; Chebyshev: an atom that has more neighbours than that is queued on the device and
- * evaluated by a fix-up launch on the same stream, so the result is complete whatever the
- * configuration does between two calls.  Two exceptions wait for the device once: the first
- * evaluation on a handle, and (Behler only) the one after a capacity error.
- * Device-side capacity errors (Behler: more in-range neighbours than the previous maximum + 1/8;
- * anna_adp: more than 128; any: a list row longer than max_numneigh) skip the affected atoms and are
+ * without blocking; an atom that has more neighbours than that is queued on the device and evaluated by a
+ * fix-up launch on the same stream (Chebyshev: of the force pass; Behler: of both passes, by groups of four
+ * atoms), so the result is complete whatever the configuration does between two calls.  Two exceptions wait
+ * for the device once: the first evaluation on a handle, and the one after a capacity error.
+ * Device-side capacity errors (more in-range neighbours than the largest LDS records hold: ~96 per atom for the
+ * Behler kernels, 128 for anna_adp; any: a list row longer than max_numneigh) skip the affected atoms and are
  * reported as ANNP_HIP_ENEIGHCAP by the NEXT call on the handle or by annp_hip_sync, however many
  * evaluations were enqueued in between (the error word stays set on the device until it was seen). */
 int annp_hip_compute_device(annp_hip_handle *handle, int inum, int nall,
@@ -240,7 +240,7 @@ int annp_hip_comm_destroy(annp_hip_handle *handle);
 int annp_hip_sync(annp_hip_handle *handle);
 
 /* Facts about the most recent evaluation (waits for its flag words only):
- *   info4[0] largest in-cutoff neighbour count   info4[1] atoms that went through the fix-up launch
+ *   info4[0] largest in-cutoff neighbour count   info4[1] atoms (Behler: groups of four atoms) that went through the fix-up launch
  *   info4[2] record capacity its force pass ran with   info4[3] capacity the next evaluation will use */
 int annp_hip_eval_info(annp_hip_handle *handle, int *info4);
 

@@ -109,6 +109,7 @@ struct annp_hip_handle {
     int descriptor = 0, ntypes = 1, ntl = 0, nhl = 0, nnod = 0, nsf = 0, npsf = 0, ntsf = 0, nl = 0;
     int nsf_dev = 0;                    // features in the device layout (Chebyshev: always 9 + 19 slots, unused ones carry zero weights)
     int ni_compat = 0;
+    bool ni_no_fixup = false;           // ANNP_HIP_NI_FIXUP=0: no queue behind the Behler records (overflow is an error again)
     bool ni_no_pairs = false;           // ANNP_HIP_NI_PAIRS=0: the Behler force pass finds its pairs itself (no lists through memory)
     bool full_list = false;             // ANNP_HIP_FULL_LIST=1: library-built lists are cut where the caller says (list_cutoff)
     // pair_style anna_adp
@@ -137,7 +138,7 @@ struct annp_hip_handle {
     std::vector<double> sym_rad, sym_ang;
     // work buffers
     DevBuf<double> G, coef, x, f, eatom, vatom;
-    DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ni_npair, ovf;
+    DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ni_npair, ni_fix_nbr, ovf;
     DevBuf<unsigned short> ni_pairs;    // Behler: in-range (j,k) pairs per atom, descriptor pass -> force pass
     DevBuf<long long> first;
     double *d_scalars = nullptr;        // [0] energy, [1..6] virial
@@ -331,12 +332,11 @@ void digest_flags(annp_hip_handle *h)
             h->sticky_rc = fail(h, ANNP_HIP_ENEIGHCAP, "an atom has %d in-cutoff neighbours, more than the list-row capacity the "
                                 "evaluation was given (max_numneigh) or than LDS holds; it was skipped", over);
     } else if (h->descriptor == ANNP_HIP_DESC_BEHLER) {
-        if (over > 0) {
+        if (over > 0) {         // not an atom that outgrew its records (the fix-up launches take those): more than LDS can hold
             h->ni_cap = round_up(over + 2, 8);
             h->ni_primed = false;
-            h->sticky_rc = fail(h, ANNP_HIP_ENEIGHCAP, "%d neighbours inside the descriptor cutoff exceed the record capacity %d of "
-                                "that evaluation; the affected atoms were skipped: re-issue it (the capacity has been raised)",
-                                over, h->cap_last);
+            h->sticky_rc = fail(h, ANNP_HIP_ENEIGHCAP, "%d neighbours inside the descriptor cutoff exceed what the kernels' LDS records can hold "
+                                "(or the list row is longer than max_numneigh said); the affected atoms were skipped", over);
         } else {
             h->ni_cap = ni_next_cap(mx);
         }
@@ -577,37 +577,41 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             q.pairs = h->ni_pairs.p; q.npair = h->ni_npair.p; q.pstride = (int)ps;
             return 0;
         };
-        if (!h->ni_primed) {
-            // first evaluation (or the one after a capacity error): size the records synchronously, retry once
-            for (int attempt = 0;; attempt++) {
-                a.n_cap = std::min(h->ni_cap, cap_max);
-                if ((rc = ensure(h, h->ni_nbr, (size_t)inum * a.n_cap)) || (rc = pair_room(a))) return rc;
-                a.nbr = h->ni_nbr.p; a.nbr_stride = a.n_cap;
-                ni_launch_desc(a, h->ni_shape, s);
-                HIP_TRY(h, hipGetLastError());
-                hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
-                HIP_TRY(h, hipGetLastError());
-                HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
-                HIP_TRY(h, hipStreamSynchronize(s));
-                if (h->h_flags[0] <= 0) break;
-                HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, 3 * sizeof(int), s));
-                if (h->h_flags[0] > cap_max || attempt > 0)
-                    return fail(h, ANNP_HIP_ENEIGHCAP, "%d neighbours inside the descriptor cutoff exceed the kernel capacity %d",
-                                h->h_flags[0], cap_max);
-                h->ni_cap = round_up(h->h_flags[0], 8);           // some atom overflowed: redo the pass with room for it
+        // Records: n_cap per atom from the previous evaluation's maximum.  A group of four atoms that has more is queued by the
+        // descriptor pass and taken, pass by pass, by a second small launch whose records hold a whole list row (cap_big), so
+        // the evaluation is complete whatever the configuration did since the capacity was learned.  An error remains only
+        // for more in-range neighbours than the largest records LDS can hold, or a list row longer than the caller said.
+        a.n_cap = std::min(h->ni_cap, cap_max);
+        if ((rc = ensure(h, h->ni_nbr, (size_t)inum * a.n_cap)) || (rc = pair_room(a))) return rc;
+        a.nbr = h->ni_nbr.p; a.nbr_stride = a.n_cap;
+        const int cap_big = std::min(cap_max, std::max(a.n_cap, round_up(std::max(max_numneigh, 8), 8)));
+        const bool fixup = cap_big > a.n_cap && !h->ni_no_fixup;
+        const int ngroups = (inum + NI_GA - 1) / NI_GA;
+        a.ovf_count = h->d_flags + 2; a.ovf_list = nullptr; a.ovf_cap = 0; a.fix = 0; a.skip_above = a.n_cap;
+        if (fixup) {
+            if ((rc = ensure(h, h->ovf, (size_t)ngroups)) || (rc = ensure(h, h->ni_fix_nbr, (size_t)ngroups * NI_GA * cap_big))) return rc;
+            a.ovf_list = h->ovf.p; a.ovf_cap = ngroups;
+        }
+        NiArgs b = a;           // the fix-up launches
+        b.fix = 1; b.n_cap = cap_big; b.nbr = h->ni_fix_nbr.p; b.nbr_stride = cap_big; b.pairs = nullptr; b.pstride = 0;
+        ni_launch_desc(a, h->ni_shape, s);
+        HIP_TRY(h, hipGetLastError());
+        if (fixup) { ni_launch_desc_fix(b, h->ni_shape, s); HIP_TRY(h, hipGetLastError()); }
+        hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
+        HIP_TRY(h, hipGetLastError());
+        cap_force = a.n_cap;
+        if (!h->ni_primed) {    // first evaluation on the handle (or the one after an error): look at the counts once
+            HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+            if (h->h_flags[0] > 0) {
+                h->reset_err = true;
+                h->ni_cap = std::min(cap_max, round_up(h->h_flags[0] + 2, 8));
+                return fail(h, ANNP_HIP_ENEIGHCAP, "%d neighbours inside the descriptor cutoff exceed the kernel capacity %d (list rows: %d)",
+                            h->h_flags[0], cap_big, max_numneigh);
             }
             h->ni_cap = ni_next_cap(h->h_flags[1]);
             h->ni_primed = true;
-            cap_force = std::max(8, round_up(h->h_flags[1], 2));
-        } else {
-            a.n_cap = std::min(h->ni_cap, cap_max);
-            if ((rc = ensure(h, h->ni_nbr, (size_t)inum * a.n_cap)) || (rc = pair_room(a))) return rc;
-            a.nbr = h->ni_nbr.p; a.nbr_stride = a.n_cap;
-            ni_launch_desc(a, h->ni_shape, s);
-            HIP_TRY(h, hipGetLastError());
-            hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
-            HIP_TRY(h, hipGetLastError());
-            cap_force = a.n_cap;
+            cap_force = std::max(8, std::min(a.n_cap, round_up(h->h_flags[1], 2)));     // (fewer LDS bytes: more resident workgroups)
         }
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
         m.act_plain = 1; m.energy_raw = 1;
@@ -618,6 +622,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
         ni_launch_force(a, h->ni_shape, d_virial != nullptr || d_vatom != nullptr, s);
         HIP_TRY(h, hipGetLastError());
+        if (fixup) { ni_launch_force_fix(b, h->ni_shape, d_virial != nullptr || d_vatom != nullptr, s); HIP_TRY(h, hipGetLastError()); }
     }
     // flag words of this evaluation, for whoever looks next (poll_flags)
     HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -738,7 +743,7 @@ void annp_hip_clear(annp_hip_handle *h)
     if (h->d_map) (void)hipFree(h->d_map);
     if (h->d_net) (void)hipFree(h->d_net);
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom); release(h, h->vatom);
-    release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr); release(h, h->ni_npair); release(h, h->ni_pairs); release(h, h->ovf);
+    release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr); release(h, h->ni_npair); release(h, h->ni_fix_nbr); release(h, h->ni_pairs); release(h, h->ovf);
     release(h, h->first);
     neigh_release(h->nb);
     if (h->d_scalars) (void)hipFree(h->d_scalars);
@@ -845,6 +850,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     h->e_scale = p->e_scale; h->e_shift = p->e_shift; h->e_atom = p->e_atom; h->cut = p->cut;
     if (const char *e = std::getenv("ANNP_HIP_FULL_LIST")) h->full_list = std::atoi(e) != 0;
     if (const char *e = std::getenv("ANNP_HIP_NI_PAIRS")) h->ni_no_pairs = std::atoi(e) == 0;
+    if (const char *e = std::getenv("ANNP_HIP_NI_FIXUP")) h->ni_no_fixup = std::atoi(e) == 0;
     h->cutsq = cutsq_all;
     h->nelem = ne; h->multi = multi; h->active = active;
     if (multi) {
@@ -1178,7 +1184,6 @@ int annp_hip_neigh_build_device(annp_hip_handle *h, int nlocal, int nall, const 
     std::string msg;
     size_t before = h->nb.bytes;
     int rc = neigh_build(h->nb, nlocal, nall, d_x, list_cutoff(h, cutneigh), (hipStream_t)stream, msg);
-    h->ni_primed = false;       // Behler: the evaluation behind a rebuild sizes its records from its own counts (one sync)
     h->bytes += h->nb.bytes - before;
     if (rc) return fail(h, rc, "%s", msg.c_str());
     if (d_numneigh) *d_numneigh = h->nb.numneigh;
@@ -1627,7 +1632,6 @@ int annp_hip_compute_n(annp_hip_handle *h, int ago, int inum, int nall, int ngho
         std::string msg;
         size_t before = h->nb.bytes;
         rc = neigh_build(h->nb, inum, nall, h->x.p, list_cutoff(h, cutneigh), s, msg);
-        h->ni_primed = false;
         h->bytes += h->nb.bytes - before;
         if (rc) return fail(h, rc, "%s", msg.c_str());
     }

@@ -77,6 +77,16 @@ struct NiArgs {
     unsigned short *pairs;      // [inum][pstride]
     int pstride;                // >= n_cap (n_cap - 1) / 2 of the descriptor pass
     int *npair;                 // [inum]
+    // Groups of four atoms whose records do not fit n_cap are not lost: the descriptor pass appends the group (its first
+    // list slot) to a queue, and a second, small launch of each pass (`fix` = 1: one wave per queue entry, n_cap large enough
+    // for a whole list row, its own neighbour rows indexed by queue slot) evaluates them -- the same arrangement as the
+    // Chebyshev force pass's fix-up launch.  errflag is raised only when that cannot be done (queue full, or more in-range
+    // neighbours than the largest records LDS can hold).
+    int *ovf_count;             // queue length (device word); null: no queue, overflow is an error
+    int *ovf_list;              // [ovf_cap] first list slot ii0 of each queued group
+    int ovf_cap;
+    int fix;                    // this launch walks the queue
+    int skip_above;             // main force launch: groups with more in-range neighbours than this are the queue's (= n_cap of the main descriptor launch)
     int *errflag;
 };
 
@@ -562,7 +572,7 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
 }
 
 // Force pass: rebuild the records from the compact lists the descriptor pass left (same entries, same order).
-__device__ __forceinline__ int ni_stage_compact(const NiArgs &p, int ii0, const NiLds &L, const double *T, int lane, int &nl, int &npairs)
+__device__ __forceinline__ int ni_stage_compact(const NiArgs &p, int ii0, int row0, const NiLds &L, const double *T, int lane, int &nl, int &npairs)
 {
     const int cap = p.n_cap;
     int hi = -1, hn = 0, hp = 0;
@@ -592,7 +602,7 @@ __device__ __forceinline__ int ni_stage_compact(const NiArgs &p, int ii0, const 
         L.r[s] = 1e3; L.rinv[s] = 1e-3; L.fc[s] = 0.0; L.dfc[s] = 0.0;
     }
     wave_lds_sync();        // math table and coefficient rows written above are visible from here on
-    const int *row = p.nbr + (size_t)(ii0 + g) * p.nbr_stride;
+    const int *row = p.nbr + (size_t)(row0 + g) * p.nbr_stride;       // row0 = ii0, or 4 x the queue slot in a fix-up launch
     for (int a = l; a < nmax; a += NI_GL) {
         if (a < nl) {
             const int s = g * cap + a;
@@ -689,25 +699,43 @@ __device__ __forceinline__ int ni_prepass(const NiLds &L, const NiConst &c, NiWa
 }
 
 // ---------------------------------------------------------------------------------
-template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM>
+// FIX: the fix-up instantiation (its waves walk the queue: a loop around the body, bounded to 2 waves per SIMD so that what the
+// loop keeps live does not spill; it runs on the few groups that outgrew their records, if any)
+template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM, bool FIX>
 // (the table-driven instantiation keeps NI_MAXP + NI_MAXT = 40 accumulators per lane: 128 VGPRs would spill 39 of them)
-__global__ __launch_bounds__(256, NL > 0 ? NI_WAVES_PER_SIMD : 3) void annp_ni_desc(NiArgs p)
+__global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) void annp_ni_desc(NiArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = lane_id();
+    const int lane0 = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int ii0 = uniform((xcd_block() * ANNP_WAVES_PER_BLOCK + wave) * NI_GA);
-    if (ii0 >= p.inum) return;
     const int nsf = p.npsf + p.ntsf;
     const int cap = p.n_cap;
     NiTab tab = ni_tab(p.sym, p.isym, p.npsf, p.ntsf, nullptr);
     const double *srad = tab.rad;
-    const NiConst kc = ni_tables_fill<NL, NE, NZ>(reinterpret_cast<double *>(lds_raw), p, tab, lane);
+    const NiConst kc = ni_tables_fill<NL, NE, NZ>(reinterpret_cast<double *>(lds_raw), p, tab, lane0);
     const double *T = kc.T;
     unsigned char *wbase = lds_raw + NI_TABLE_DOUBLES * 8 + (size_t)wave * ni_lds_per_wave(cap, false, nsf);
     const NiLds L = ni_carve<false>(wbase, cap, 0);
     double *scratch = reinterpret_cast<double *>(wbase);
-    const int g = lane >> 4, l = lane & 15;
+    // main launch: one group of four atoms per wave.  Fix-up launch: a small grid whose waves walk the queue.
+    const int nslots = FIX ? min(*p.ovf_count, p.ovf_cap) : 0;
+    for (int it = 0; FIX || it < 1; it++) {         // (main launch: exactly one trip, no loop is generated)
+    // (the lane number is opaque per trip, as in the force pass: per-lane LDS addresses are formed where they are used instead
+    // of being hoisted out of this loop and spilled -- 60 VGPRs otherwise)
+    int lane_q = lane0;
+    if (FIX) asm volatile("" : "+v"(lane_q));
+    const int lane = lane_q, g = lane_q >> 4, l = lane_q & 15;
+    int ii0, row0;              // first list slot of the group; first row of its neighbour / pair lists
+    if (!FIX) {
+        ii0 = row0 = uniform((xcd_block() * ANNP_WAVES_PER_BLOCK + wave) * NI_GA);
+        if (ii0 >= p.inum) break;
+    } else {
+        const int slot = uniform((it * (int)gridDim.x + (int)blockIdx.x) * ANNP_WAVES_PER_BLOCK + wave);
+        if (slot >= nslots) break;
+        ii0 = uniform(p.ovf_list[slot]);
+        row0 = slot * NI_GA;
+        wave_lds_sync();        // the records and the reduction scratch of the previous entry are dead
+    }
     int nl;
     const int nmax = ni_stage<false>(p, ii0, L, T, lane, nl);
     const int ncl = __shfl(nl, NI_GL * (lane & (NI_GA - 1)), 64);     // count of atom (lane & 3), for lanes 0..3
@@ -716,15 +744,23 @@ __global__ __launch_bounds__(256, NL > 0 ? NI_WAVES_PER_SIMD : 3) void annp_ni_d
     if (p.ncount && lane < NI_GA && ii0 + lane < p.inum) p.ncount[ii0 + lane] = nmax > cap ? 0 : ncl;
     if (p.npair && nmax > cap && lane < NI_GA && ii0 + lane < p.inum) p.npair[ii0 + lane] = 0;
     if (nmax > cap) {
-        if (lane == 0) atomicMax(p.errflag, nmax);
+        if (lane == 0) {
+            bool queued = false;
+            if (!FIX && p.ovf_list) {
+                const int q = atomicAdd(p.ovf_count, 1);
+                queued = q < p.ovf_cap;
+                if (queued) p.ovf_list[q] = ii0;
+            }
+            if (!queued) atomicMax(p.errflag, nmax);
+        }
         for (int idx = lane; idx < NI_GA * ANNP_GPAD; idx += 64)
             if (ii0 + idx / ANNP_GPAD < p.inum) p.G[(size_t)ii0 * ANNP_GPAD + idx] = 0.0;
-        return;
+        continue;
     }
     wave_lds_sync();
     const int sbase = g * cap;
     // the survivors, for the force pass (which then need not filter the full list rows again)
-    for (int a = l; a < nl; a += NI_GL) p.nbr[(size_t)(ii0 + g) * p.nbr_stride + a] = L.j[sbase + a];
+    for (int a = l; a < nl; a += NI_GL) p.nbr[(size_t)(row0 + g) * p.nbr_stride + a] = L.j[sbase + a];
 
     double gr[NP], ga[NT];
 #pragma unroll
@@ -775,7 +811,7 @@ __global__ __launch_bounds__(256, NL > 0 ? NI_WAVES_PER_SIMD : 3) void annp_ni_d
         if (p.pairs) {          // the chunk's list, for the force pass (an atom has at most n (n - 1) / 2 <= pstride entries in all)
             int gq = g;         // (opaque: the row's address is formed here, once per chunk, not kept in registers across the visit)
             asm volatile("" : "+v"(gq));
-            unsigned short *gp = p.pairs + (size_t)(ii0 + gq) * p.pstride + poff;
+            unsigned short *gp = p.pairs + (size_t)(row0 + gq) * p.pstride + poff;
             for (int idx = l; idx < cnt; idx += NI_GL) gp[idx] = L.pl[gq * PLIST + idx];
             poff += cnt;
         }
@@ -812,6 +848,7 @@ __global__ __launch_bounds__(256, NL > 0 ? NI_WAVES_PER_SIMD : 3) void annp_ni_d
     }
     for (int idx = lane; idx < NI_GA * ANNP_GPAD; idx += 64)
         if (idx % ANNP_GPAD >= nsf && ii0 + idx / ANNP_GPAD < p.inum) p.G[(size_t)ii0 * ANNP_GPAD + idx] = 0.0;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -824,8 +861,10 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int run = uniform(xcd_block() * ANNP_WAVES_PER_BLOCK + wave);
-    if (run * NI_RUN * NI_GA >= p.inum) return;
+    const int run = uniform((p.fix ? (int)blockIdx.x : xcd_block()) * ANNP_WAVES_PER_BLOCK + wave);
+    if (!p.fix && run * NI_RUN * NI_GA >= p.inum) return;
+    const int nslots = p.fix ? min(*p.ovf_count, p.ovf_cap) : 0;   // fix-up launch: a small grid whose waves walk the queue
+    const int nwaves = (int)gridDim.x * ANNP_WAVES_PER_BLOCK;
     const int nsf = p.npsf + p.ntsf;
     const int cap = p.n_cap;
     const int cstride = ni_coef_stride(nsf);
@@ -851,8 +890,17 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
         atomicAdd(&p.f[3 * (size_t)j], fx); atomicAdd(&p.f[3 * (size_t)j + 1], fy); atomicAdd(&p.f[3 * (size_t)j + 2], fz);
     };
 #pragma unroll 1
-    for (int gk = 0; gk < NI_RUN; gk++) {
-    const int ii0 = uniform((run * NI_RUN + gk) * NI_GA);
+    for (int gk = 0;; gk++) {
+    int ii0, row0;
+    if (!p.fix) {
+        if (gk >= NI_RUN) break;
+        ii0 = row0 = uniform((run * NI_RUN + gk) * NI_GA);
+    } else {
+        const int slot = run + gk * nwaves;
+        if (slot >= nslots) break;
+        ii0 = uniform(p.ovf_list[slot]);
+        row0 = slot * NI_GA;
+    }
     if (ii0 >= p.inum) break;
     ni_forget_lds();            // nothing read from the LDS tables is carried from one group to the next in registers
     // The lane number is made opaque per group: otherwise every per-lane LDS address of the staging loops below (7 record
@@ -869,8 +917,14 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
         L.coef[gq * cstride + k] = v;
     }
     int nl, npg;
-    const int nmax = ni_stage_compact(p, ii0, L, T, lane_q, nl, npg);
-    if (nmax > cap) { if (lane_q == 0) atomicMax(p.errflag, nmax); wave_lds_sync(); continue; }
+    const int nmax = ni_stage_compact(p, ii0, row0, L, T, lane_q, nl, npg);
+    // more neighbours than these records hold: the group is in the queue (the descriptor pass's fix-up launch left its true
+    // counts) and the force pass's own fix-up launch takes it; without a queue it is an error
+    if (nmax > (p.fix ? cap : min(cap, p.skip_above))) {
+        if (lane_q == 0 && (p.fix || !p.ovf_list)) atomicMax(p.errflag, nmax);
+        wave_lds_sync();
+        continue;
+    }
     wave_lds_sync();
     const double *cr = L.coef + g * cstride;        // radial weights of this lane's atom
     const double *cw = cr + p.npsf;                 // angular, visit order
@@ -880,7 +934,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     const int trips = (nmax * (nmax - 1) / 2 + NI_GL - 1) / NI_GL;
     NiWalk walk = ni_walk_init(l, nl);
     constexpr int CH = ni_ch(true), PLIST = ni_plist(true);
-    const unsigned short *gpl = GPAIRS ? p.pairs + (size_t)(ii0 + g) * p.pstride : nullptr;
+    const unsigned short *gpl = GPAIRS ? p.pairs + (size_t)(row0 + g) * p.pstride : nullptr;
     int pv_next = (GPAIRS && l < npg) ? gpl[l] : 0;         // the entry of the coming trip is in flight while this one is visited
     for (int t0 = 0; t0 < (GPAIRS ? 1 : trips); t0 += CH) {
     int cnt;
@@ -1056,9 +1110,9 @@ inline int ni_launch_desc(const NiArgs &a, NiShape sh, hipStream_t s)
     if (a.npsf > NI_MAXP || a.ntsf > NI_MAXT) return -1;
     const int blocks = ni_blocks(a.inum);
     if (ni_is_shipped_shape(a, sh))
-        hipLaunchKernelGGL((annp_ni_desc<NI_SHIPPED>), dim3(blocks), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((annp_ni_desc<NI_SHIPPED, false>), dim3(blocks), dim3(256), lds, s, a);
     else
-        hipLaunchKernelGGL((annp_ni_desc<NI_GENERIC>), dim3(blocks), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((annp_ni_desc<NI_GENERIC, false>), dim3(blocks), dim3(256), lds, s, a);
     return 0;
 }
 
@@ -1070,6 +1124,29 @@ inline void ni_launch_force_t(const NiArgs &a, NiShape sh, hipStream_t s)
     const int blocks = (a.inum + per_block - 1) / per_block;
     if (ni_is_shipped_shape(a, sh)) hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, VIR, GP>), dim3(blocks), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((annp_ni_force<NI_GENERIC, VIR, GP>), dim3(blocks), dim3(256), lds, s, a);
+}
+
+// the fix-up launches: a fixed small grid whose waves walk the queue (empty in the steady state: they exit at once)
+constexpr int NI_FIX_BLOCKS = 64;
+inline void ni_launch_desc_fix(const NiArgs &a, NiShape sh, hipStream_t s)
+{
+    const size_t lds = ni_lds_block(a.n_cap, false, a.npsf + a.ntsf);
+    const int blocks = std::max(1, std::min(NI_FIX_BLOCKS, (a.ovf_cap + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK));
+    if (ni_is_shipped_shape(a, sh)) hipLaunchKernelGGL((annp_ni_desc<NI_SHIPPED, true>), dim3(blocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((annp_ni_desc<NI_GENERIC, true>), dim3(blocks), dim3(256), lds, s, a);
+}
+inline void ni_launch_force_fix(const NiArgs &a, NiShape sh, bool virial, hipStream_t s)
+{
+    const size_t lds = ni_lds_block(a.n_cap, true, a.npsf + a.ntsf, false);
+    const int blocks = std::max(1, std::min(NI_FIX_BLOCKS, (a.ovf_cap + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK));
+    const bool shipped = ni_is_shipped_shape(a, sh);
+    if (virial) {
+        if (shipped) hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, true, false>), dim3(blocks), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((annp_ni_force<NI_GENERIC, true, false>), dim3(blocks), dim3(256), lds, s, a);
+    } else {
+        if (shipped) hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, false, false>), dim3(blocks), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((annp_ni_force<NI_GENERIC, false, false>), dim3(blocks), dim3(256), lds, s, a);
+    }
 }
 
 // a.pairs != nullptr: the descriptor pass of this evaluation left the pair lists
@@ -1085,8 +1162,10 @@ inline hipError_t ni_set_lds_attributes()
     const int full = 160 * 1024;
     hipError_t e;
 #define NI_ATTR(...) if ((e = hipFuncSetAttribute((const void *)__VA_ARGS__, hipFuncAttributeMaxDynamicSharedMemorySize, full)) != hipSuccess) return e
-    NI_ATTR(annp_ni_desc<NI_SHIPPED>);
-    NI_ATTR(annp_ni_desc<NI_GENERIC>);
+    NI_ATTR(annp_ni_desc<NI_SHIPPED, false>);
+    NI_ATTR(annp_ni_desc<NI_GENERIC, false>);
+    NI_ATTR(annp_ni_desc<NI_SHIPPED, true>);
+    NI_ATTR(annp_ni_desc<NI_GENERIC, true>);
     NI_ATTR(annp_ni_force<NI_SHIPPED, true, true>);
     NI_ATTR(annp_ni_force<NI_SHIPPED, false, true>);
     NI_ATTR(annp_ni_force<NI_GENERIC, true, true>);

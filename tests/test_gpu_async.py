@@ -1,6 +1,7 @@
 """The evaluation never waits for the device in the steady state (include/annp_hip.h, annp_hip_compute_device):
-record capacities come from the previous evaluation, atoms that outgrow them take the fix-up launch (Chebyshev) or
-raise a capacity error that survives until the host looks (Behler, anna_adp).  Results must not depend on any of it."""
+record capacities come from the previous evaluation, atoms that outgrow them take the fix-up launches (Chebyshev force pass,
+both Behler passes) or raise a capacity error that survives until the host looks (anna_adp; anything no LDS record can hold).
+Results must not depend on any of it."""
 import ctypes as C
 
 import numpy as np
@@ -173,10 +174,12 @@ def test_anna_overflow_survives_a_second_enqueue():
         p.close()
 
 
-def test_ni_steady_state_overflow_is_reported_then_recovers(ni_pot):
-    """Behler kernels through the device entry: capacity learned from a normal fcc box, then a much denser one.
-    The overflowing evaluation is reported as -7 (next call or sync), the one after it is sized afresh and correct.
-    The host-pointer entry hides all of that (it re-runs the evaluation itself)."""
+def test_ni_groups_that_outgrow_their_records_take_the_fixup_launches(ni_pot):
+    """Behler kernels through the device entry: capacity learned from a normal fcc box (18 in-range neighbours), then a much
+    denser one (56).  Every group of four atoms outgrows its records; the descriptor pass queues them and the fix-up launches
+    of both passes (records for a whole list row) evaluate them in the same call: nothing is skipped, nothing has to be
+    re-issued, and the call after that runs with the adapted capacity.  An error is left only for what no LDS record can
+    hold: a list row longer than the caller declared."""
     import torch
     xa, boxa = fcc(5, 5, 5, A_NI)
     sa = System(perturb(xa, 8, 0.04), boxa, rc_list=5.0)
@@ -185,24 +188,60 @@ def test_ni_steady_state_overflow_is_reported_then_recovers(ni_pot):
     ob = oracle_compute(ni_pot, sb, KIND_NI_FIXED, FAST)
     p = make_pair(NI_POT, "Ni")
     try:
-        run(p, sa)                                    # primes the capacity (~24)
+        run(p, sa)                                    # primes the capacity (~20)
         p.eatom[:] = 0.0
-        r = run(p, sb)                                # host entry: transparent re-run
+        r = run(p, sb)                                # host entry
         assert np.abs(r["f"] - ob["f"]).max() < 1e-5 * max(1.0, np.abs(ob["f"]).max())
         p.eatom[:] = 0.0
         run(p, sa)
-        run(p, sa)                                    # capacity back to ~24
+        run(p, sa)                                    # capacity back to ~20
+        assert eval_info(p)[1] == 0 and eval_info(p)[2] <= 24
         lib, dev, x, num, first, neigh = _device_handles(p, sb)
         f = torch.zeros_like(x)
+        ea = torch.zeros(sb.nall, dtype=torch.float64, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream
         args = (p.handle, sb.nlocal, sb.nall, x.data_ptr(), None, None, num.data_ptr(), first.data_ptr(), neigh.data_ptr(),
-                int(sb.numneigh.max()), f.data_ptr(), None, None, None, None, st)
-        assert lib.annp_hip_compute_device(*args) == 0
-        assert lib.annp_hip_sync(p.handle) == -7
-        f.zero_()
-        assert lib.annp_hip_compute_device(*args) == 0
-        assert lib.annp_hip_sync(p.handle) == 0
-        fo = sb.fold(f.cpu().numpy())
-        assert np.abs(fo - ob["f"]).max() < 1e-5 * max(1.0, np.abs(ob["f"]).max())
+                int(sb.numneigh.max()), f.data_ptr(), ea.data_ptr(), None, None, None, st)
+        for call in range(2):
+            f.zero_(); ea.zero_()
+            assert lib.annp_hip_compute_device(*args) == 0
+            assert lib.annp_hip_sync(p.handle) == 0
+            mx, nfix, cap, cap_next = eval_info(p)
+            assert mx > 40 and cap_next >= mx
+            assert (nfix == (sb.nlocal + 3) // 4 and cap <= 24) if call == 0 else (nfix == 0 and cap >= mx)
+            fo = sb.fold(f.cpu().numpy())
+            assert np.abs(fo - ob["f"]).max() < 1e-8 * max(1.0, np.abs(ob["f"]).max())
+            assert np.abs(ea.cpu().numpy()[: sb.nlocal] - ob["eatom"]).max() < 1e-6
+        # a mixed case: the normal box with a compressed core -- only some groups are queued
+        xc = perturb(xa, 8, 0.04)
+        centre = boxa[3:] / 2
+        core = np.linalg.norm(xc - centre, axis=1) < 4.0
+        xc[core] = centre + (xc[core] - centre) * 0.8
+        sc = System(xc, boxa, rc_list=5.0)
+        oc = oracle_compute(ni_pot, sc, KIND_NI_FIXED, FAST)
+        run(p, sa)
+        run(p, sa)
+        lib, dev, x, num, first, neigh = _device_handles(p, sc)
+        f = torch.zeros_like(x)
+        args = (p.handle, sc.nlocal, sc.nall, x.data_ptr(), None, None, num.data_ptr(), first.data_ptr(), neigh.data_ptr(),
+                int(sc.numneigh.max()), f.data_ptr(), None, None, None, None, st)
+        assert lib.annp_hip_compute_device(*args) == 0 and lib.annp_hip_sync(p.handle) == 0
+        nfix = eval_info(p)[1]
+        assert 0 < nfix < sc.nlocal // 8
+        assert np.abs(sc.fold(f.cpu().numpy()) - oc["f"]).max() < 1e-8 * max(1.0, np.abs(oc["f"]).max())
+        # more in-range neighbours than any LDS record can hold (fcc at a = 2.0 A: ~125): that is an error, reported by the
+        # next look at the handle; the normal box evaluates again afterwards
+        xd, boxd = fcc(6, 6, 6, 2.0)
+        sd = System(perturb(xd, 8, 0.02), boxd, rc_list=4.5)
+        lib, dev, x, num, first, neigh = _device_handles(p, sd)
+        fd = torch.zeros_like(x)
+        dense = (p.handle, sd.nlocal, sd.nall, x.data_ptr(), None, None, num.data_ptr(), first.data_ptr(), neigh.data_ptr(),
+                 int(sd.numneigh.max()), fd.data_ptr(), None, None, None, None, st)
+        rc1 = lib.annp_hip_compute_device(*dense)
+        rc2 = lib.annp_hip_sync(p.handle)
+        assert -7 in (rc1, rc2) and b"LDS" in lib.annp_hip_last_error(p.handle)
+        p.eatom[:] = 0.0
+        r = run(p, sc)
+        assert np.abs(r["f"] - oc["f"]).max() < 1e-8 * max(1.0, np.abs(oc["f"]).max())
     finally:
         p.close()

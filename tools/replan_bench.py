@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Developer tool: what a reneighbouring step costs beyond a plain step, piece by piece (one rank, host clock around
+torch.cuda.synchronize): SlabDomain.replan() = Comm::exchange + Comm::borders, the device list build, the evaluation.
+   python tools/replan_bench.py 40      # 128 000 atoms"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+    from annp_testlib import A_FE, FE_POT, bcc, perturb
+    from meng_zhang_amd import PairANNP
+    from meng_zhang_amd.domain import SlabDomain
+    from meng_zhang_amd.lib import load_library
+    cells = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    lib = load_library()
+    dev = torch.device("cuda", 0)
+    x0, box = bcc(cells, cells, cells, A_FE)
+    xg = perturb(x0, 12345, 0.05)
+    pair = PairANNP(1, device=0)
+    pair.settings([])
+    pair.coeff(["*", "*", FE_POT, "Fe"])
+    pair.init_style()
+    h = pair.handle
+    dom = SlabDomain.from_global(xg, box, (1, 1, 1), 8.5, dev, extra={"v": np.zeros_like(xg)}, hip=(lib, h))
+    st = torch.cuda.current_stream(dev).cuda_stream
+    pn, pf, pg, mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    eng = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    def timed(fn, reps=5):
+        out = []
+        for _ in range(reps):
+            sync()
+            t = time.perf_counter()
+            fn()
+            sync()
+            out.append((time.perf_counter() - t) * 1e3)
+        return min(out), sorted(out)[len(out) // 2]
+
+    def build():
+        assert lib.annp_hip_neigh_build_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), 8.5, C.byref(pn), C.byref(pf), C.byref(pg), C.byref(mx), st) == 0
+
+    def evaluate():
+        assert lib.annp_hip_compute_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value, dom.f.data_ptr(), None,
+                                           eng.data_ptr(), None, None, st) == 0
+    build()
+    evaluate()
+    print("atoms %d ghosts %d" % (dom.nlocal, dom.nghost))
+    for name, fn in (("replan (exchange + borders)", dom.replan), ("  of which exchange", dom._exchange), ("list build", build), ("evaluation", evaluate),
+                     ("forward + reverse", lambda: (dom.forward(clear_forces=True, eng=eng), dom.reverse()))):
+        lo, med = timed(fn)
+        print("%-30s min %7.3f  median %7.3f ms" % (name, lo, med))
+    pair.close()
+
+
+if __name__ == "__main__":
+    main()
