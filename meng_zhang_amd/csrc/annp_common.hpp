@@ -156,6 +156,63 @@ __device__ __forceinline__ double exp_neg_tab(double x, const double *T)
     return __builtin_ldexp(p, (int)kf);
 }
 
+// ---- the same functions with the coefficients in scalar registers --------------------------------------------------
+// The LDS table above keeps the constants out of the vector registers, but every coefficient costs an LDS instruction (a
+// 64-lane broadcast read: 2 cycles of the CU's one LDS pipe), and in the Behler force pass those broadcasts were 75 % of all
+// LDS instructions of a pass that the LDS pipe bounds.  Here the coefficients come from constant memory through the
+// scalar unit (s_load_dwordx8/x16: eight doubles per instruction, served by the scalar cache) and enter the Horner steps
+// as the SGPR operand of v_fma_f64.  Two things the compiler does not do by itself: (1) it hoists such loads out of the
+// surrounding loops and then spills the scalar registers, so the table's address is made opaque where it is used (an empty
+// volatile asm on an "s" operand: still known to be uniform, no longer loop-invariant); (2) it turns fma(p, x, c) with c in
+// scalar registers into v_fmac_f64 on a vector copy of c -- two v_mov_b32 per coefficient -- so the step is written as the
+// VOP3 form it should have picked.
+typedef const double __attribute__((address_space(4))) *annp_cptr;
+
+__device__ __forceinline__ annp_cptr mtab_scalar()
+{
+    unsigned long long v = (unsigned long long)(const void *)annp_mtab;
+    asm volatile("" : "+s"(v));
+    return (annp_cptr)v;
+}
+
+// a * b + c with c in scalar registers
+__device__ __forceinline__ double fma_vvs(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
+__device__ __forceinline__ void sincos_0_pi_s(double t, double &sn, double &cs)
+{
+    const annp_cptr T = mtab_scalar();
+    const double h = t - T[21];
+    const double h2 = h * h;
+    double ps = T[0];
+#pragma unroll
+    for (int k = 1; k < 10; k++) ps = fma_vvs(ps, h2, T[k]);
+    double pc = T[10];
+#pragma unroll
+    for (int k = 11; k < 21; k++) pc = fma_vvs(pc, h2, T[k]);
+    sn = fma(-h2, pc, 1.0);                 // cos h
+    cs = -fma(-(h * h2), ps, h);            // -sin h
+}
+
+__device__ __forceinline__ double exp_neg_s(double x)
+{
+    const annp_cptr T = mtab_scalar();
+    const double kf = rint(x * T[22]);
+    double r = fma(-kf, T[23], x);
+    r = fma(-kf, T[24], r);
+    double p = T[25];
+#pragma unroll
+    for (int k = 26; k < ANNP_MTAB; k++) p = fma_vvs(p, r, T[k]);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)kf);
+}
+
 // fast_rsqrt written so that its only constant (0.5) is an inline operand
 __device__ __forceinline__ double fast_rsqrt_ic(double x)
 {

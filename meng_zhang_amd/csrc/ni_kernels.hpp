@@ -187,11 +187,11 @@ __device__ __forceinline__ void ni_visit_functions(const NiTab &t, int ntsf, dou
 {
     // exp(-eta r2sum) for the distinct etas: one exp, powers of it where eta_e is a multiple of eta_0
     double E[NI_MAXE];
-    E[0] = exp_neg_tab(-t.etas[0] * r2sum, t.T);
+    E[0] = exp_neg_s(-t.etas[0] * r2sum);
 #pragma unroll
     for (int e = 1; e < NI_MAXE; e++) {
         E[e] = 0.0;
-        if (e < t.ne) E[e] = (t.emult[e] > 0) ? ni_powi(E[0], t.emult[e]) : exp_neg_tab(-t.etas[e] * r2sum, t.T);
+        if (e < t.ne) E[e] = (t.emult[e] > 0) ? ni_powi(E[0], t.emult[e]) : exp_neg_s(-t.etas[e] * r2sum);
     }
     double lam_prev = 0.0, U0 = 0.0;
     double U[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -274,7 +274,7 @@ __device__ __forceinline__ NiConst ni_tables_fill(double *lds, const NiArgs &p, 
 template <int NE, unsigned EM>
 __device__ __forceinline__ void ni_exps(const NiConst &c, double r2sum, double (&E)[NE])
 {
-    E[0] = exp_neg_tab(-c.K[NI_KE] * r2sum, c.T);
+    E[0] = exp_neg_s(-c.K[NI_KE] * r2sum);
 #pragma unroll
     for (int e = 1; e < NE; e++) E[e] = ni_powi(E[0], NI_BYTE(EM, e));
 }
@@ -560,7 +560,7 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
             double fc = 0.0, dfc = 0.0;
             if (rm < p.rc_ang) {
                 double sn, cs;
-                sincos_0_pi_tab(pi_over_rc * rm, T, sn, cs);
+                sincos_0_pi_s(pi_over_rc * rm, sn, cs);
                 fc = 0.5 * (cs + 1.0);
                 dfc = -0.5 * pi_over_rc * sn;
             }
@@ -615,7 +615,7 @@ __device__ __forceinline__ int ni_stage_compact(const NiArgs &p, int ii0, int ro
             double fc = 0.0, dfc = 0.0;
             if (rm < p.rc_ang) {
                 double sn, cs;
-                sincos_0_pi_tab(pi_over_rc * rm, T, sn, cs);
+                sincos_0_pi_s(pi_over_rc * rm, sn, cs);
                 fc = 0.5 * (cs + 1.0);
                 dfc = -0.5 * pi_over_rc * sn;
             }
@@ -657,7 +657,7 @@ __device__ __forceinline__ NiPairS ni_pair(const NiLds &L, const NiConst &c, int
     if (q.ok) {
         double sn, cs;
         const double por = c.K[NI_KM];
-        sincos_0_pi_tab(por * q.rgm, c.T, sn, cs);
+        sincos_0_pi_s(por * q.rgm, sn, cs);
         q.fcjk = 0.5 * (cs + 1.0);
         q.dfcjk = -0.5 * por * sn;
         q.tfc = L.fc[sa] * L.fc[sb] * q.fcjk;
@@ -772,15 +772,15 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
         const double rm = (a < nl ? L.r[sbase + a] : 1e30) * ANNP_CFLENGTH;
         if (rm < p.rc_rad) {
             double sn, cs;
-            sincos_0_pi_tab(ANNP_MY_PI / p.rc_rad * rm, T, sn, cs);
+            sincos_0_pi_s(ANNP_MY_PI / p.rc_rad * rm, sn, cs);
             const double fc = 0.5 * (cs + 1.0);
-            const double e0 = exp_neg_tab(-srad[0] * rm * rm, T);
+            const double e0 = exp_neg_s(-srad[0] * rm * rm);
 #pragma unroll
             for (int m = 0; m < NP; m++)
                 if (m < p.npsf) {
                     // (the compiled-in shape has its radial etas in the ratios EM too: ni_is_shipped_shape)
                     const int km = NL > 0 ? NI_BYTE(EM, m & 3) : (int)((p.rad_em >> (8 * m)) & 255ull);
-                    gr[m] += (km > 0 ? ni_powi(e0, km) : exp_neg_tab(-srad[3 * m] * rm * rm, T)) * fc;
+                    gr[m] += (km > 0 ? ni_powi(e0, km) : exp_neg_s(-srad[3 * m] * rm * rm)) * fc;
                 }
         }
     }
@@ -1002,16 +1002,16 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
             if (rm < p.rc_rad) {                                     // ni:693-709
                 double sn, cs;
                 const double por = ANNP_MY_PI / p.rc_rad;
-                sincos_0_pi_tab(por * rm, T, sn, cs);
+                sincos_0_pi_s(por * rm, sn, cs);
                 const double fc = 0.5 * (cs + 1.0), dfc = -0.5 * por * sn;
                 double R = 0.0;
-                const double e0 = exp_neg_tab(-srad[0] * rm * rm, T);
+                const double e0 = exp_neg_s(-srad[0] * rm * rm);
 #pragma unroll
                 for (int m = 0; m < NP; m++)
                     if (m < p.npsf) {
                         const double eta = srad[3 * m];
                         const int km = NL > 0 ? NI_BYTE(EM, m & 3) : (int)((p.rad_em >> (8 * m)) & 255ull);
-                        const double em = km > 0 ? ni_powi(e0, km) : exp_neg_tab(-eta * rm * rm, T);
+                        const double em = km > 0 ? ni_powi(e0, km) : exp_neg_s(-eta * rm * rm);
                         R = fma(cr[m], em * (-fc * 2.0 * eta * rm + dfc), R);
                     }
                 const double sc = -R * L.rinv[s];                     // dr_dj = -xij/rij
