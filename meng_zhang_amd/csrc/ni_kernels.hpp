@@ -17,6 +17,16 @@
 // 10 trips, 96 % of the lane slots used; round-robin enumeration, see NiWalk), per-lane partial sums are private to the
 // atom, and the closing reductions are over 16 lanes.
 // Roles follow list order (j before k) because compat mode is not symmetric in j,k.
+//
+// Round 3, what travels between the passes and what stands behind them:
+//   * the descriptor pass leaves, per atom, the indices of its in-range neighbours (nbr) AND its in-range (j,k) pairs
+//     (pairs: record slots a | b << 8); the force pass rebuilds its records from the former and reads the latter instead
+//     of running its own distance pre-pass over all n (n - 1) / 2 candidates;
+//   * a group of four atoms whose records do not fit n_cap is appended to a device queue by the descriptor pass and
+//     evaluated by a second small launch of each pass (fix = 1: waves walk the queue, records for a whole list row), so an
+//     evaluation is complete whatever happened to the configuration since the capacity was learned;
+//   * the sincos / exp polynomial coefficients come from constant memory through the scalar unit (annp_common.hpp:
+//     sincos_0_pi_s, exp_neg_s); the LDS table only holds the constants that depend on the potential (K).
 #pragma once
 #include "annp_common.hpp"
 
