@@ -49,7 +49,10 @@ __host__ __device__ constexpr int ni_plist(bool force) { return ni_ch(force) * 1
 // Force pass: a wave takes NI_RUN consecutive groups of four atoms (16 atoms: four fcc cells of a row reference 304 atoms,
 // ~80 of them distinct) and sends their force contributions through a wave-private table keyed by atom index, flushed
 // with one global atomic per distinct atom and component at the end of the run (same scheme as annp_anna_adp).
-constexpr int NI_RUN = 4;
+#ifndef NI_RUN_GROUPS
+#define NI_RUN_GROUPS 4
+#endif
+constexpr int NI_RUN = NI_RUN_GROUPS;
 constexpr int NI_TSLOTS = 128;
 constexpr int NI_TPROBE = 8;
 #ifndef NI_WAVES_PER_SIMD

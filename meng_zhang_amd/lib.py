@@ -23,7 +23,8 @@ PAIR_SYMBOLS = [
 
 
 def library_path():
-    return os.path.join(_HERE, "libannp_hip.so")
+    # ANNP_HIP_LIBRARY: another build of the same library (developer A/B runs of kernel variants); never a different implementation
+    return os.environ.get("ANNP_HIP_LIBRARY") or os.path.join(_HERE, "libannp_hip.so")
 
 
 def load_library():
