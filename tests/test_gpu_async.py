@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from annp_testlib import (A_FE, A_NI, ANNA_POT, FAST, FE_POT, KIND_FE, KIND_NI_FIXED, NI_POT, System, bcc, fcc,
-                          oracle_compute, perturb)
+                          oracle_compute, oracle_vatom, perturb)
 from test_gpu_parity import make_pair, run
 
 pytestmark = pytest.mark.gpu
@@ -199,11 +199,14 @@ def test_ni_groups_that_outgrow_their_records_take_the_fixup_launches(ni_pot):
         lib, dev, x, num, first, neigh = _device_handles(p, sb)
         f = torch.zeros_like(x)
         ea = torch.zeros(sb.nall, dtype=torch.float64, device=dev)
+        va = torch.zeros((sb.nall, 6), dtype=torch.float64, device=dev)
+        vir = torch.zeros(6, dtype=torch.float64, device=dev)
+        vb = oracle_vatom(ni_pot, sb, KIND_NI_FIXED)
         st = torch.cuda.current_stream(dev).cuda_stream
         args = (p.handle, sb.nlocal, sb.nall, x.data_ptr(), None, None, num.data_ptr(), first.data_ptr(), neigh.data_ptr(),
-                int(sb.numneigh.max()), f.data_ptr(), ea.data_ptr(), None, None, None, st)
+                int(sb.numneigh.max()), f.data_ptr(), ea.data_ptr(), None, vir.data_ptr(), va.data_ptr(), st)
         for call in range(2):
-            f.zero_(); ea.zero_()
+            f.zero_(); ea.zero_(); va.zero_(); vir.zero_()
             assert lib.annp_hip_compute_device(*args) == 0
             assert lib.annp_hip_sync(p.handle) == 0
             mx, nfix, cap, cap_next = eval_info(p)
@@ -212,6 +215,8 @@ def test_ni_groups_that_outgrow_their_records_take_the_fixup_launches(ni_pot):
             fo = sb.fold(f.cpu().numpy())
             assert np.abs(fo - ob["f"]).max() < 1e-8 * max(1.0, np.abs(ob["f"]).max())
             assert np.abs(ea.cpu().numpy()[: sb.nlocal] - ob["eatom"]).max() < 1e-6
+            assert np.abs(va.cpu().numpy() - vb).max() < 1e-8 * max(1.0, np.abs(vb).max())       # the fix-up launches tally the virial too
+            assert np.abs(vir.cpu().numpy() - vb.sum(0)).max() < 1e-8 * max(1.0, np.abs(vb.sum(0)).max())
         # a mixed case: the normal box with a compressed core -- only some groups are queued
         xc = perturb(xa, 8, 0.04)
         centre = boxa[3:] / 2
