@@ -584,20 +584,39 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
     return nmax;
 }
 
-// Force pass: rebuild the records from the compact lists the descriptor pass left (same entries, same order).
-__device__ __forceinline__ int ni_stage_compact(const NiArgs &p, int ii0, int row0, const NiLds &L, const double *T, int lane, int &nl, int &npairs)
+// What the force pass needs from memory before it can stage a group, requested ahead: the group's headers (lanes 0..3) and the
+// first two entries of this lane's neighbour row.  A wave handles NI_RUN groups one after the other, and each used to start
+// with three dependent memory round trips (header -> list row -> positions) with nothing of its own to overlap them; the
+// next group's first two are now in flight behind the current group's pair loop.
+// (Five registers, which is what the pass has left: the centre's position is fetched with the neighbours' at staging time --
+// its index is known by then, so that is the same round trip, not another one.)
+struct NiAhead { int hi, hn, hp, j0, j1; };
+__device__ __forceinline__ void ni_request(const NiArgs &p, int ii0, int row0, int lane, NiAhead &q)
 {
-    const int cap = p.n_cap;
-    int hi = -1, hn = 0, hp = 0;
-    double hx = 0.0, hy = 0.0, hz = 0.0;
+    q.hi = -1; q.hn = 0; q.hp = 0;
     if (lane < NI_GA) {
         const int ii = ii0 + lane;
         if (ii < p.inum) {
-            hi = p.ilist ? p.ilist[ii] : ii;
-            hn = p.ncount[ii];
-            if (p.npair) hp = p.npair[ii];
-            hx = p.x[3 * (size_t)hi]; hy = p.x[3 * (size_t)hi + 1]; hz = p.x[3 * (size_t)hi + 2];
+            q.hi = p.ilist ? p.ilist[ii] : ii;
+            q.hn = p.ncount[ii];
+            if (p.npair) q.hp = p.npair[ii];
         }
+    }
+    const int g = lane >> 4, l = lane & 15;
+    const int *row = p.nbr + (size_t)(row0 + g) * p.nbr_stride;
+    const bool there = ii0 + g < p.inum;        // (entries beyond the atom's count are whatever the row holds: never used)
+    q.j0 = (there && l < p.nbr_stride) ? row[l] : 0;
+    q.j1 = (there && l + NI_GL < p.nbr_stride) ? row[l + NI_GL] : 0;
+}
+
+// Force pass: rebuild the records from the compact lists the descriptor pass left (same entries, same order).
+__device__ __forceinline__ int ni_stage_compact(const NiArgs &p, const NiAhead &q, int row0, const NiLds &L, const double *T, int lane, int &nl, int &npairs)
+{
+    const int cap = p.n_cap;
+    const int hi = q.hi, hn = q.hn, hp = q.hp;
+    double hx = 0.0, hy = 0.0, hz = 0.0;
+    if (lane < NI_GA) {
+        if (hi >= 0) { hx = p.x[3 * (size_t)hi]; hy = p.x[3 * (size_t)hi + 1]; hz = p.x[3 * (size_t)hi + 2]; }
         L.ci[lane] = hi;
     }
     const int g = lane >> 4, l = lane & 15;
@@ -619,7 +638,7 @@ __device__ __forceinline__ int ni_stage_compact(const NiArgs &p, int ii0, int ro
     for (int a = l; a < nmax; a += NI_GL) {
         if (a < nl) {
             const int s = g * cap + a;
-            const int j = row[a];
+            const int j = a == l ? q.j0 : (a == l + NI_GL ? q.j1 : row[a]);
             const double dx = xi - p.x[3 * (size_t)j], dy = yi - p.x[3 * (size_t)j + 1], dz = zi - p.x[3 * (size_t)j + 2];
             const double rsq = dx * dx + dy * dy + dz * dz;
             const double rinv = fast_rsqrt_ic(rsq);
@@ -902,6 +921,8 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
         }
         atomicAdd(&p.f[3 * (size_t)j], fx); atomicAdd(&p.f[3 * (size_t)j + 1], fy); atomicAdd(&p.f[3 * (size_t)j + 2], fz);
     };
+    NiAhead ahead;
+    bool requested = false;     // `ahead` holds the coming group (main launch, from the second group of the run on)
 #pragma unroll 1
     for (int gk = 0;; gk++) {
     int ii0, row0;
@@ -930,7 +951,12 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
         L.coef[gq * cstride + k] = v;
     }
     int nl, npg;
-    const int nmax = ni_stage_compact(p, ii0, row0, L, T, lane_q, nl, npg);
+    if (!requested) ni_request(p, ii0, row0, lane_q, ahead);
+    const int nmax = ni_stage_compact(p, ahead, row0, L, T, lane_q, nl, npg);
+    // (only in the instantiation that reads its pairs from memory: the one with its own pre-pass has no register to spare, and it
+    // is the fall-back and the fix-up kernel, not the steady state)
+    requested = GPAIRS && !p.fix && gk + 1 < NI_RUN && ii0 + NI_GA < p.inum;
+    if (requested) ni_request(p, ii0 + NI_GA, ii0 + NI_GA, lane_q, ahead);       // consumed by the next trip of this loop
     // more neighbours than these records hold: the group is in the queue (the descriptor pass's fix-up launch left its true
     // counts) and the force pass's own fix-up launch takes it; without a queue it is an error
     if (nmax > (p.fix ? cap : min(cap, p.skip_above))) {
