@@ -147,13 +147,28 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
     double e_wave = 0.0;
     wave_lds_sync();
     const int nruns = (p.inum + ANNA_RUN - 1) / ANNA_RUN;
+    // What an atom needs from memory before any of its arithmetic can start -- its header (index, row length, row start), its
+    // descriptor value for the network and the first 192 entries of its list row -- is requested while the atom before it in
+    // the run is worked on: an atom used to begin with four dependent memory round trips (header -> row -> positions, then G)
+    // that only the two other waves of the SIMD could cover.  `ahead` says whether a_* hold the atom that is starting.
+    bool ahead = false;
+    int a_i = 0, a_jn = 0, a_j0 = 0, a_j1 = 0, a_j2 = 0;
+    long long a_first = 0;
+    double a_g = 0.0;
     for (int run = uniform(blockIdx.x * ANNP_WAVES_PER_BLOCK + wave); run < nruns; run += gridDim.x * ANNP_WAVES_PER_BLOCK) {
+    ahead = false;
     for (int ii = run * ANNA_RUN; ii < min(p.inum, (run + 1) * ANNA_RUN); ii++) {
     double *hbuf = hbuf0;
-    const int i = p.ilist ? p.ilist[ii] : ii;
+    int i, jn;
+    long long rfirst;
+    if (ahead) { i = a_i; jn = a_jn; rfirst = a_first; }
+    else { i = p.ilist ? p.ilist[ii] : ii; jn = p.numneigh[i]; rfirst = p.first[i]; }
+    i = uniform(i); jn = uniform(jn);
     const double xi = p.x[3 * (size_t)i], yi = p.x[3 * (size_t)i + 1], zi = p.x[3 * (size_t)i + 2];
-    const int *row = p.neigh + p.first[i];
-    const int jn = p.numneigh[i];
+    const int *row = p.neigh + rfirst;
+    const bool have_row = ahead;            // a_j0..2 hold row[lane], row[64 + lane], row[128 + lane]
+    const double g_in = ahead ? a_g : ((lane < p.nin) ? p.G[(size_t)ii * ANNP_GPAD + lane] : 0.0);
+    const int pj0 = a_j0, pj1 = a_j1, pj2 = a_j2;
     const unsigned long long lt = (1ull << lane) - 1ull;
 
     // ---- in-range neighbours (adp:171-173: r > Rc or r < 1e-12 skipped), compacted in list order
@@ -165,7 +180,10 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
         for (int u = 0; u < 4; u++) {
             const int jj = c0 + 64 * u + lane;
             valid[u] = jj < jn;
-            j[u] = valid[u] ? (row[jj] & ANNP_NEIGHMASK) : 0;
+            int raw;
+            if (have_row && c0 == 0 && u < 3) raw = u == 0 ? pj0 : (u == 1 ? pj1 : pj2);
+            else raw = valid[u] ? row[jj] : 0;
+            j[u] = valid[u] ? (raw & ANNP_NEIGHMASK) : 0;
         }
         double dx[4], dy[4], dz[4];
 #pragma unroll
@@ -183,7 +201,15 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
         }
     }
     n = uniform(n);
-    if (n > cap) { if (lane == 0) atomicMax(p.errflag, n); continue; }
+    // the next atom of the run: header and descriptor value now, its row a little later (when the header has arrived)
+    ahead = ii + 1 < min(p.inum, (run + 1) * ANNA_RUN);
+    if (ahead) {
+        a_i = p.ilist ? p.ilist[ii + 1] : ii + 1;
+        a_jn = p.numneigh[a_i];
+        a_first = p.first[a_i];
+        a_g = (lane < p.nin) ? p.G[(size_t)(ii + 1) * ANNP_GPAD + lane] : 0.0;
+    }
+    if (n > cap) { if (lane == 0) atomicMax(p.errflag, n); ahead = false; continue; }
 
     // ---- the network (adp:633-667).  A row's dot product is split over P = 2^k lanes (as many as fit 64 / rows)
     //      and folded with xor-shuffles: a 28-term sum is then 4 FMAs + 3 shuffles deep instead of 28 dependent
@@ -191,7 +217,7 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
     //      reference's left-to-right sum by rounding only.
     {
         double *hin = hbuf, *hout = hbuf + 64;
-        if (lane < p.nin) hin[lane] = p.G[(size_t)ii * ANNP_GPAD + lane];
+        if (lane < p.nin) hin[lane] = g_in;
         wave_lds_sync();
         const double *w = p.net_in_lds ? Lnet : p.net;
         for (int l = 0; l < p.nl; l++) {
@@ -214,6 +240,12 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
         hbuf = hin;      // the outputs
     }
     const double d2 = hbuf[0], q2 = hbuf[1];                   // adp:162
+    if (ahead) {
+        const int *rown = p.neigh + a_first;
+        a_j0 = (lane < a_jn) ? rown[lane] : 0;
+        a_j1 = (64 + lane < a_jn) ? rown[64 + lane] : 0;
+        a_j2 = (128 + lane < a_jn) ? rown[128 + lane] : 0;
+    }
 
     const double A0 = p.gp[0], yy = p.gp[1], gamma = p.gp[2], C0 = p.gp[3], c1F = p.gp[4], c2F = p.gp[5], V0 = p.gp[6];
     const double b1 = p.gp[7], b2 = p.gp[8], delta = p.gp[9], r0 = p.gp[10], r1 = p.gp[11], hc = p.gp[12];
