@@ -223,11 +223,31 @@ __device__ __forceinline__ double fast_rsqrt_ic(double x)
     return y;
 }
 
+// Sum over the 64 lanes of a wave (all of them active), returned to every lane.  Data-parallel-primitive moves instead of
+// __shfl_xor (which is ds_bpermute on this target: an LDS round trip per level, 12 per double): four row_shr steps leave each
+// row of 16 lanes' total in its last lane, row_bcast:15 and row_bcast:31 carry them to lane 63, v_readlane hands the result
+// out through scalar registers.  The moves are 32-bit: a double goes as two halves.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_from(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffull), CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);      // lanes without a source read 0.0
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_from<0x111, 0xf>(v);       // row_shr:1
+    v += dpp_from<0x112, 0xf>(v);       // row_shr:2
+    v += dpp_from<0x114, 0xf>(v);       // row_shr:4
+    v += dpp_from<0x118, 0xf>(v);       // row_shr:8   -> lane 15 of each row holds the row's sum
+    v += dpp_from<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_from<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 }  // namespace annp
