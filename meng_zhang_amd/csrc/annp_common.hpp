@@ -236,6 +236,16 @@ __device__ __forceinline__ double dpp_from(double v)
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);      // lanes without a source read 0.0
 }
 
+// sum over each row of 16 lanes, left in the row's last lane (lanes 15, 31, 47, 63); the other lanes hold partial sums
+__device__ __forceinline__ double row16_sum_to_last(double v)
+{
+    v += dpp_from<0x111, 0xf>(v);
+    v += dpp_from<0x112, 0xf>(v);
+    v += dpp_from<0x114, 0xf>(v);
+    v += dpp_from<0x118, 0xf>(v);
+    return v;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
     v += dpp_from<0x111, 0xf>(v);       // row_shr:1

@@ -1072,11 +1072,9 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     }
     // group sums (16 lanes) -> the centre atom
     const int i = L.ci[g];
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
-        fi0 += __shfl_xor(fi0, off, 64); fi1 += __shfl_xor(fi1, off, 64); fi2 += __shfl_xor(fi2, off, 64);
-    }
-    if (l == 0 && i >= 0) table_add(i, fi0 * ANNP_CFFORCE, fi1 * ANNP_CFFORCE, fi2 * ANNP_CFFORCE);
+    // (a group is a DPP row: four row shifts leave its sum in its last lane, no LDS traffic)
+    fi0 = row16_sum_to_last(fi0); fi1 = row16_sum_to_last(fi1); fi2 = row16_sum_to_last(fi2);
+    if (l == NI_GL - 1 && i >= 0) table_add(i, fi0 * ANNP_CFFORCE, fi1 * ANNP_CFFORCE, fi2 * ANNP_CFFORCE);
     if (VIRIAL) {
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
