@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define ANNP_HIP_ABI_VERSION 4
+#define ANNP_HIP_ABI_VERSION 5
 
 #define ANNP_HIP_OK 0
 #define ANNP_HIP_EARG (-1)
@@ -258,6 +258,12 @@ int annp_hip_timing_stats(annp_hip_handle *handle, double *ms4_mean, int *nsampl
 /* In-cutoff neighbour counts of the last evaluation (one int per list entry ii),
  * copied to the host: the n that SURVEY.md 8d's flop formula is evaluated with. */
 int annp_hip_last_counts(annp_hip_handle *handle, int *counts, int inum);
+
+/* Descriptor rows of the last evaluation as the descriptor pass left them, 32 doubles per list entry ii, copied to the host.
+ * Chebyshev (pair_style annp Fe, anna_adp): the raw sums of fe_v2/src/pair_annp.cpp:633-695 before normalisation, radial
+ * in [0,9), angular T_0..T_18 in [9,28); Behler: the G2/G4 sums.  A diagnostic: the parity tests compare two descriptor kernels
+ * through it. */
+int annp_hip_last_descriptors(annp_hip_handle *handle, double *rows, int inum);
 
 /* Replaces annp_gpu_clear: frees everything; the handle is invalid afterwards. NULL ok. */
 void annp_hip_clear(annp_hip_handle *handle);

@@ -42,6 +42,15 @@ __device__ __forceinline__ int xcd_block()
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// a double of lane `srclane` (uniform), through scalar registers
+__device__ __forceinline__ double readlane_f64(double v, int srclane)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), srclane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), srclane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // Is LAMMPS type t mapped to an element?  `active` has bit t set for the mapped types 1..ntypes (<= 30).  A type outside that
 // range (a caller's mistake the device-resident entry points cannot check on the host) reads as "not mapped": the atom is
 // dropped, nothing is indexed with it.

@@ -28,7 +28,7 @@
 
 #include "../../include/annp_hip.h"
 #include "annp_common.hpp"
-#include "fe_kernels.hpp"
+#include "fe_sh_kernels.hpp"
 #include "mlp_kernels.hpp"
 #include "neigh_kernels.hpp"
 #include "ni_kernels.hpp"
@@ -121,6 +121,9 @@ struct annp_hip_handle {
     bool ni_primed = false;             // ... has been sized from a completed evaluation (else the next one sizes it synchronously)
     int fe_cap = 0;                     // Chebyshev force pass: record capacity for the next evaluation (0 = not sized yet)
     int cap_last = 0;                   // capacity the last force pass ran with
+    int sh_cap = SH_CAP_MAX;            // Chebyshev descriptor pass (annp_fe_desc_sh): state slots per atom for the next evaluation
+    bool fe_desc_pairs = false;         // ANNP_HIP_FE_DESC=pairs: the pair-loop descriptor kernel (annp_fe_desc) for every atom
+    int sh_wpb = 0;                     // waves per workgroup of annp_fe_desc_sh (ANNP_HIP_SH_WPB; 0 = chosen per launch)
     int flagact[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // up to max(MLP_MAXL, ANNA_MAXL) weight layers
     static_assert(MLP_MAXL <= 8 && ANNA_MAXL <= 8, "flagact holds 8 layers");
     double e_scale = 0, e_shift = 0, e_atom = 0, cut = 0, cutsq = 0;
@@ -138,12 +141,12 @@ struct annp_hip_handle {
     std::vector<double> sym_rad, sym_ang;
     // work buffers
     DevBuf<double> G, coef, x, f, eatom, vatom;
-    DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ni_npair, ni_fix_nbr, ovf;
+    DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ni_npair, ni_fix_nbr, ovf, ovf_desc;
     DevBuf<unsigned short> ni_pairs;    // Behler: in-range (j,k) pairs per atom, descriptor pass -> force pass
     DevBuf<long long> first;
     double *d_scalars = nullptr;        // [0] energy, [1..6] virial
     int *d_flags = nullptr;             // [0] capacity error: max n of the atoms that were skipped (stays set until the host has
-                                        //     seen it), [1] max in-cutoff n, [2] length of the fix-up queue; [1], [2] per evaluation
+                                        //     seen it), [1] max in-cutoff n, [2] length of the force fix-up queue, [3] of the descriptor fix-up queue; [1..3] per evaluation
     int *h_flags = nullptr;             // pinned mirror, copied back behind every evaluation
     hipEvent_t ev_flags = nullptr;      // ... that copy has landed
     int sticky_rc = 0;                  // error found in a landed copy, returned by the next call on the handle
@@ -313,6 +316,8 @@ int fe_next_cap(int mx)
     if (mx <= 128 && c > 128) c = 128;
     return c;
 }
+// Chebyshev descriptor pass: state slots per atom (16 per lane-iteration, SH_CAP_MAX at most; an atom above goes to the fix-up launch)
+int sh_next_cap(int mx) { return std::min((int)SH_CAP_MAX, std::max(16, round_up(mx, 16))); }       // (no slack: the fix-up launch is the slack)
 // Behler kernels: nothing stands behind an overflow (it is reported and the evaluation has to be re-issued), so the
 // slack is generous: an eighth of the count, at least 2.
 // (in steps of 2: the force pass's LDS decides how many workgroups a CU holds -- 18 in-range neighbours of fcc Ni: capacity 20
@@ -325,6 +330,7 @@ void digest_flags(annp_hip_handle *h)
 {
     const int over = h->h_flags[0], mx = h->h_flags[1], nfix = h->h_flags[2];
     h->info[0] = mx; h->info[1] = nfix; h->info[2] = h->cap_last;
+    if (mx > 0) h->sh_cap = sh_next_cap(mx);
     if (h->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
         h->fe_cap = fe_next_cap(mx);
         h->info[3] = h->fe_cap;
@@ -425,6 +431,49 @@ void launch_fe_force(const FeArgs &a, hipStream_t s)
         hipLaunchKernelGGL((annp_fe_force<FE_NP, FE_NT, VIR, false>), dim3(blocks), dim3(64 * wpb), fe_force_lds_per_wave(a.n_cap, false) * wpb, s, a);
 }
 
+// Chebyshev descriptor pass (pair_style annp Fe and anna_adp): the moment kernel for atoms with at most sh_cap in-cutoff
+// neighbours, the pair-loop kernel behind it for the ones it queued (none in the steady state: microseconds)
+int launch_fe_desc(annp_hip_handle *h, FeArgs a, int inum, int cap_list, int max_numneigh, hipStream_t s)
+{
+    int rc;
+    if (h->fe_desc_pairs) {
+        a.n_cap = cap_list;
+        const int wpd = fe_wpb_desc();
+        const size_t lds1 = fe_desc_lds_per_wave(a.n_cap) * wpd;
+        if (lds1 > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "neighbour list too long for LDS (%d)", max_numneigh);
+        hipLaunchKernelGGL((annp_fe_desc<FE_NP, FE_NT>), dim3((inum + wpd - 1) / wpd), dim3(64 * wpd), lds1, s, a);
+        HIP_TRY(h, hipGetLastError());
+        return 0;
+    }
+    const int cap = std::min(h->sh_cap, cap_list);          // both multiples of 16
+    const size_t lds_fix = fe_desc_lds_per_wave(cap_list);
+    const bool fix = cap_list > cap;
+    if (fix && lds_fix > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "neighbour list too long for LDS (%d)", max_numneigh);
+    if (fix && (rc = ensure(h, h->ovf_desc, (size_t)inum))) return rc;
+    a.n_cap = cap;
+    a.ovf_count = h->d_flags + 3; a.ovf_list = fix ? h->ovf_desc.p : nullptr; a.ovf_cap = fix ? inum : 0;
+    // waves per workgroup: as many waves per CU as the LDS allows, and of those shapes the largest workgroup (measured at
+    // 1 M atoms, 8 waves per CU each: 5.8 ms with 4 waves per workgroup, 6.3 with 1)
+    int wpb = h->sh_wpb;
+    if (wpb <= 0) {
+        int best = 0;
+        for (int w = 1; w <= 4; w++) {
+            const int waves = (int)((size_t)160 * 1024 / (sh_lds_per_wave(cap) * w)) * w;
+            if (waves >= best) { best = waves; wpb = w; }
+        }
+    }
+    const int groups = (inum + SH_GA - 1) / SH_GA;
+    hipLaunchKernelGGL((annp_fe_desc_sh<FE_NP, FE_NT>), dim3((groups + wpb - 1) / wpb), dim3(64 * wpb), sh_lds_per_wave(cap) * wpb, s, a);
+    HIP_TRY(h, hipGetLastError());
+    if (fix) {
+        FeArgs b = a;
+        b.n_cap = cap_list;
+        hipLaunchKernelGGL((annp_fe_desc_fixup<FE_NP, FE_NT>), dim3(std::min(inum, 1024)), dim3(64), lds_fix, s, b);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return 0;
+}
+
 // ---- one evaluation on device-resident data ----------------------------------------
 // Nothing here waits for the device in the steady state: capacities come from the previous evaluation's flag
 // words (whenever their copy has landed), this evaluation's flag words are copied back behind its last kernel.
@@ -440,17 +489,16 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     if ((rc = ensure(h, h->coef, (size_t)inum * ANNP_CPAD))) return rc;
     if ((rc = ensure(h, h->ncount, (size_t)inum))) return rc;
     if (h->reset_err) {
-        HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, 3 * sizeof(int), s));
+        HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, 4 * sizeof(int), s));
         h->reset_err = false;
     } else {
-        HIP_TRY(h, hipMemsetAsync(h->d_flags + 1, 0, 2 * sizeof(int), s));
+        HIP_TRY(h, hipMemsetAsync(h->d_flags + 1, 0, 3 * sizeof(int), s));
     }
     if (h->timing) {
         h->ev = h->evring.data() + 4 * (size_t)(h->ev_count % annp_hip_handle::kRing);
         HIP_TRY(h, hipEventRecord(h->ev[0], s));
     }
 
-    const int blocks = (inum + ANNP_WAVES_PER_BLOCK - 1) / ANNP_WAVES_PER_BLOCK;
     const int cap_list = std::max(16, round_up(max_numneigh, 16));
 
     if (h->multi && !d_type)
@@ -472,13 +520,8 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.type = types; a.active = h->active;
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.vatom = d_vatom; a.ncount = h->ncount.p;
         a.errflag = h->d_flags;
-        // pass 1: capacity = list length (upper bound of the in-cutoff count)
-        a.n_cap = cap_list;
-        const int wpd = fe_wpb_desc();
-        size_t lds1 = fe_desc_lds_per_wave(a.n_cap) * wpd;
-        if (lds1 > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "neighbour list too long for LDS (%d)", max_numneigh);
-        hipLaunchKernelGGL((annp_fe_desc<FE_NP, FE_NT>), dim3((inum + wpd - 1) / wpd), dim3(64 * wpd), lds1, s, a);
-        HIP_TRY(h, hipGetLastError());
+        // pass 1
+        if ((rc = launch_fe_desc(h, a, inum, cap_list, max_numneigh, s))) return rc;
         hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
         HIP_TRY(h, hipGetLastError());
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
@@ -494,7 +537,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         // first evaluation on this handle: read the maximum just measured, once.  Also whenever a whole list row would not
         // fit the fix-up launch's LDS (very long rows): nothing would stand behind a stale capacity then
         if (h->fe_cap == 0 || (!fix_possible && h->fe_cap < cap_list)) {
-            HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
             if (h->h_flags[0] > 0) {
                 h->reset_err = true;
@@ -530,10 +573,8 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
         a.cutsq = h->cutsq; a.rc_list = h->cut; a.rc_par = h->cut;          // fc and the radial argument both use the file's cutoff (adp:105,130,588)
         a.G = h->G.p; a.ncount = h->ncount.p; a.errflag = h->d_flags;
-        a.n_cap = cap_list;
-        size_t lds1 = fe_desc_lds_per_wave(a.n_cap) * ANNP_WAVES_PER_BLOCK;
-        if (lds1 > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "neighbour list too long for LDS (%d)", max_numneigh);
-        hipLaunchKernelGGL((annp_fe_desc<FE_NP, FE_NT>), dim3(blocks), dim3(256), lds1, s, a);
+        if ((rc = launch_fe_desc(h, a, inum, cap_list, max_numneigh, s))) return rc;
+        hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
         HIP_TRY(h, hipGetLastError());
         if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[1], s)); HIP_TRY(h, hipEventRecord(h->ev[2], s)); }
         // pass 2: network, ADP sums, energy, forces
@@ -601,7 +642,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         HIP_TRY(h, hipGetLastError());
         cap_force = a.n_cap;
         if (!h->ni_primed) {    // first evaluation on the handle (or the one after an error): look at the counts once
-            HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
             if (h->h_flags[0] > 0) {
                 h->reset_err = true;
@@ -625,7 +666,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         if (fixup) { ni_launch_force_fix(b, h->ni_shape, d_virial != nullptr || d_vatom != nullptr, s); HIP_TRY(h, hipGetLastError()); }
     }
     // flag words of this evaluation, for whoever looks next (poll_flags)
-    HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipEventRecord(h->ev_flags, s));
     h->flags_pending = true;
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[3], s)); h->ev_count++; }
@@ -851,6 +892,9 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (const char *e = std::getenv("ANNP_HIP_FULL_LIST")) h->full_list = std::atoi(e) != 0;
     if (const char *e = std::getenv("ANNP_HIP_NI_PAIRS")) h->ni_no_pairs = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_NI_FIXUP")) h->ni_no_fixup = std::atoi(e) == 0;
+    if (const char *e = std::getenv("ANNP_HIP_FE_DESC")) h->fe_desc_pairs = std::strcmp(e, "pairs") == 0;
+    if (const char *e = std::getenv("ANNP_HIP_SH_WPB")) h->sh_wpb = std::min(4, std::max(0, std::atoi(e)));
+    if (const char *e = std::getenv("ANNP_HIP_SH_CAP")) h->sh_cap = std::min((int)SH_CAP_MAX, std::max(16, round_up(std::atoi(e), 16)));
     h->cutsq = cutsq_all;
     h->nelem = ne; h->multi = multi; h->active = active;
     if (multi) {
@@ -1055,6 +1099,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     {
         const int full = 160 * 1024;
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc_sh<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc_fixup<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
@@ -1137,6 +1183,15 @@ int annp_hip_last_counts(annp_hip_handle *h, int *counts, int inum)
     DEVICE_GUARD(h);
     HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipMemcpy(counts, h->ncount.p, sizeof(int) * (size_t)inum, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int annp_hip_last_descriptors(annp_hip_handle *h, double *rows, int inum)
+{
+    if (!h || !rows || inum < 0 || (size_t)inum * ANNP_GPAD > h->G.cap) return h ? fail(h, ANNP_HIP_EARG, "last_descriptors: bad argument") : ANNP_HIP_EARG;
+    DEVICE_GUARD(h);
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(rows, h->G.p, sizeof(double) * ANNP_GPAD * (size_t)inum, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -170,15 +170,9 @@ __device__ __forceinline__ int fe_round_min_steps(int q_lane, int H, int L, bool
 // pass 1: descriptor
 // ---------------------------------------------------------------------------------
 template <int NP, int NT>
-__global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
+__device__ __forceinline__ void fe_desc_atom(const FeArgs &p, const int ii, const int lane, unsigned char *wbase)
 {
     static_assert(NT >= 3, "angular closed forms assume at least T_0..T_2");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = lane_id();
-    const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(xcd_block() * (int)(blockDim.x >> 6) + wave);
-    if (ii >= p.inum) return;
-    unsigned char *wbase = lds_raw + (size_t)wave * fe_desc_lds_per_wave(p.n_cap);
     double2 *recA = reinterpret_cast<double2 *>(wbase);
     double2 *recB = recA + fe_slots(p.n_cap);
     double *scratch = reinterpret_cast<double *>(wbase);          // reused after the pair loop: [8][64]
@@ -347,6 +341,17 @@ __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
         }
         Gout[lane] = v;
     }
+}
+
+template <int NP, int NT>
+__global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const int wave = uniform(threadIdx.x >> 6);
+    const int ii = uniform(xcd_block() * (int)(blockDim.x >> 6) + wave);
+    if (ii >= p.inum) return;
+    fe_desc_atom<NP, NT>(p, ii, lane, lds_raw + (size_t)wave * fe_desc_lds_per_wave(p.n_cap));
 }
 
 // ---------------------------------------------------------------------------------

@@ -1,0 +1,430 @@
+// fe_sh_kernels.hpp -- the Chebyshev descriptor pass (fe_v2/src/pair_annp.cpp:633-695, "fe:") without a pair loop.
+//
+// The angular functions are sums over the n(n-1)/2 neighbour pairs of a polynomial of cos(theta_ab) = e_a . e_b:
+//     G_{9+n} = sum_{a<b} fc_a fc_b T_n((e_a.e_b + 1)/2)                                                     (fe:671-678)
+// annp_fe_desc (fe_kernels.hpp) evaluates them pair by pair: 6 216 pairs x 40 instructions for 112 neighbours.  A polynomial
+// of e_a . e_b separates (Legendre addition theorem):
+//     P_l(e_a.e_b) = sum_{m=0..l} kappa_lm [ C_lm(a) C_lm(b) + S_lm(a) S_lm(b) ],
+//     C_lm(a) + i S_lm(a) = Pm_{l-m}(z_a) (x_a + i y_a)^m        (Pm_k: d^m P_l / dz^m made monic, a polynomial in z alone)
+// so with the 361 moments  A_lm = sum_a fc_a (C_lm(a) + i S_lm(a))  of the neighbourhood
+//     pw_l   = sum_{a,b} fc_a fc_b P_l(e_a.e_b) = sum_m kappa_lm |A_lm|^2
+//     G_{9+n} = 1/2 ( sum_l q_nl pw_l - sum_a fc_a^2 ),       T_n((z+1)/2) = sum_{l<=n} q_nl P_l(z)
+// -- the same numbers (the identities are exact; the constants are exact rationals rounded once, tools/gen_sh_tables.py;
+// measured difference to the pair loop: a few 1e-13 relative), for 112 x 190 recurrence steps instead of 6 216 x 17.
+// The T_0 / T_1 closed forms of annp_fe_desc are the l = 0, 1 cases of this.
+//
+// Work decomposition: a wave takes FOUR atoms, 16 lanes each; a lane owns neighbours l, l+16, l+32, .. of its atom.
+//   stage A  the four list rows are filtered one after the other by the whole wave (fe_compact), raw entries straight into
+//            the atom's state area in LDS; then every lane turns its entries into (e_x,e_y), z, (fc,0) -- the running power
+//            fc (x+iy)^m starts at m = 0 -- and sums the radial functions.
+//   columns  m = 0..18, unrolled: a lane walks its neighbours (run-time loop, state from LDS), runs the recurrence in
+//            l = m..18 (2 instructions per step, the constant a literal) and adds Pm (x+iy)^m fc into its 2(19-m)
+//            accumulators (2 per step); the power is advanced and written back.  Then the accumulators are summed over the
+//            16 lanes -- a transposing butterfly on DPP moves: 16 registers x 16 lanes -> one register whose 16 lanes hold
+//            the 16 totals, ~5 instructions per total for four atoms at once -- scaled by sqrt(kappa), squared and added to
+//            pw_l in LDS.
+//   final    lane n of an atom: G_{9+n} from the 19 pw_l (q from constant memory), the radial sums, one 32-double row out.
+// An atom with more in-cutoff neighbours than the state area holds (n_cap, at most 128) is queued for
+// annp_fe_desc_fixup (the pair-loop kernel with room for a whole list row) instead.
+#pragma once
+#include "fe_kernels.hpp"
+#include "sh_tables.hpp"
+
+namespace annp {
+
+constexpr int SH_GA = 4;          // atoms per wave
+constexpr int SH_GL = 16;         // lanes per atom
+constexpr int SH_CAP_MAX = 128;   // state slots per atom the launch may ask for
+static_assert(SH_LMAX == FE_NT - 1, "tables are generated for T_0..T_18");
+
+__constant__ double annp_sh_q[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_Q_INIT;
+__constant__ double annp_sh_kappa[SH_NMOM + 16] = ANNP_SH_KAPPA_INIT;      // (+16: a lane past the last batch's end reads a zero)
+
+// LDS of one wave: (e_x,e_y)[4][cap+8] | (pc,ps)[4][cap+8] | z[4][cap+8] | pw[4][20] | radial totals[4][16].
+// cap is a multiple of 16.  The pitches place the four atoms' runs of a lane group of ds_read_b128 ({0-3,12-15,20-27}, .. :
+// MI355X_MICROARCH.md, LDS) on the four 64-byte quarters of the bank row: pitch = 128 mod 256 bytes; and the eight 32-byte runs
+// of a 32-lane group of ds_read_b64 on its eight eighths: pitch = 64 or 192 mod 256 bytes.
+__host__ __device__ constexpr int sh_pitch2(int n_cap) { return n_cap + 8; }
+__host__ __device__ constexpr int sh_pitch1(int n_cap) { return n_cap + 8; }
+__host__ __device__ constexpr size_t sh_lds_per_wave(int n_cap)
+{
+    return (size_t)SH_GA * (sh_pitch2(n_cap) * 32 + sh_pitch1(n_cap) * 8) + SH_GA * 20 * 8 + SH_GA * 16 * 8;
+}
+
+// ---- sums over the 16 lanes of an atom ------------------------------------------------------------------------------
+// Lane λ of the wave works for atom g = (λ >> 2) & 3 as its lane l = 4 (λ >> 4) + (λ & 3): the four atoms are interleaved quad
+// by quad, so that two bits of l are the wave's lane bits 5 and 4 -- the ones gfx950's v_permlane32_swap / v_permlane16_swap
+// exchange between two registers -- and two are bits inside a quad (DPP quad_perm).
+// One level of the transposing butterfly over a lane bit, for a register pair (ra, rb): lanes with the bit clear come out with
+// ra + partner's ra, lanes with the bit set with rb + partner's rb (partner = λ ^ bit).  16 registers x 16 lanes become one
+// register whose 16 lanes hold the 16 totals after 8 + 4 + 2 + 1 such steps.
+//   bit 5: v_permlane32_swap a, b   a <- (a.lo32lanes, b.lo32lanes), b <- (a.hi, b.hi): two swaps (a double is two words)
+//   bit 4: v_permlane16_swap a, b   the same with odd / even rows of 16          and one add = 3 instructions
+//   bits 1, 0: select what to keep and what to send (v_cndmask), quad_perm move, add = 7 instructions
+template <bool ROWS16>
+__device__ __forceinline__ double sh_comb_swap(double ra, double rb)
+{
+    const unsigned long long a = __builtin_bit_cast(unsigned long long, ra), b = __builtin_bit_cast(unsigned long long, rb);
+    const unsigned alo = (unsigned)a, ahi = (unsigned)(a >> 32), blo = (unsigned)b, bhi = (unsigned)(b >> 32);
+    unsigned nalo, nahi, nblo, nbhi;
+    if (ROWS16) {
+        const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        nalo = lo[0]; nblo = lo[1]; nahi = hi[0]; nbhi = hi[1];
+    } else {
+        const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        nalo = lo[0]; nblo = lo[1]; nahi = hi[0]; nbhi = hi[1];
+    }
+    return __builtin_bit_cast(double, ((unsigned long long)nahi << 32) | nalo) + __builtin_bit_cast(double, ((unsigned long long)nbhi << 32) | nblo);
+}
+template <int QUAD>
+__device__ __forceinline__ double sh_quad(double x)          // x of the quad partner
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(u & 0xffffffffull), QUAD, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(u >> 32), QUAD, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int QUAD>
+__device__ __forceinline__ double sh_comb_quad(double ra, double rb, bool bit)
+{
+    const double keep = bit ? rb : ra, send = bit ? ra : rb;
+    return keep + sh_quad<QUAD>(send);
+}
+// plain sums over one lane bit (both lanes of a pair get the total)
+template <bool ROWS16>
+__device__ __forceinline__ double sh_sum_swap(double x) { return sh_comb_swap<ROWS16>(x, x); }
+template <int QUAD>
+__device__ __forceinline__ double sh_sum_quad(double x) { return x + sh_quad<QUAD>(x); }
+
+// RP = 1, 2, 4, 8, 16 registers summed over the 16 lanes of every atom: a lane returns the total of v[ShLane::jrev & (RP-1)]
+// (every lane of the atom that shares those bits holds the same total).  v is clobbered.
+template <int RP>
+__device__ __forceinline__ double sh_row_reduce(double (&v)[16], bool bit1, bool bit0)
+{
+    int n = RP;
+    if (n >= 2) {
+        n >>= 1;
+#pragma unroll
+        for (int i = 0; i < n; i++) v[i] = sh_comb_swap<false>(v[2 * i], v[2 * i + 1]);
+    } else v[0] = sh_sum_swap<false>(v[0]);
+    if (n >= 2) {
+        n >>= 1;
+#pragma unroll
+        for (int i = 0; i < n; i++) v[i] = sh_comb_swap<true>(v[2 * i], v[2 * i + 1]);
+    } else v[0] = sh_sum_swap<true>(v[0]);
+    if (n >= 2) {
+        n >>= 1;
+#pragma unroll
+        for (int i = 0; i < n; i++) v[i] = sh_comb_quad<0x4E>(v[2 * i], v[2 * i + 1], bit1);      // quad_perm [2,3,0,1]
+    } else v[0] = sh_sum_quad<0x4E>(v[0]);
+    if (n >= 2) v[0] = sh_comb_quad<0xB1>(v[0], v[1], bit0);                                        // quad_perm [1,0,3,2]
+    else v[0] = sh_sum_quad<0xB1>(v[0]);
+    return v[0];
+}
+__host__ __device__ constexpr int sh_pow2_at_least(int r) { return r <= 1 ? 1 : r <= 2 ? 2 : r <= 4 ? 4 : r <= 8 ? 8 : 16; }
+
+struct ShLane {
+    double2 *SA, *SC;      // this lane's first slot of (e_x,e_y) and of the running power
+    double *SZ;
+    double *pwg;           // pw of this lane's atom
+    int iters;             // neighbours per lane to walk (uniform)
+    int jrev;              // which of a batch's 16 totals this lane ends up with: wave lane bits 5,4,1,0 -> bits 0,1,2,3
+    bool bit1, bit0;       // wave lane bits 1 and 0
+};
+
+// batch B of column M: moments 16B .. 16B+R-1 of the column (cosine l = M..18, then sine l = M..18) summed over the atom's
+// lanes; the lane that ends up with moment j adds kappa |A|^2 to pw_l.  kap = this lane's kappa of this batch, fetched before
+// the neighbour loop (sh_column).
+template <int M, int B>
+__device__ __forceinline__ void sh_batch(const ShLane &w, const double *ac, const double *as, double kap)
+{
+    constexpr int K = SH_LMAX + 1 - M;
+    constexpr int NV = (M > 0 ? 2 : 1) * K;
+    constexpr int R = NV - 16 * B < 16 ? NV - 16 * B : 16;
+    constexpr int RP = sh_pow2_at_least(R);
+    double v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int vv = 16 * B + j;
+        const int k = vv < K ? vv : vv - K;
+        v[j] = (j < R) ? (vv < K ? ac[k < K ? k : 0] : as[k < K ? k : 0]) : 0.0;
+    }
+    const double t = sh_row_reduce<RP>(v, w.bit1, w.bit0);
+    const int j = w.jrev & (RP - 1);
+    const int vv = 16 * B + j;
+    const int ll = M + (vv < K ? vv : vv - K);
+    if ((w.jrev & (16 - RP)) == 0 && j < R) atomicAdd(w.pwg + ll, kap * (t * t));     // one lane per moment
+}
+
+template <int M>
+__device__ __forceinline__ void sh_column(const ShLane &w)
+{
+    constexpr int K = SH_LMAX + 1 - M;
+    constexpr int NV = (M > 0 ? 2 : 1) * K;
+    constexpr int NB = (NV + 15) / 16;
+    static_assert(NB <= 3, "three batches per column at most");
+    // this lane's kappa for each batch of the column: in flight behind the neighbour loop
+    const double *kp = annp_sh_kappa + SH_COL_OFF[M] + w.jrev;
+    const double kap0 = kp[0], kap1 = NB > 1 ? kp[16] : 0.0, kap2 = NB > 2 ? kp[32] : 0.0;
+    double ac[K], as[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { ac[k] = 0.0; as[k] = 0.0; }
+    double2 *pa = w.SA, *pc = w.SC;
+    double *pz = w.SZ;
+    int left = uniform(w.iters);        // >= 1
+    // the next neighbour's state is requested before the current one is worked on: with the few waves a CU holds of this
+    // kernel (its LDS) the round trip is not hidden otherwise.  (One slot past the last is read and dropped: it exists.)
+    double2 A = *pa, C = *pc;
+    double z = *pz;
+    do {
+        const double2 An = pa[SH_GL], Cn = pc[SH_GL];
+        const double zn = pz[SH_GL];
+        ac[0] += C.x;
+        if (M > 0) as[0] += C.y;
+        if (K > 1) {
+            ac[1] = fma(z, C.x, ac[1]);
+            if (M > 0) as[1] = fma(z, C.y, as[1]);
+        }
+        double P2 = 1.0, P1 = z;
+#pragma unroll
+        for (int k = 2; k < K; k++) {
+            const double P = fma(z, P1, -(sh_gamma(M, k) * P2));
+            ac[k] = fma(P, C.x, ac[k]);
+            if (M > 0) as[k] = fma(P, C.y, as[k]);
+            P2 = P1; P1 = P;
+        }
+        if (M < SH_LMAX) *pc = make_double2(fma(C.x, A.x, -(C.y * A.y)), fma(C.x, A.y, C.y * A.x));     // fc (x+iy)^(m+1)
+        pa += SH_GL; pc += SH_GL; pz += SH_GL;
+        A = An; C = Cn; z = zn;
+    } while (--left > 0);
+    sh_batch<M, 0>(w, ac, as, kap0);
+    if (NB > 1) sh_batch<M, (NB > 1 ? 1 : 0)>(w, ac, as, kap1);
+    if (NB > 2) sh_batch<M, (NB > 2 ? 2 : 0)>(w, ac, as, kap2);
+}
+template <int M>
+struct ShColumns {
+    static __device__ __forceinline__ void run(const ShLane &w)
+    {
+        sh_column<M>(w);
+        ShColumns<M + 1>::run(w);
+    }
+};
+template <>
+struct ShColumns<SH_LMAX + 1> {
+    static __device__ __forceinline__ void run(const ShLane &) {}
+};
+
+// fe_geometry with the sincos coefficients from scalar registers (annp_common.hpp)
+__device__ __forceinline__ FeNbr sh_geometry(double2 R0, double2 R1, double pi_over_rc)
+{
+    FeNbr g;
+    g.rinv = fast_rsqrt_ic(R1.y);
+    g.r = R1.y * g.rinv;
+    g.ex = R0.x * g.rinv; g.ey = R0.y * g.rinv; g.ez = R1.x * g.rinv;
+    double sn, cs;
+    sincos_0_pi_s(pi_over_rc * g.r, sn, cs);
+    g.fc = 0.5 * (cs + 1.0);                    // fe:592
+    g.dfc = 0.0;
+    return g;
+}
+
+template <int NP, int NT>
+__global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
+{
+    static_assert(NT == SH_LMAX + 1 && NP + NT <= ANNP_GPAD && NP + 1 <= 16, "layout of the output row");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const int wave = uniform(threadIdx.x >> 6);
+    const int ii0 = uniform((xcd_block() * (int)(blockDim.x >> 6) + wave) * SH_GA);
+    if (ii0 >= p.inum) return;
+    const int cap = p.n_cap;
+    unsigned char *wbase = lds_raw + (size_t)wave * sh_lds_per_wave(cap);
+    double2 *SA = reinterpret_cast<double2 *>(wbase);
+    const int P2 = sh_pitch2(cap), P1 = sh_pitch1(cap);
+    double2 *SC = SA + SH_GA * P2;
+    double *SZ = reinterpret_cast<double *>(SC + SH_GA * P2);
+    double *pw = SZ + SH_GA * P1;
+    double *rt = pw + SH_GA * 20;
+    const int g = (lane >> 2) & 3, l = ((lane >> 4) << 2) | (lane & 3);      // atoms interleaved quad by quad (sh_row_reduce)
+    const double pi_over_rc = ANNP_MY_PI / p.rc_list;
+    const double two_over_rcp = 2.0 / p.rc_par;
+
+    // ---- stage A: the four rows, raw (dx,dy) -> SA, (dz,r^2) -> SC.  Lane ga < 4 fetches the header of atom ga.
+    int hi = 0, hjn = -1;                // hjn = -1: no such atom
+    long long hbase = 0;
+    double hx = 0.0, hy = 0.0, hz = 0.0;
+    if (lane < SH_GA && ii0 + lane < p.inum) {
+        hi = p.ilist ? p.ilist[ii0 + lane] : ii0 + lane;
+        hjn = p.numneigh[hi];
+        if (p.type && !type_mapped(p.active, p.type[hi])) hjn = 0;          // centre of an unmapped type: no neighbours, zero row
+        hbase = p.first[hi];
+        hx = p.x[3 * (size_t)hi]; hy = p.x[3 * (size_t)hi + 1]; hz = p.x[3 * (size_t)hi + 2];
+    }
+    int nl = 0, nmax = 0;
+    bool dead = false;                 // this lane's atom does not exist or went to the fix-up queue: no output
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int jn_all = max(max(__builtin_amdgcn_readlane(hjn, 0), __builtin_amdgcn_readlane(hjn, 1)),
+                           max(__builtin_amdgcn_readlane(hjn, 2), __builtin_amdgcn_readlane(hjn, 3)));
+    auto settle = [&](int ga, int n, bool gone) {         // bookkeeping of row ga once its in-cutoff count is known (uniform)
+        const int ii = ii0 + ga;
+        if (!gone) {
+            if (p.ncount && lane == 0) p.ncount[ii] = n;
+            if (n > cap) {                  // more than the state area holds: the pair-loop kernel takes this atom
+                if (lane == 0) {
+                    const int k = p.ovf_list ? atomicAdd(p.ovf_count, 1) : p.ovf_cap;
+                    if (k < p.ovf_cap) p.ovf_list[k] = ii;
+                    else atomicMax(p.errflag, n);
+                }
+                gone = p.ovf_list != nullptr;       // (without a queue: zero row out, error word set, as annp_fe_desc does)
+                n = 0;
+            }
+        }
+        if (g == ga) { nl = n; dead = gone; }
+        nmax = max(nmax, n);
+    };
+    if (jn_all <= 256) {
+        // rows of up to 256 entries (an 8.5 A list of bcc Fe has ~235): the index loads of all four rows go out together, then
+        // all the coordinate gathers -- two dependent memory round trips for the wave instead of two per row
+        int j[SH_GA][4];
+        bool valid[SH_GA][4];
+#pragma unroll
+        for (int ga = 0; ga < SH_GA; ga++) {
+            const int jn = __builtin_amdgcn_readlane(hjn, ga);
+            const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)(hbase & 0xffffffffll), ga);
+            const int bhi = __builtin_amdgcn_readlane((int)(hbase >> 32), ga);
+            const int *row = p.neigh + (((long long)bhi << 32) | (long long)blo);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int jj = 64 * u + lane;
+                valid[ga][u] = jj < jn;
+                j[ga][u] = valid[ga][u] ? (row[jj] & ANNP_NEIGHMASK) : 0;
+            }
+        }
+        if (p.type) {
+#pragma unroll
+            for (int ga = 0; ga < SH_GA; ga++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) valid[ga][u] = valid[ga][u] && type_mapped(p.active, p.type[j[ga][u]]);
+        }
+        double qx[SH_GA][4], qy[SH_GA][4], qz[SH_GA][4];
+#pragma unroll
+        for (int ga = 0; ga < SH_GA; ga++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                qx[ga][u] = p.x[3 * (size_t)j[ga][u]]; qy[ga][u] = p.x[3 * (size_t)j[ga][u] + 1]; qz[ga][u] = p.x[3 * (size_t)j[ga][u] + 2];
+            }
+#pragma unroll
+        for (int ga = 0; ga < SH_GA; ga++) {
+            const double xi = readlane_f64(hx, ga), yi = readlane_f64(hy, ga), zi = readlane_f64(hz, ga);
+            double2 *recA = SA + ga * P2, *recB = SC + ga * P2;
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const double dx = xi - qx[ga][u], dy = yi - qy[ga][u], dz = zi - qz[ga][u];
+                const double rsq = dx * dx + dy * dy + dz * dz;
+                const bool in = valid[ga][u] && !(rsq > p.cutsq) && !(rsq < 1.0e-12);        // fe:144
+                const unsigned long long m = __ballot(in);
+                const int pos = n + __popcll(m & lt);
+                if (in && pos < cap) {
+                    recA[pos] = make_double2(dx, dy);
+                    recB[pos] = make_double2(dz, rsq);
+                }
+                n += __popcll(m);
+            }
+            settle(ga, uniform(n), __builtin_amdgcn_readlane(hjn, ga) < 0);
+        }
+    } else {
+        for (int ga = 0; ga < SH_GA; ga++) {
+            const int jn = __builtin_amdgcn_readlane(hjn, ga);
+            int n = 0;
+            if (jn > 0) n = fe_compact<false>(p, __builtin_amdgcn_readlane(hi, ga), lane, SA + ga * P2, SC + ga * P2, nullptr, cap);
+            settle(ga, n, jn < 0);
+        }
+    }
+    if (lane < SH_GA * 20) pw[lane] = 0.0;
+    if (lane + 64 < SH_GA * 20) pw[lane + 64] = 0.0;
+    wave_lds_sync();
+
+    // ---- per-neighbour terms; radial sums (fe:633-656)
+    const int iters = uniform(max(1, (nmax + SH_GL - 1) / SH_GL));      // (at least one: the loops below are do-while; an empty slot is zeros)
+    double v16[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v16[k] = 0.0;
+    {
+        int s = g * P2 + l, sz = g * P1 + l, it = 0;
+        do {
+            double2 RA = make_double2(0.0, 0.0), RC = make_double2(0.0, 0.0);
+            double zz = 0.0;
+            if (l + SH_GL * it < nl) {
+                const FeNbr q = sh_geometry(SA[s], SC[s], pi_over_rc);
+                RA = make_double2(q.ex, q.ey); zz = q.ez; RC = make_double2(q.fc, 0.0);
+                v16[NP] = fma(q.fc, q.fc, v16[NP]);                 // S2 = sum fc^2
+                const double xr = q.r * two_over_rcp - 1.0;        // fe:643
+                const double y2 = 2.0 * xr;
+                double tm2 = 1.0, tm1 = xr;
+                v16[0] += q.fc;
+                if (NP > 1) v16[1] = fma(xr, q.fc, v16[1]);
+#pragma unroll
+                for (int mm = 2; mm < NP; mm++) {
+                    const double t = fma(y2, tm1, -tm2);
+                    v16[mm] = fma(t, q.fc, v16[mm]);
+                    tm2 = tm1; tm1 = t;
+                }
+            }
+            SA[s] = RA; SZ[sz] = zz; SC[s] = RC;
+            s += SH_GL; sz += SH_GL;
+        } while (++it < iters);
+    }
+    ShLane w;
+    w.SA = SA + g * P2 + l; w.SC = SC + g * P2 + l; w.SZ = SZ + g * P1 + l; w.pwg = pw + g * 20;
+    w.iters = iters;
+    w.jrev = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 1) & 1) << 2) | ((lane & 1) << 3);
+    w.bit1 = (lane & 2) != 0; w.bit0 = (lane & 1) != 0;
+    {
+        const double t = sh_row_reduce<16>(v16, w.bit1, w.bit0);
+        rt[g * 16 + w.jrev] = t;
+    }
+    wave_lds_sync();
+
+    // ---- the moments, column by column
+    ShColumns<0>::run(w);
+    wave_lds_sync();
+
+    // ---- output row: slots l and l + 16 of the atom's 32
+    if (!dead) {
+        double *Gout = p.G + (size_t)(ii0 + g) * ANNP_GPAD;
+        const double S2 = rt[g * 16 + NP];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int slot = l + 16 * half;
+            double val = 0.0;
+            if (slot < NP) val = rt[g * 16 + slot];
+            else if (slot < NP + NT) {
+                const int n = slot - NP;
+                const double *qrow = annp_sh_q + n * NT;
+                double acc = 0.0;
+#pragma unroll
+                for (int lp = 0; lp < NT; lp++) acc = fma(qrow[lp], w.pwg[lp], acc);
+                val = 0.5 * (acc - S2);
+            }
+            Gout[slot] = val;
+        }
+    }
+}
+
+// ---- the pair-loop kernel for the atoms annp_fe_desc_sh queued: one wave per workgroup, every wave walks the queue
+template <int NP, int NT>
+__global__ __launch_bounds__(64) void annp_fe_desc_fixup(FeArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const int count = min(*p.ovf_count, p.ovf_cap);
+    for (int k = blockIdx.x; k < count; k += gridDim.x) {
+        fe_desc_atom<NP, NT>(p, uniform(p.ovf_list[k]), lane, lds_raw);
+        wave_lds_sync();
+    }
+}
+
+}  // namespace annp

@@ -408,14 +408,6 @@ __device__ __forceinline__ NiLds ni_carve(unsigned char *wbase, int cap, int cst
     return L;
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int srclane)
-{
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), srclane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), srclane);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-
 // Filter the list rows of atoms ii0 .. ii0+3 into the records.  Returns the largest in-range count of the
 // four (uniform; > p.n_cap means the records overflowed and must not be used); nl = count of this lane's atom.
 template <bool FORCE>

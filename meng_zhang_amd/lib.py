@@ -9,7 +9,7 @@ _LIB = None
 ABI_SYMBOLS = [
     "annp_hip_init", "annp_hip_compute", "annp_hip_compute_n", "annp_hip_compute_device",
     "annp_hip_neigh_build_device", "annp_hip_list_cutoff", "annp_hip_list_layout", "annp_hip_neigh_to_host", "annp_hip_sync", "annp_hip_eval_info", "annp_hip_set_timing", "annp_hip_last_timing",
-    "annp_hip_timing_stats", "annp_hip_last_counts",
+    "annp_hip_timing_stats", "annp_hip_last_counts", "annp_hip_last_descriptors",
     "annp_hip_comm_unique_id", "annp_hip_comm_init", "annp_hip_comm_route", "annp_hip_comm_destroy",
     "annp_hip_halo_pack", "annp_hip_halo_unpack_images", "annp_hip_reverse_fold", "annp_hip_verlet_half",
     "annp_hip_clear", "annp_hip_bytes", "annp_hip_last_error", "annp_hip_abi_version", "annp_hip_device_count",
@@ -66,6 +66,7 @@ def load_library():
     lib.annp_hip_last_timing.argtypes = [vp, dp]
     lib.annp_hip_timing_stats.argtypes = [vp, dp, ip]
     lib.annp_hip_last_counts.argtypes = [vp, ip, C.c_int]
+    lib.annp_hip_last_descriptors.argtypes = [vp, dp, C.c_int]
     lib.annp_hip_compute_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.annp_hip_neigh_build_device.argtypes = [vp, C.c_int, C.c_int, vp, C.c_double,
                                                 C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), ip, vp]

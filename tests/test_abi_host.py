@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported(lib):
         assert getattr(lib, name) is not None, name
     from meng_zhang_amd.lib import ABI_SYMBOLS
     assert sorted(ABI_SYMBOLS) == declared
-    assert lib.annp_hip_abi_version() == 4      # 4: annp_hip_list_cutoff, halo / integrator entry points
+    assert lib.annp_hip_abi_version() == 5      # 5: annp_hip_last_descriptors
 
 
 def test_pair_symbols_exported(lib):
