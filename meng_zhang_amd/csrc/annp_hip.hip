@@ -317,7 +317,7 @@ int fe_next_cap(int mx)
     return c;
 }
 // Chebyshev descriptor pass: state slots per atom (16 per lane-iteration, SH_CAP_MAX at most; an atom above goes to the fix-up launch)
-int sh_next_cap(int mx) { return std::min((int)SH_CAP_MAX, std::max(16, round_up(mx, 16))); }       // (no slack: the fix-up launch is the slack)
+int sh_next_cap(int mx) { return std::min((int)SH_CAP_MAX, std::max((int)SH_CAP_MIN, round_up(mx, 16))); }       // (no slack: the fix-up launch is the slack)
 // Behler kernels: nothing stands behind an overflow (it is reported and the evaluation has to be re-issued), so the
 // slack is generous: an eighth of the count, at least 2.
 // (in steps of 2: the force pass's LDS decides how many workgroups a CU holds -- 18 in-range neighbours of fcc Ni: capacity 20
@@ -445,7 +445,7 @@ int launch_fe_desc(annp_hip_handle *h, FeArgs a, int inum, int cap_list, int max
         HIP_TRY(h, hipGetLastError());
         return 0;
     }
-    const int cap = std::min(h->sh_cap, cap_list);          // both multiples of 16
+    const int cap = std::max((int)SH_CAP_MIN, std::min(h->sh_cap, cap_list));          // multiples of 16
     const size_t lds_fix = fe_desc_lds_per_wave(cap_list);
     const bool fix = cap_list > cap;
     if (fix && lds_fix > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "neighbour list too long for LDS (%d)", max_numneigh);
@@ -894,7 +894,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (const char *e = std::getenv("ANNP_HIP_NI_FIXUP")) h->ni_no_fixup = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_FE_DESC")) h->fe_desc_pairs = std::strcmp(e, "pairs") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SH_WPB")) h->sh_wpb = std::min(4, std::max(0, std::atoi(e)));
-    if (const char *e = std::getenv("ANNP_HIP_SH_CAP")) h->sh_cap = std::min((int)SH_CAP_MAX, std::max(16, round_up(std::atoi(e), 16)));
+    if (const char *e = std::getenv("ANNP_HIP_SH_CAP")) h->sh_cap = std::min((int)SH_CAP_MAX, std::max((int)SH_CAP_MIN, round_up(std::atoi(e), 16)));
     h->cutsq = cutsq_all;
     h->nelem = ne; h->multi = multi; h->active = active;
     if (multi) {

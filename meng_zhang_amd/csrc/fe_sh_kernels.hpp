@@ -40,16 +40,20 @@ static_assert(SH_LMAX == FE_NT - 1, "tables are generated for T_0..T_18");
 __constant__ double annp_sh_q[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_Q_INIT;
 __constant__ double annp_sh_kappa[SH_NMOM + 16] = ANNP_SH_KAPPA_INIT;      // (+16: a lane past the last batch's end reads a zero)
 
-// LDS of one wave: (e_x,e_y)[4][cap+8] | (pc,ps)[4][cap+8] | z[4][cap+8] | pw[4][20] | radial totals[4][16].
-// cap is a multiple of 16.  The pitches place the four atoms' runs of a lane group of ds_read_b128 ({0-3,12-15,20-27}, .. :
-// MI355X_MICROARCH.md, LDS) on the four 64-byte quarters of the bank row: pitch = 128 mod 256 bytes; and the eight 32-byte runs
-// of a 32-lane group of ds_read_b64 on its eight eighths: pitch = 64 or 192 mod 256 bytes.
-__host__ __device__ constexpr int sh_pitch2(int n_cap) { return n_cap + 8; }
-__host__ __device__ constexpr int sh_pitch1(int n_cap) { return n_cap + 8; }
+constexpr int SH_R = 3;           // neighbours per lane whose state stays in registers (ShRegs)
+constexpr int SH_CAP_MIN = SH_GL * SH_R + 16;
+
+// LDS of one wave, capl = cap - 48 slots per atom: (e_x,e_y)[4][capl+8] | (pc,ps)[4][capl+8] | z[4][capl+8] | 1536 bytes: first the
+// staging rows of stage A, then pw[4][20] and the radial totals[4][16].
+// cap is a multiple of 16.  The pitch places the four atoms' runs of a lane group of ds_read_b128 ({0-3,12-15,20-27}, .. :
+// MI355X_MICROARCH.md, LDS) on the four 64-byte quarters of the bank row (128 mod 256 bytes), and the eight 32-byte runs
+// of a 32-lane group of ds_read_b64 on its eight eighths (64 or 192 mod 256 bytes).
+__host__ __device__ constexpr int sh_pitch(int capl) { return capl + 8; }
 __host__ __device__ constexpr size_t sh_lds_per_wave(int n_cap)
 {
-    return (size_t)SH_GA * (sh_pitch2(n_cap) * 32 + sh_pitch1(n_cap) * 8) + SH_GA * 20 * 8 + SH_GA * 16 * 8;
+    return (size_t)SH_GA * sh_pitch(n_cap - SH_GL * SH_R) * 40 + SH_GL * SH_R * 32;
 }
+static_assert(SH_GL * SH_R * 32 >= (SH_GA * 20 + SH_GA * 16) * 8, "pw and the radial totals live where the staging rows were");
 
 // ---- sums over the 16 lanes of an atom ------------------------------------------------------------------------------
 // Lane λ of the wave works for atom g = (λ >> 2) & 3 as its lane l = 4 (λ >> 4) + (λ & 3): the four atoms are interleaved quad
@@ -126,13 +130,16 @@ __device__ __forceinline__ double sh_row_reduce(double (&v)[16], bool bit1, bool
 __host__ __device__ constexpr int sh_pow2_at_least(int r) { return r <= 1 ? 1 : r <= 2 ? 2 : r <= 4 ? 4 : r <= 8 ? 8 : 16; }
 
 struct ShLane {
-    double2 *SA, *SC;      // this lane's first slot of (e_x,e_y) and of the running power
+    double2 *SA, *SC;      // this lane's first LDS slot of (e_x,e_y) and of the running power
     double *SZ;
     double *pwg;           // pw of this lane's atom
-    int iters;             // neighbours per lane to walk (uniform)
+    int iters;             // LDS-resident neighbours per lane to walk (uniform, may be 0)
     int jrev;              // which of a batch's 16 totals this lane ends up with: wave lane bits 5,4,1,0 -> bits 0,1,2,3
     bool bit1, bit0;       // wave lane bits 1 and 0
 };
+// the first SH_R neighbours of a lane (l, l+16, l+32 of its atom) stay in registers for the whole kernel: 40 bytes of LDS per
+// neighbour are what bounds the waves a CU holds, and with them the kernel's speed
+struct ShRegs { double z[SH_R], ex[SH_R], ey[SH_R], pc[SH_R], ps[SH_R]; };
 
 // batch B of column M: moments 16B .. 16B+R-1 of the column (cosine l = M..18, then sine l = M..18) summed over the atom's
 // lanes; the lane that ends up with moment j adds kappa |A|^2 to pw_l.  kap = this lane's kappa of this batch, fetched before
@@ -159,7 +166,7 @@ __device__ __forceinline__ void sh_batch(const ShLane &w, const double *ac, cons
 }
 
 template <int M>
-__device__ __forceinline__ void sh_column(const ShLane &w)
+__device__ __forceinline__ void sh_column(const ShLane &w, ShRegs &st)
 {
     constexpr int K = SH_LMAX + 1 - M;
     constexpr int NV = (M > 0 ? 2 : 1) * K;
@@ -171,49 +178,64 @@ __device__ __forceinline__ void sh_column(const ShLane &w)
     double ac[K], as[K];
 #pragma unroll
     for (int k = 0; k < K; k++) { ac[k] = 0.0; as[k] = 0.0; }
-    double2 *pa = w.SA, *pc = w.SC;
-    double *pz = w.SZ;
-    int left = uniform(w.iters);        // >= 1
-    // the next neighbour's state is requested before the current one is worked on: with the few waves a CU holds of this
-    // kernel (its LDS) the round trip is not hidden otherwise.  (One slot past the last is read and dropped: it exists.)
-    double2 A = *pa, C = *pc;
-    double z = *pz;
-    do {
-        const double2 An = pa[SH_GL], Cn = pc[SH_GL];
-        const double zn = pz[SH_GL];
-        ac[0] += C.x;
-        if (M > 0) as[0] += C.y;
+    // one neighbour: Pm_k(z), k = 0..K-1, times its power (cx, cy) = fc (x+iy)^M into the accumulators
+    auto neighbour = [&](const double z, const double cx, const double cy) {
+        ac[0] += cx;
+        if (M > 0) as[0] += cy;
         if (K > 1) {
-            ac[1] = fma(z, C.x, ac[1]);
-            if (M > 0) as[1] = fma(z, C.y, as[1]);
+            ac[1] = fma(z, cx, ac[1]);
+            if (M > 0) as[1] = fma(z, cy, as[1]);
         }
         double P2 = 1.0, P1 = z;
 #pragma unroll
         for (int k = 2; k < K; k++) {
             const double P = fma(z, P1, -(sh_gamma(M, k) * P2));
-            ac[k] = fma(P, C.x, ac[k]);
-            if (M > 0) as[k] = fma(P, C.y, as[k]);
+            ac[k] = fma(P, cx, ac[k]);
+            if (M > 0) as[k] = fma(P, cy, as[k]);
             P2 = P1; P1 = P;
         }
-        if (M < SH_LMAX) *pc = make_double2(fma(C.x, A.x, -(C.y * A.y)), fma(C.x, A.y, C.y * A.x));     // fc (x+iy)^(m+1)
-        pa += SH_GL; pc += SH_GL; pz += SH_GL;
-        A = An; C = Cn; z = zn;
-    } while (--left > 0);
+    };
+#pragma unroll
+    for (int r = 0; r < SH_R; r++) {
+        const double cx = st.pc[r], cy = st.ps[r];
+        neighbour(st.z[r], cx, cy);
+        if (M < SH_LMAX) {          // fc (x+iy)^(m+1)
+            st.pc[r] = fma(cx, st.ex[r], -(cy * st.ey[r]));
+            st.ps[r] = fma(cx, st.ey[r], cy * st.ex[r]);
+        }
+    }
+    int left = uniform(w.iters);
+    if (left > 0) {
+        double2 *pa = w.SA, *pc = w.SC;
+        double *pz = w.SZ;
+        // the next neighbour's state is requested before the current one is worked on.  (One slot past the last is read and
+        // dropped: it exists.)
+        double2 A = *pa, C = *pc;
+        double z = *pz;
+        do {
+            const double2 An = pa[SH_GL], Cn = pc[SH_GL];
+            const double zn = pz[SH_GL];
+            neighbour(z, C.x, C.y);
+            if (M < SH_LMAX) *pc = make_double2(fma(C.x, A.x, -(C.y * A.y)), fma(C.x, A.y, C.y * A.x));
+            pa += SH_GL; pc += SH_GL; pz += SH_GL;
+            A = An; C = Cn; z = zn;
+        } while (--left > 0);
+    }
     sh_batch<M, 0>(w, ac, as, kap0);
     if (NB > 1) sh_batch<M, (NB > 1 ? 1 : 0)>(w, ac, as, kap1);
     if (NB > 2) sh_batch<M, (NB > 2 ? 2 : 0)>(w, ac, as, kap2);
 }
 template <int M>
 struct ShColumns {
-    static __device__ __forceinline__ void run(const ShLane &w)
+    static __device__ __forceinline__ void run(const ShLane &w, ShRegs &st)
     {
-        sh_column<M>(w);
-        ShColumns<M + 1>::run(w);
+        sh_column<M>(w, st);
+        ShColumns<M + 1>::run(w, st);
     }
 };
 template <>
 struct ShColumns<SH_LMAX + 1> {
-    static __device__ __forceinline__ void run(const ShLane &) {}
+    static __device__ __forceinline__ void run(const ShLane &, ShRegs &) {}
 };
 
 // fe_geometry with the sincos coefficients from scalar registers (annp_common.hpp)
@@ -239,19 +261,23 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
     const int wave = uniform(threadIdx.x >> 6);
     const int ii0 = uniform((xcd_block() * (int)(blockDim.x >> 6) + wave) * SH_GA);
     if (ii0 >= p.inum) return;
-    const int cap = p.n_cap;
+    const int cap = p.n_cap;                         // in-cutoff neighbours per atom this launch has room for
+    const int capl = cap - SH_GL * SH_R;             // ... of which in LDS
     unsigned char *wbase = lds_raw + (size_t)wave * sh_lds_per_wave(cap);
+    const int PL = sh_pitch(capl);
     double2 *SA = reinterpret_cast<double2 *>(wbase);
-    const int P2 = sh_pitch2(cap), P1 = sh_pitch1(cap);
-    double2 *SC = SA + SH_GA * P2;
-    double *SZ = reinterpret_cast<double *>(SC + SH_GA * P2);
-    double *pw = SZ + SH_GA * P1;
+    double2 *SC = SA + SH_GA * PL;
+    double *SZ = reinterpret_cast<double *>(SC + SH_GA * PL);
+    double *pw = SZ + SH_GA * PL;                    // [4][20], then radial totals [4][16]; before that ...
     double *rt = pw + SH_GA * 20;
+    double2 *stA = reinterpret_cast<double2 *>(pw);  // ... the staging rows of the register-resident entries: raw (dx,dy)[48], (dz,r^2)[48]
+    double2 *stB = stA + SH_GL * SH_R;
     const int g = (lane >> 2) & 3, l = ((lane >> 4) << 2) | (lane & 3);      // atoms interleaved quad by quad (sh_row_reduce)
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
     const double two_over_rcp = 2.0 / p.rc_par;
 
-    // ---- stage A: the four rows, raw (dx,dy) -> SA, (dz,r^2) -> SC.  Lane ga < 4 fetches the header of atom ga.
+    // ---- stage A: the four rows, raw (dx,dy | dz,r^2): in-cutoff entries 0..47 of a row through the staging rows into the
+    //      registers of the atom's lanes, the others into the atom's LDS slots.  Lane ga < 4 fetches the header of atom ga.
     int hi = 0, hjn = -1;                // hjn = -1: no such atom
     long long hbase = 0;
     double hx = 0.0, hy = 0.0, hz = 0.0;
@@ -264,14 +290,19 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
     }
     int nl = 0, nmax = 0;
     bool dead = false;                 // this lane's atom does not exist or went to the fix-up queue: no output
+    double2 rawA[SH_R], rawB[SH_R];
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int jn_all = max(max(__builtin_amdgcn_readlane(hjn, 0), __builtin_amdgcn_readlane(hjn, 1)),
                            max(__builtin_amdgcn_readlane(hjn, 2), __builtin_amdgcn_readlane(hjn, 3)));
-    auto settle = [&](int ga, int n, bool gone) {         // bookkeeping of row ga once its in-cutoff count is known (uniform)
+    auto keep = [&](int ga, int pos, double dx, double dy, double dz, double rsq) {      // entry `pos` of row ga
+        if (pos < SH_GL * SH_R) { stA[pos] = make_double2(dx, dy); stB[pos] = make_double2(dz, rsq); }
+        else if (pos < cap) { SA[ga * PL + pos - SH_GL * SH_R] = make_double2(dx, dy); SC[ga * PL + pos - SH_GL * SH_R] = make_double2(dz, rsq); }
+    };
+    auto settle = [&](int ga, int n, bool gone) {         // row ga is filtered, n = its in-cutoff count (uniform)
         const int ii = ii0 + ga;
         if (!gone) {
             if (p.ncount && lane == 0) p.ncount[ii] = n;
-            if (n > cap) {                  // more than the state area holds: the pair-loop kernel takes this atom
+            if (n > cap) {                  // more than this launch has room for: the pair-loop kernel takes the atom
                 if (lane == 0) {
                     const int k = p.ovf_list ? atomicAdd(p.ovf_count, 1) : p.ovf_cap;
                     if (k < p.ovf_cap) p.ovf_list[k] = ii;
@@ -281,7 +312,17 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
                 n = 0;
             }
         }
-        if (g == ga) { nl = n; dead = gone; }
+        wave_lds_sync();
+        if (g == ga) {
+            nl = n; dead = gone;
+#pragma unroll
+            for (int r = 0; r < SH_R; r++) {
+                const int a = l + SH_GL * r;
+                rawA[r] = a < n ? stA[a] : make_double2(0.0, 0.0);
+                rawB[r] = a < n ? stB[a] : make_double2(0.0, 0.0);
+            }
+        }
+        wave_lds_sync();            // the staging rows are free for the next atom
         nmax = max(nmax, n);
     };
     if (jn_all <= 256) {
@@ -318,7 +359,6 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
 #pragma unroll
         for (int ga = 0; ga < SH_GA; ga++) {
             const double xi = readlane_f64(hx, ga), yi = readlane_f64(hy, ga), zi = readlane_f64(hz, ga);
-            double2 *recA = SA + ga * P2, *recB = SC + ga * P2;
             int n = 0;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -326,11 +366,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
                 const double rsq = dx * dx + dy * dy + dz * dz;
                 const bool in = valid[ga][u] && !(rsq > p.cutsq) && !(rsq < 1.0e-12);        // fe:144
                 const unsigned long long m = __ballot(in);
-                const int pos = n + __popcll(m & lt);
-                if (in && pos < cap) {
-                    recA[pos] = make_double2(dx, dy);
-                    recB[pos] = make_double2(dz, rsq);
-                }
+                if (in) keep(ga, n + __popcll(m & lt), dx, dy, dz, rsq);
                 n += __popcll(m);
             }
             settle(ga, uniform(n), __builtin_amdgcn_readlane(hjn, ga) < 0);
@@ -338,47 +374,69 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
     } else {
         for (int ga = 0; ga < SH_GA; ga++) {
             const int jn = __builtin_amdgcn_readlane(hjn, ga);
+            const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)(hbase & 0xffffffffll), ga);
+            const int bhi = __builtin_amdgcn_readlane((int)(hbase >> 32), ga);
+            const int *row = p.neigh + (((long long)bhi << 32) | (long long)blo);
+            const double xi = readlane_f64(hx, ga), yi = readlane_f64(hy, ga), zi = readlane_f64(hz, ga);
             int n = 0;
-            if (jn > 0) n = fe_compact<false>(p, __builtin_amdgcn_readlane(hi, ga), lane, SA + ga * P2, SC + ga * P2, nullptr, cap);
-            settle(ga, n, jn < 0);
+            for (int c0 = 0; c0 < jn; c0 += 64) {
+                const int jj = c0 + lane;
+                bool ok = jj < jn;
+                const int jx = ok ? (row[jj] & ANNP_NEIGHMASK) : 0;
+                if (p.type) ok = ok && type_mapped(p.active, p.type[jx]);
+                const double dx = xi - p.x[3 * (size_t)jx], dy = yi - p.x[3 * (size_t)jx + 1], dz = zi - p.x[3 * (size_t)jx + 2];
+                const double rsq = dx * dx + dy * dy + dz * dz;
+                const bool in = ok && !(rsq > p.cutsq) && !(rsq < 1.0e-12);
+                const unsigned long long m = __ballot(in);
+                if (in) keep(ga, n + __popcll(m & lt), dx, dy, dz, rsq);
+                n += __popcll(m);
+            }
+            settle(ga, uniform(n), jn < 0);
         }
     }
-    if (lane < SH_GA * 20) pw[lane] = 0.0;
+    if (lane < SH_GA * 20) pw[lane] = 0.0;           // (the staging rows are done with: settle ended on a barrier)
     if (lane + 64 < SH_GA * 20) pw[lane + 64] = 0.0;
-    wave_lds_sync();
 
     // ---- per-neighbour terms; radial sums (fe:633-656)
-    const int iters = uniform(max(1, (nmax + SH_GL - 1) / SH_GL));      // (at least one: the loops below are do-while; an empty slot is zeros)
     double v16[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) v16[k] = 0.0;
+    auto terms = [&](const double2 R0, const double2 R1, double2 &RA, double &zz, double2 &RC) {
+        const FeNbr q = sh_geometry(R0, R1, pi_over_rc);
+        RA = make_double2(q.ex, q.ey); zz = q.ez; RC = make_double2(q.fc, 0.0);
+        v16[NP] = fma(q.fc, q.fc, v16[NP]);                 // S2 = sum fc^2
+        const double xr = q.r * two_over_rcp - 1.0;        // fe:643
+        const double y2 = 2.0 * xr;
+        double tm2 = 1.0, tm1 = xr;
+        v16[0] += q.fc;
+        if (NP > 1) v16[1] = fma(xr, q.fc, v16[1]);
+#pragma unroll
+        for (int mm = 2; mm < NP; mm++) {
+            const double t = fma(y2, tm1, -tm2);
+            v16[mm] = fma(t, q.fc, v16[mm]);
+            tm2 = tm1; tm1 = t;
+        }
+    };
+    ShRegs st;
+#pragma unroll
+    for (int r = 0; r < SH_R; r++) {
+        double2 RA = make_double2(0.0, 0.0), RC = make_double2(0.0, 0.0);
+        double zz = 0.0;
+        if (l + SH_GL * r < nl) terms(rawA[r], rawB[r], RA, zz, RC);
+        st.ex[r] = RA.x; st.ey[r] = RA.y; st.z[r] = zz; st.pc[r] = RC.x; st.ps[r] = RC.y;
+    }
+    const int iters = uniform(max(0, (nmax - SH_GL * SH_R + SH_GL - 1) / SH_GL));     // LDS-resident neighbours per lane
     {
-        int s = g * P2 + l, sz = g * P1 + l, it = 0;
-        do {
+        int s = g * PL + l;
+        for (int it = 0; it < iters; it++, s += SH_GL) {
             double2 RA = make_double2(0.0, 0.0), RC = make_double2(0.0, 0.0);
             double zz = 0.0;
-            if (l + SH_GL * it < nl) {
-                const FeNbr q = sh_geometry(SA[s], SC[s], pi_over_rc);
-                RA = make_double2(q.ex, q.ey); zz = q.ez; RC = make_double2(q.fc, 0.0);
-                v16[NP] = fma(q.fc, q.fc, v16[NP]);                 // S2 = sum fc^2
-                const double xr = q.r * two_over_rcp - 1.0;        // fe:643
-                const double y2 = 2.0 * xr;
-                double tm2 = 1.0, tm1 = xr;
-                v16[0] += q.fc;
-                if (NP > 1) v16[1] = fma(xr, q.fc, v16[1]);
-#pragma unroll
-                for (int mm = 2; mm < NP; mm++) {
-                    const double t = fma(y2, tm1, -tm2);
-                    v16[mm] = fma(t, q.fc, v16[mm]);
-                    tm2 = tm1; tm1 = t;
-                }
-            }
-            SA[s] = RA; SZ[sz] = zz; SC[s] = RC;
-            s += SH_GL; sz += SH_GL;
-        } while (++it < iters);
+            if (l + SH_GL * (SH_R + it) < nl) terms(SA[s], SC[s], RA, zz, RC);
+            SA[s] = RA; SZ[s] = zz; SC[s] = RC;
+        }
     }
     ShLane w;
-    w.SA = SA + g * P2 + l; w.SC = SC + g * P2 + l; w.SZ = SZ + g * P1 + l; w.pwg = pw + g * 20;
+    w.SA = SA + g * PL + l; w.SC = SC + g * PL + l; w.SZ = SZ + g * PL + l; w.pwg = pw + g * 20;
     w.iters = iters;
     w.jrev = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 1) & 1) << 2) | ((lane & 1) << 3);
     w.bit1 = (lane & 2) != 0; w.bit0 = (lane & 1) != 0;
@@ -389,7 +447,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
     wave_lds_sync();
 
     // ---- the moments, column by column
-    ShColumns<0>::run(w);
+    ShColumns<0>::run(w, st);
     wave_lds_sync();
 
     // ---- output row: slots l and l + 16 of the atom's 32
