@@ -123,6 +123,8 @@ struct annp_hip_handle {
     int cap_last = 0;                   // capacity the last force pass ran with
     int sh_cap = SH_CAP_MAX;            // Chebyshev descriptor pass (annp_fe_desc_sh): state slots per atom for the next evaluation
     bool fe_desc_pairs = false;         // ANNP_HIP_FE_DESC=pairs: the pair-loop descriptor kernel (annp_fe_desc) for every atom
+    bool fe_force_pairs = false;        // ANNP_HIP_FE_FORCE=pairs: the pair-loop force kernel (annp_fe_force) for every atom
+    int sh_cap_used = 0;                // state slots the last annp_fe_desc_sh launch had (= atoms with moments have at most that many neighbours)
     int sh_wpb = 0;                     // waves per workgroup of annp_fe_desc_sh (ANNP_HIP_SH_WPB; 0 = chosen per launch)
     int flagact[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // up to max(MLP_MAXL, ANNA_MAXL) weight layers
     static_assert(MLP_MAXL <= 8 && ANNA_MAXL <= 8, "flagact holds 8 layers");
@@ -140,7 +142,7 @@ struct annp_hip_handle {
     NiShape ni_shape = {0, 0, 0};       // {lambda} x {eta} x {zeta} product shape of the angular set (0 = none)
     std::vector<double> sym_rad, sym_ang;
     // work buffers
-    DevBuf<double> G, coef, x, f, eatom, vatom;
+    DevBuf<double> G, coef, x, f, eatom, vatom, mom;        // mom: moments of the neighbourhoods, descriptor pass -> force pass (fe_sh_kernels.hpp)
     DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ni_npair, ni_fix_nbr, ovf, ovf_desc;
     DevBuf<unsigned short> ni_pairs;    // Behler: in-range (j,k) pairs per atom, descriptor pass -> force pass
     DevBuf<long long> first;
@@ -451,6 +453,7 @@ int launch_fe_desc(annp_hip_handle *h, FeArgs a, int inum, int cap_list, int max
     if (fix && lds_fix > 160 * 1024) return fail(h, ANNP_HIP_ENEIGHCAP, "neighbour list too long for LDS (%d)", max_numneigh);
     if (fix && (rc = ensure(h, h->ovf_desc, (size_t)inum))) return rc;
     a.n_cap = cap;
+    h->sh_cap_used = cap;
     a.ovf_count = h->d_flags + 3; a.ovf_list = fix ? h->ovf_desc.p : nullptr; a.ovf_cap = fix ? inum : 0;
     // waves per workgroup: as many waves per CU as the LDS allows, and of those shapes the largest workgroup (measured at
     // 1 M atoms, 8 waves per CU each: 5.8 ms with 4 waves per workgroup, 6.3 with 1)
@@ -520,7 +523,14 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.type = types; a.active = h->active;
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.vatom = d_vatom; a.ncount = h->ncount.p;
         a.errflag = h->d_flags;
-        // pass 1
+        // pass 1 (and, for the force pass on the moments, their buffer; that pass needs the fix-up launch behind it)
+        const size_t lds_fix = fe_force_lds_per_wave(cap_list, false);      // the fix-up runs one wave per workgroup
+        const bool fix_possible = lds_fix <= 160 * 1024;
+        const bool sh_force = !h->fe_desc_pairs && !h->fe_force_pairs && fix_possible;
+        if (sh_force) {
+            if ((rc = ensure(h, h->mom, (size_t)inum * SH_MPAD))) return rc;
+            a.A = h->mom.p;
+        }
         if ((rc = launch_fe_desc(h, a, inum, cap_list, max_numneigh, s))) return rc;
         hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
         HIP_TRY(h, hipGetLastError());
@@ -531,9 +541,31 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], s));
         // pass 3: LDS records sized by the in-cutoff maximum of the previous evaluation; an atom that has more
         // is queued by the kernel and taken by the fix-up launch behind it, which has room for a whole list row
+        const bool vir = d_virial || d_vatom;
+        if (sh_force) {
+            // pass 3 on the moments: atoms the descriptor pass had no state for (more than sh_cap_used neighbours) go to the queue
+            // and the pair-loop fix-up launch, which has room for a whole list row; nothing to size, nothing to wait for
+            const int cap = h->sh_cap_used;
+            const bool fixup = cap_list > cap;
+            if (fixup && (rc = ensure(h, h->ovf, (size_t)inum))) return rc;
+            a.n_cap = cap;
+            a.ovf_count = h->d_flags + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
+            if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
+            const int wpb = fe_wpb_force();
+            if (vir) hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, true>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), shf_lds_per_wave() * wpb, s, a);
+            else hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, false>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), shf_lds_per_wave() * wpb, s, a);
+            HIP_TRY(h, hipGetLastError());
+            if (fixup) {
+                FeArgs b = a;
+                b.n_cap = cap_list;
+                const int fblocks = std::min(inum, 1024);
+                if (vir) hipLaunchKernelGGL((annp_fe_force_fixup<FE_NP, FE_NT, true>), dim3(fblocks), dim3(64), lds_fix, s, b);
+                else hipLaunchKernelGGL((annp_fe_force_fixup<FE_NP, FE_NT, false>), dim3(fblocks), dim3(64), lds_fix, s, b);
+                HIP_TRY(h, hipGetLastError());
+            }
+            h->cap_last = cap;
+        } else {
         int cap3;
-        const size_t lds_fix = fe_force_lds_per_wave(cap_list, false);      // the fix-up runs one wave per workgroup
-        const bool fix_possible = lds_fix <= 160 * 1024;
         // first evaluation on this handle: read the maximum just measured, once.  Also whenever a whole list row would not
         // fit the fix-up launch's LDS (very long rows): nothing would stand behind a stale capacity then
         if (h->fe_cap == 0 || (!fix_possible && h->fe_cap < cap_list)) {
@@ -548,7 +580,6 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         } else {
             cap3 = std::min(h->fe_cap, cap_list);
         }
-        const bool vir = d_virial || d_vatom;
         if ((rc = ensure(h, h->ovf, (size_t)inum))) return rc;
         a.n_cap = cap3;
         const bool fixup = cap3 < cap_list && fix_possible;
@@ -567,6 +598,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             HIP_TRY(h, hipGetLastError());
         }
         h->cap_last = cap3;
+        }
     } else if (h->descriptor == ANNP_HIP_DESC_ANNA_ADP) {
         // pass 1: the same Chebyshev descriptor kernel, raw sums (adp:584-612 has no normalisation)
         FeArgs a{};
@@ -893,6 +925,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (const char *e = std::getenv("ANNP_HIP_NI_PAIRS")) h->ni_no_pairs = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_NI_FIXUP")) h->ni_no_fixup = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_FE_DESC")) h->fe_desc_pairs = std::strcmp(e, "pairs") == 0;
+    if (const char *e = std::getenv("ANNP_HIP_FE_FORCE")) h->fe_force_pairs = std::strcmp(e, "pairs") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SH_WPB")) h->sh_wpb = std::min(4, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("ANNP_HIP_SH_CAP")) h->sh_cap = std::min((int)SH_CAP_MAX, std::max((int)SH_CAP_MIN, round_up(std::atoi(e), 16)));
     h->cutsq = cutsq_all;

@@ -59,6 +59,9 @@ struct FeArgs {
     int *ovf_count;            // device int, zeroed per evaluation
     int *ovf_list;             // [ovf_cap] entries ii
     int ovf_cap;
+    // moment form (fe_sh_kernels.hpp): the 361 moments of every atom's neighbourhood, [inum][SH_MPAD]; written by
+    // annp_fe_desc_sh when given, read by annp_fe_force_sh
+    double *A;
 };
 
 // LDS layout of one wave.  A record is two 16-byte halves (e_x,e_y) and (e_z,fc), kept in two

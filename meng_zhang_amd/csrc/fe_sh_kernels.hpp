@@ -39,6 +39,9 @@ static_assert(SH_LMAX == FE_NT - 1, "tables are generated for T_0..T_18");
 
 __constant__ double annp_sh_q[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_Q_INIT;
 __constant__ double annp_sh_kappa[SH_NMOM + 16] = ANNP_SH_KAPPA_INIT;      // (+16: a lane past the last batch's end reads a zero)
+__constant__ double annp_sh_ml[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_ML_INIT;
+__constant__ unsigned short annp_shf_mk[SHF_NE] = ANNP_SHF_MK_INIT;
+constexpr int SH_MPAD = 368;      // doubles per atom in the moment buffer (361 moments in the order of annp_sh_kappa)
 
 constexpr int SH_R = 3;           // neighbours per lane whose state stays in registers (ShRegs)
 constexpr int SH_CAP_MIN = SH_GL * SH_R + 16;
@@ -133,6 +136,7 @@ struct ShLane {
     double2 *SA, *SC;      // this lane's first LDS slot of (e_x,e_y) and of the running power
     double *SZ;
     double *pwg;           // pw of this lane's atom
+    double *Aout;          // nullable: the atom's row of the moment buffer
     int iters;             // LDS-resident neighbours per lane to walk (uniform, may be 0)
     int jrev;              // which of a batch's 16 totals this lane ends up with: wave lane bits 5,4,1,0 -> bits 0,1,2,3
     bool bit1, bit0;       // wave lane bits 1 and 0
@@ -162,7 +166,10 @@ __device__ __forceinline__ void sh_batch(const ShLane &w, const double *ac, cons
     const int j = w.jrev & (RP - 1);
     const int vv = 16 * B + j;
     const int ll = M + (vv < K ? vv : vv - K);
-    if ((w.jrev & (16 - RP)) == 0 && j < R) atomicAdd(w.pwg + ll, kap * (t * t));     // one lane per moment
+    if ((w.jrev & (16 - RP)) == 0 && j < R) {       // one lane per moment
+        atomicAdd(w.pwg + ll, kap * (t * t));
+        if (w.Aout) w.Aout[SH_COL_OFF[M] + vv] = t;
+    }
 }
 
 template <int M>
@@ -438,6 +445,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
     ShLane w;
     w.SA = SA + g * PL + l; w.SC = SC + g * PL + l; w.SZ = SZ + g * PL + l; w.pwg = pw + g * 20;
     w.iters = iters;
+    w.Aout = (p.A && !dead) ? p.A + (size_t)(ii0 + g) * SH_MPAD : nullptr;
     w.jrev = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 1) & 1) << 2) | ((lane & 1) << 3);
     w.bit1 = (lane & 2) != 0; w.bit0 = (lane & 1) != 0;
     {
@@ -482,6 +490,273 @@ __global__ __launch_bounds__(64) void annp_fe_desc_fixup(FeArgs p)
     for (int k = blockIdx.x; k < count; k += gridDim.x) {
         fe_desc_atom<NP, NT>(p, uniform(p.ovf_list[k]), lane, lds_raw);
         wave_lds_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Force pass on the moments.  With P(z) = sum_l W_l P_l(z) the atom's angular polynomial (the network pass hands it over in
+// powers of z: W_l = sum_k p_k ml[k][l]),
+//     E_ang = sum_{a<b} fc_a fc_b P(e_a.e_b) = 1/2 sum_a fc_a (U(e_a) - P(1) fc_a),
+//     U(e) = sum_b fc_b P(e.e_b) = sum_{l,m} W_l kappa_lm [ A^c_lm C_lm(e) + A^s_lm S_lm(e) ]
+//          = sum_m Re[ (beta^c_m(z) - i beta^s_m(z)) (x+iy)^m ],     beta_m(z) = sum_k B_{m+k,m} Pm_k(z),  B = W kappa A
+// is a polynomial of e = (x,y,z) whose value and gradient at e_a are what annp_fe_force accumulates pair by pair:
+// S_a = sum_{b != a} P fc_b = U(e_a) - P(1) fc_a,  V'_a = sum_b P' fc_b e_b = grad U(e_a)  (the self term of the gradient
+// is along e_a and drops out of the force, which only sees grad U's part across e_a).  Per neighbour:
+//     dU/dz = sum_m Re[(beta'^c_m - i beta'^s_m) w^m],  dU/dx = sum_m m Re[(beta^c_m - i beta^s_m) w^(m-1)],  dU/dy likewise with i w^(m-1)
+// and d/dz Pm^(m)_k = k Pm^(m+1)_(k-1): beta'_m is summed with column m+1's polynomials, so one pass over the 190 recurrence
+// steps (2 instructions each) carries four sums (beta^c_m, beta^s_m, beta'^c_(m-1), beta'^s_(m-1): 4 FMAs) -- 112 x 190 x 6
+// instructions instead of 6 216 pairs x 46.
+// One wave per atom, a lane owns neighbours lane and lane + 64 (registers); the atom's 190 x 4 coefficients sit in LDS (every lane
+// reads the same address: a broadcast) and serve both neighbours of a lane at once.  Atoms with more neighbours than the
+// descriptor pass had state for (no moments) or than 128 go to annp_fe_force_fixup, as before.
+__host__ __device__ constexpr size_t shf_lds_per_wave() { return (size_t)SHF_NE * 32 + 80 * 8; }
+static_assert(SHF_NE * 32 >= 128 * (32 + 4), "the coefficient table takes the place of the staging records");
+__host__ __device__ constexpr int sh_col_off(int m) { return m == 0 ? 0 : 19 + 38 * (m - 1) - (m - 1) * m; }   // = SH_COL_OFF[m]
+static_assert(sh_col_off(1) == SH_COL_OFF[1] && sh_col_off(7) == SH_COL_OFF[7] && sh_col_off(18) == SH_COL_OFF[18], "moment order");
+
+struct ShfNbr {
+    double z, ex, ey, pc, ps, qc, qs;     // e = (ex, ey, z); (pc,ps) = (x+iy)^m, (qc,qs) = (x+iy)^(m-1)
+    double U, Ux, Uy, Uz;
+};
+
+typedef double shf_v2d __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) shf_v2d *shf_lds_ptr;
+constexpr int SHF_AHEAD = 2;
+template <int M>
+__device__ __forceinline__ void shf_column(const unsigned T, ShfNbr (&nb)[2])      // T: the table's byte address in LDS
+{
+    constexpr int K = SH_LMAX + 1 - M;
+    // a column starts when the previous one is done: its recurrence depends on z alone and would otherwise be started early,
+    // all 19 columns' worth of it, and held in registers; and the sums at the end of a column would be put off to the end of the kernel
+    asm volatile("" : "+v"(nb[0].z), "+v"(nb[1].z), "+v"(nb[0].U), "+v"(nb[1].U), "+v"(nb[0].Ux), "+v"(nb[1].Ux), "+v"(nb[0].Uy), "+v"(nb[1].Uy),
+                      "+v"(nb[0].Uz), "+v"(nb[1].Uz), "+v"(nb[0].pc), "+v"(nb[1].pc), "+v"(nb[0].ps), "+v"(nb[1].ps),
+                      "+v"(nb[0].qc), "+v"(nb[1].qc), "+v"(nb[0].qs), "+v"(nb[1].qs));
+    double bc[2] = {0.0, 0.0}, bs[2] = {0.0, 0.0}, dc[2] = {0.0, 0.0}, ds[2] = {0.0, 0.0};
+    double P2[2] = {1.0, 1.0}, P1[2] = {nb[0].z, nb[1].z};
+    // The coefficients of step k are requested SHF_AHEAD steps before they are used.  All 190 x 2 loads have known addresses and
+    // nothing but data flow orders arithmetic: left alone the compiler issues every load at the top of the kernel, runs the
+    // recurrences of all columns ahead of the sums that consume them, and spills 5 KB per lane.  An empty asm that "modifies" the
+    // table address together with the sums pins each step between its neighbours: the requests that follow it cannot start
+    // before it, it cannot start before the previous step's sums are done.
+    shf_v2d c0[K], c1[K];
+    unsigned tb = T;
+    auto pin = [&]() {
+        asm volatile("" : "+v"(tb), "+v"(bc[0]), "+v"(bc[1]), "+v"(bs[0]), "+v"(bs[1]), "+v"(dc[0]), "+v"(dc[1]), "+v"(ds[0]), "+v"(ds[1]),
+                          "+v"(P1[0]), "+v"(P1[1]));
+    };
+    auto request = [&](int k) {
+        const shf_lds_ptr tp = (shf_lds_ptr)(uintptr_t)(tb + 32u * (unsigned)(SHF_OFF[M] + k));
+        c0[k] = tp[0]; c1[k] = tp[1];
+    };
+    pin();
+#pragma unroll
+    for (int k = 0; k < (K < SHF_AHEAD ? K : SHF_AHEAD); k++) request(k);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (k + SHF_AHEAD < K) request(k + SHF_AHEAD);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            double P;
+            if (k == 0) P = 1.0;
+            else if (k == 1) P = nb[u].z;
+            else { P = fma(nb[u].z, P1[u], -(sh_gamma(M, k) * P2[u])); P2[u] = P1[u]; P1[u] = P; }
+            bc[u] = fma(c0[k].x, P, bc[u]);
+            if (M > 0) bs[u] = fma(c0[k].y, P, bs[u]);
+            if (M > 0) dc[u] = fma(c1[k].x, P, dc[u]);
+            if (M > 1) ds[u] = fma(c1[k].y, P, ds[u]);
+        }
+        pin();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        ShfNbr &q = nb[u];
+        q.U = fma(bc[u], q.pc, q.U);
+        if (M > 0) {
+            q.U = fma(bs[u], q.ps, q.U);
+            q.Uz = fma(dc[u], q.qc, q.Uz);
+            if (M > 1) q.Uz = fma(ds[u], q.qs, q.Uz);
+            const double tx = fma(bc[u], q.qc, bs[u] * q.qs), ty = fma(bs[u], q.qc, -(bc[u] * q.qs));
+            q.Ux = fma((double)M, tx, q.Ux);
+            q.Uy = fma((double)M, ty, q.Uy);
+        }
+        if (M < SH_LMAX) {
+            q.qc = q.pc; q.qs = q.ps;
+            const double npc = fma(q.pc, q.ex, -(q.ps * q.ey)), nps = fma(q.pc, q.ey, q.ps * q.ex);
+            q.pc = npc; q.ps = nps;
+        }
+    }
+}
+template <int M>
+struct ShfColumns {
+    static __device__ __forceinline__ void run(const unsigned T, ShfNbr (&nb)[2])
+    {
+        shf_column<M>(T, nb);
+        ShfColumns<M + 1>::run(T, nb);
+    }
+};
+template <>
+struct ShfColumns<SH_LMAX + 1> {
+    static __device__ __forceinline__ void run(const unsigned, ShfNbr (&)[2]) {}
+};
+
+template <int NP, int NT, bool VIRIAL>
+__global__ __launch_bounds__(256, 3) void annp_fe_force_sh(FeArgs p)
+{
+    static_assert(NT == SH_LMAX + 1 && NP + 2 * NT - 1 <= 48, "coefficient row");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const int wave = uniform(threadIdx.x >> 6);
+    const int ii = uniform(xcd_block() * (int)(blockDim.x >> 6) + wave);
+    if (ii >= p.inum) return;
+    unsigned char *wbase = lds_raw + (size_t)wave * shf_lds_per_wave();
+    double2 *recA = reinterpret_cast<double2 *>(wbase);           // stage A: raw entries [128] (dx,dy), [128] (dz,r^2), [128] j
+    double2 *recB = recA + 128;
+    int *auxJ = reinterpret_cast<int *>(recB + 128);
+    double2 *T = reinterpret_cast<double2 *>(wbase);              // then: the coefficient table [190][2]
+    double *cw = reinterpret_cast<double *>(wbase + (size_t)SHF_NE * 32);      // [0,48) coefficient row, [48,67) W_l
+    const int i = p.ilist ? p.ilist[ii] : ii;
+    const double pi_over_rc = ANNP_MY_PI / p.rc_list;
+    const double two_over_rcp = 2.0 / p.rc_par;
+    const double *cf = p.coef + (size_t)ii * ANNP_CPAD;
+
+    if (p.type && !type_mapped(p.active, p.type[i])) return;
+    const int n = fe_compact<true>(p, i, lane, recA, recB, auxJ, 128);
+    if (n > p.n_cap) {            // no moments for this atom (or more neighbours than two per lane): the pair loop takes it
+        if (lane == 0) {
+            const int k = p.ovf_list ? atomicAdd(p.ovf_count, 1) : p.ovf_cap;
+            if (k < p.ovf_cap) p.ovf_list[k] = ii;
+            else atomicMax(p.errflag, n);
+        }
+        return;
+    }
+    if (lane < 48) cw[lane] = cf[lane];
+    wave_lds_sync();
+
+    // ---- this lane's two neighbours: geometry and the radial term (fe:648), kept in registers
+    ShfNbr nb[2];
+    double fc[2], dfc[2], rinv[2], rr[2];
+    int jn[2];
+    {
+        double cr[NP];
+#pragma unroll
+        for (int m = 0; m < NP; m++) cr[m] = cf[m];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int a = lane + 64 * u;
+            const bool has = a < n;
+            const double2 R0 = has ? recA[a] : make_double2(0.0, 0.0), R1 = has ? recB[a] : make_double2(1.0, 1.0);
+            jn[u] = has ? auxJ[a] : i;
+            const FeNbr g = fe_geometry(R0, R1, pi_over_rc);
+            const double xr = g.r * two_over_rcp - 1.0;
+            const double y2 = 2.0 * xr;
+            double tm2 = 1.0, tm1 = xr, dm2 = 0.0, dm1 = 1.0;
+            double st = cr[0], sd = 0.0;              // sum c T, sum c T'
+            if (NP > 1) { st = fma(cr[1], xr, st); sd = cr[1]; }
+#pragma unroll
+            for (int mm = 2; mm < NP; mm++) {
+                const double t = fma(y2, tm1, -tm2);
+                const double d = fma(y2, dm1, fma(2.0, tm1, -dm2));
+                st = fma(cr[mm], t, st);
+                sd = fma(cr[mm], d, sd);
+                tm2 = tm1; tm1 = t; dm2 = dm1; dm1 = d;
+            }
+            const double R = fma(sd * two_over_rcp, g.fc, st * g.dfc);
+            nb[u].z = g.ez; nb[u].ex = g.ex; nb[u].ey = g.ey;
+            nb[u].pc = 1.0; nb[u].ps = 0.0; nb[u].qc = 0.0; nb[u].qs = 0.0;
+            nb[u].U = 0.0; nb[u].Ux = 0.0; nb[u].Uy = 0.0; nb[u].Uz = 0.0;
+            fc[u] = has ? g.fc : 0.0; dfc[u] = g.dfc; rinv[u] = g.rinv; rr[u] = -R * g.r;
+        }
+    }
+    // ---- W_l = sum_k p_k ml[k][l], P(1) = sum_k p_k
+    double pone = 0.0;
+#pragma unroll
+    for (int k = 0; k < NT; k++) pone += cw[NP + k];
+    if (lane < NT) {
+        double w = 0.0;
+#pragma unroll
+        for (int k = 0; k < NT; k++) w = fma(cw[NP + k], annp_sh_ml[k * NT + lane], w);
+        cw[48 + lane] = w;
+    }
+    wave_lds_sync();            // the raw records are in registers, W_l is there: the table may take the records' place
+
+    // ---- coefficient table: entry (m,k) = B^c, B^s of (l = m+k, m) and (k+1) B^c, (k+1) B^s of (l, m-1)
+    {
+        const double *Am = p.A + (size_t)ii * SH_MPAD;
+        for (int e = lane; e < SHF_NE; e += 64) {
+            const int mk = annp_shf_mk[e];
+            const int m = mk & 255, k = mk >> 8, K = SH_LMAX + 1 - m;
+            const double w = cw[48 + m + k];
+            const int ic = sh_col_off(m) + k;
+            const double Bc = w * annp_sh_kappa[ic] * Am[ic];
+            const double Bs = m > 0 ? w * annp_sh_kappa[ic + K] * Am[ic + K] : 0.0;
+            double Dc = 0.0, Ds = 0.0;
+            if (m > 0) {
+                const int id = sh_col_off(m - 1) + k + 1;
+                const double wk = w * (double)(k + 1);
+                Dc = wk * annp_sh_kappa[id] * Am[id];
+                if (m > 1) Ds = wk * annp_sh_kappa[id + K + 1] * Am[id + K + 1];
+            }
+            T[2 * e] = make_double2(Bc, Bs);
+            T[2 * e + 1] = make_double2(Dc, Ds);
+        }
+    }
+    wave_lds_sync();
+
+    // ---- value and gradient of U at the two neighbours
+    ShfColumns<0>::run((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)T, nb);
+
+    // ---- finalize: Fn_a = sum_n c_n dG_n/dx_a ; F_a = -Fn_a to neighbour, +Fn_a to centre (fe:190-213), as annp_fe_force
+    double fi0 = 0.0, fi1 = 0.0, fi2 = 0.0;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (lane + 64 * u < n) {
+            const ShfNbr &q = nb[u];
+            const double V0 = fc[u] * q.Ux, V1 = fc[u] * q.Uy, V2 = fc[u] * q.Uz;           // V_a = fc_a grad U
+            const double S = fma(-pone, fc[u], q.U);                                        // sum_{b != a} P fc_b
+            const double cq = fma(q.ex, V0, fma(q.ey, V1, fma(q.z, V2, rr[u])));
+            const double t = fma(cq, rinv[u], -S * dfc[u]);
+            const double g0 = fma(t, q.ex, -V0 * rinv[u]);
+            const double g1 = fma(t, q.ey, -V1 * rinv[u]);
+            const double g2 = fma(t, q.z, -V2 * rinv[u]);
+            const int j = jn[u];
+            atomicAdd(&p.f[3 * (size_t)j], -g0);
+            atomicAdd(&p.f[3 * (size_t)j + 1], -g1);
+            atomicAdd(&p.f[3 * (size_t)j + 2], -g2);
+            fi0 += g0; fi1 += g1; fi2 += g2;
+            if (VIRIAL) {   // ev_tally_xyz(i,j,...,fx=-Fj, del = xi-xj = r e)   (fe:201-209)
+                const double r = 1.0 / rinv[u];
+                const double d0 = r * q.ex, d1 = r * q.ey, d2 = r * q.z;
+                const double w0 = d0 * g0, w1 = d1 * g1, w2 = d2 * g2, w3 = d0 * g1, w4 = d0 * g2, w5 = d1 * g2;
+                v0 += w0; v1 += w1; v2 += w2; v3 += w3; v4 += w4; v5 += w5;
+                if (p.vatom) {
+                    double *vj = p.vatom + 6 * (size_t)j;
+                    atomicAdd(vj + 0, 0.5 * w0); atomicAdd(vj + 1, 0.5 * w1); atomicAdd(vj + 2, 0.5 * w2);
+                    atomicAdd(vj + 3, 0.5 * w3); atomicAdd(vj + 4, 0.5 * w4); atomicAdd(vj + 5, 0.5 * w5);
+                }
+            }
+        }
+    }
+    fi0 = wave_sum(fi0); fi1 = wave_sum(fi1); fi2 = wave_sum(fi2);
+    if (lane == 0) {
+        atomicAdd(&p.f[3 * (size_t)i], fi0);
+        atomicAdd(&p.f[3 * (size_t)i + 1], fi1);
+        atomicAdd(&p.f[3 * (size_t)i + 2], fi2);
+    }
+    if (VIRIAL) {
+        v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
+        v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
+        if (lane == 0) {
+            if (p.virial) {
+                atomicAdd(&p.virial[0], v0); atomicAdd(&p.virial[1], v1); atomicAdd(&p.virial[2], v2);
+                atomicAdd(&p.virial[3], v3); atomicAdd(&p.virial[4], v4); atomicAdd(&p.virial[5], v5);
+            }
+            if (p.vatom) {
+                double *vi = p.vatom + 6 * (size_t)i;
+                atomicAdd(vi + 0, 0.5 * v0); atomicAdd(vi + 1, 0.5 * v1); atomicAdd(vi + 2, 0.5 * v2);
+                atomicAdd(vi + 3, 0.5 * v3); atomicAdd(vi + 4, 0.5 * v4); atomicAdd(vi + 5, 0.5 * v5);
+            }
+        }
     }
 }
 
