@@ -125,6 +125,9 @@ struct annp_hip_handle {
     bool fe_desc_pairs = false;         // ANNP_HIP_FE_DESC=pairs: the pair-loop descriptor kernel (annp_fe_desc) for every atom
     bool fe_force_pairs = false;        // ANNP_HIP_FE_FORCE=pairs: the pair-loop force kernel (annp_fe_force) for every atom
     int sh_cap_used = 0;                // state slots the last annp_fe_desc_sh launch had (= atoms with moments have at most that many neighbours)
+    bool fe_dense = false;              // most atoms have more neighbours than the moment kernels take (128): the pair-loop kernels for all
+    bool fe_last_sh = false;            // the last Chebyshev evaluation ran the moment kernels
+    int fe_last_inum = 0;
     int sh_wpb = 0;                     // waves per workgroup of annp_fe_desc_sh (ANNP_HIP_SH_WPB; 0 = chosen per launch)
     int flagact[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // up to max(MLP_MAXL, ANNA_MAXL) weight layers
     static_assert(MLP_MAXL <= 8 && ANNA_MAXL <= 8, "flagact holds 8 layers");
@@ -335,7 +338,12 @@ void digest_flags(annp_hip_handle *h)
     if (mx > 0) h->sh_cap = sh_next_cap(mx);
     if (h->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
         h->fe_cap = fe_next_cap(mx);
-        h->info[3] = h->fe_cap;
+        // The moment kernels take atoms with up to SH_CAP_MAX neighbours and queue the others for the pair-loop fix-up launches, which
+        // run one wave per workgroup: fine for a few atoms, slow for a dense system.  When a sixteenth of the atoms went through
+        // the queue, the next evaluation uses the pair-loop kernels for all of them, until the maximum is back under the limit.
+        if (h->fe_last_sh) h->fe_dense = mx > SH_CAP_MAX && nfix > h->fe_last_inum / 16;
+        else h->fe_dense = mx > SH_CAP_MAX;
+        h->info[3] = (h->fe_dense || h->fe_desc_pairs || h->fe_force_pairs) ? h->fe_cap : h->sh_cap;     // capacity of the next force pass
         if (over > 0)
             h->sticky_rc = fail(h, ANNP_HIP_ENEIGHCAP, "an atom has %d in-cutoff neighbours, more than the list-row capacity the "
                                 "evaluation was given (max_numneigh) or than LDS holds; it was skipped", over);
@@ -438,7 +446,7 @@ void launch_fe_force(const FeArgs &a, hipStream_t s)
 int launch_fe_desc(annp_hip_handle *h, FeArgs a, int inum, int cap_list, int max_numneigh, hipStream_t s)
 {
     int rc;
-    if (h->fe_desc_pairs) {
+    if (h->fe_desc_pairs || (h->fe_dense && h->descriptor == ANNP_HIP_DESC_CHEBYSHEV)) {
         a.n_cap = cap_list;
         const int wpd = fe_wpb_desc();
         const size_t lds1 = fe_desc_lds_per_wave(a.n_cap) * wpd;
@@ -523,10 +531,12 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.type = types; a.active = h->active;
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.vatom = d_vatom; a.ncount = h->ncount.p;
         a.errflag = h->d_flags;
+        if (const char *e = std::getenv("ANNP_HIP_DBG")) a.dbg = std::atoi(e);
         // pass 1 (and, for the force pass on the moments, their buffer; that pass needs the fix-up launch behind it)
         const size_t lds_fix = fe_force_lds_per_wave(cap_list, false);      // the fix-up runs one wave per workgroup
         const bool fix_possible = lds_fix <= 160 * 1024;
-        const bool sh_force = !h->fe_desc_pairs && !h->fe_force_pairs && fix_possible;
+        const bool sh_force = !h->fe_desc_pairs && !h->fe_force_pairs && !h->fe_dense && fix_possible;
+        h->fe_last_sh = sh_force; h->fe_last_inum = inum;
         if (sh_force) {
             if ((rc = ensure(h, h->mom, (size_t)inum * SH_MPAD))) return rc;
             a.A = h->mom.p;
@@ -551,9 +561,9 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             a.n_cap = cap;
             a.ovf_count = h->d_flags + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
             if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
-            const int wpb = fe_wpb_force();
-            if (vir) hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, true>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), shf_lds_per_wave() * wpb, s, a);
-            else hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, false>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), shf_lds_per_wave() * wpb, s, a);
+            const int wpb = SHF_WAVES;
+            if (vir) hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, true>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), shf_lds_per_block(), s, a);
+            else hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, false>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), shf_lds_per_block(), s, a);
             HIP_TRY(h, hipGetLastError());
             if (fixup) {
                 FeArgs b = a;
@@ -1134,6 +1144,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc_sh<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc_fixup<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh<FE_NP, FE_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh<FE_NP, FE_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));

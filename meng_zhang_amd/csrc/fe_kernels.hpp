@@ -62,6 +62,7 @@ struct FeArgs {
     // moment form (fe_sh_kernels.hpp): the 361 moments of every atom's neighbourhood, [inum][SH_MPAD]; written by
     // annp_fe_desc_sh when given, read by annp_fe_force_sh
     double *A;
+    int dbg;                   // developer switches (ANNP_HIP_DBG): 1 = annp_fe_force_sh skips the neighbour atomics, 2 = skips the columns
 };
 
 // LDS layout of one wave.  A record is two 16-byte halves (e_x,e_y) and (e_z,fc), kept in two
@@ -108,7 +109,9 @@ __device__ __forceinline__ int fe_compact(const FeArgs &p, int i, int lane, doub
         for (int u = 0; u < 4; u++) {
             const int jj = c0 + 64 * u + lane;
             valid[u] = jj < jn;
-            j[u] = valid[u] ? (p.neigh[base + jj] & ANNP_NEIGHMASK) : i;
+            // (unconditional, clamped to the row's last entry: a load under `valid ? .. : ..` becomes a branch with its own wait,
+            // four dependent round trips through memory instead of one)
+            j[u] = p.neigh[base + min(jj, jn - 1)] & ANNP_NEIGHMASK;
         }
         if (p.type) {          // wave-uniform: only potentials with an unmapped type pay for the gather
 #pragma unroll

@@ -40,7 +40,6 @@ static_assert(SH_LMAX == FE_NT - 1, "tables are generated for T_0..T_18");
 __constant__ double annp_sh_q[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_Q_INIT;
 __constant__ double annp_sh_kappa[SH_NMOM + 16] = ANNP_SH_KAPPA_INIT;      // (+16: a lane past the last batch's end reads a zero)
 __constant__ double annp_sh_ml[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_ML_INIT;
-__constant__ unsigned short annp_shf_mk[SHF_NE] = ANNP_SHF_MK_INIT;
 constexpr int SH_MPAD = 368;      // doubles per atom in the moment buffer (361 moments in the order of annp_sh_kappa)
 
 constexpr int SH_R = 3;           // neighbours per lane whose state stays in registers (ShRegs)
@@ -168,7 +167,7 @@ __device__ __forceinline__ void sh_batch(const ShLane &w, const double *ac, cons
     const int ll = M + (vv < K ? vv : vv - K);
     if ((w.jrev & (16 - RP)) == 0 && j < R) {       // one lane per moment
         atomicAdd(w.pwg + ll, kap * (t * t));
-        if (w.Aout) w.Aout[SH_COL_OFF[M] + vv] = t;
+        if (w.Aout) w.Aout[SH_COL_OFF[M] + vv] = kap * t;        // kappa_lm A_lm: what annp_fe_force_sh multiplies W_l with
     }
 }
 
@@ -342,12 +341,16 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
             const int jn = __builtin_amdgcn_readlane(hjn, ga);
             const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)(hbase & 0xffffffffll), ga);
             const int bhi = __builtin_amdgcn_readlane((int)(hbase >> 32), ga);
-            const int *row = p.neigh + (((long long)bhi << 32) | (long long)blo);
+            // loads are unconditional and clamped to the row's last entry (a load under `valid ? .. : ..` becomes a branch with its
+            // own wait); an empty or missing row reads numneigh[0] instead, whatever that is
+            const int *row = jn > 0 ? p.neigh + (((long long)bhi << 32) | (long long)blo) : p.numneigh;
+            const int last = max(jn, 1) - 1;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int jj = 64 * u + lane;
                 valid[ga][u] = jj < jn;
-                j[ga][u] = valid[ga][u] ? (row[jj] & ANNP_NEIGHMASK) : 0;
+                const int jr = row[min(jj, last)] & ANNP_NEIGHMASK;
+                j[ga][u] = valid[ga][u] ? jr : 0;
             }
         }
         if (p.type) {
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
             for (int c0 = 0; c0 < jn; c0 += 64) {
                 const int jj = c0 + lane;
                 bool ok = jj < jn;
-                const int jx = ok ? (row[jj] & ANNP_NEIGHMASK) : 0;
+                const int jx = row[min(jj, jn - 1)] & ANNP_NEIGHMASK;
                 if (p.type) ok = ok && type_mapped(p.active, p.type[jx]);
                 const double dx = xi - p.x[3 * (size_t)jx], dy = yi - p.x[3 * (size_t)jx + 1], dz = zi - p.x[3 * (size_t)jx + 2];
                 const double rsq = dx * dx + dy * dy + dz * dz;
@@ -509,13 +512,13 @@ __global__ __launch_bounds__(64) void annp_fe_desc_fixup(FeArgs p)
 // One wave per atom, a lane owns neighbours lane and lane + 64 (registers); the atom's 190 x 4 coefficients sit in LDS (every lane
 // reads the same address: a broadcast) and serve both neighbours of a lane at once.  Atoms with more neighbours than the
 // descriptor pass had state for (no moments) or than 128 go to annp_fe_force_fixup, as before.
-__host__ __device__ constexpr size_t shf_lds_per_wave() { return (size_t)SHF_NE * 32 + 80 * 8; }
-static_assert(SHF_NE * 32 >= 128 * (32 + 4), "the coefficient table takes the place of the staging records");
+__host__ __device__ constexpr size_t shf_lds_per_wave() { return (size_t)SHF_NE * 32 + 108 * 8 + 128 * 4; }
+static_assert(SHF_NE * 32 >= 128 * 32, "the coefficient table takes the place of the staging records");
 __host__ __device__ constexpr int sh_col_off(int m) { return m == 0 ? 0 : 19 + 38 * (m - 1) - (m - 1) * m; }   // = SH_COL_OFF[m]
 static_assert(sh_col_off(1) == SH_COL_OFF[1] && sh_col_off(7) == SH_COL_OFF[7] && sh_col_off(18) == SH_COL_OFF[18], "moment order");
 
 struct ShfNbr {
-    double z, ex, ey, pc, ps, qc, qs;     // e = (ex, ey, z); (pc,ps) = (x+iy)^m, (qc,qs) = (x+iy)^(m-1)
+    double z, ex, ey, qc, qs;             // e = (ex, ey, z); (qc,qs) = (x+iy)^(m-1) at the start of column m
     double U, Ux, Uy, Uz;
 };
 
@@ -529,8 +532,7 @@ __device__ __forceinline__ void shf_column(const unsigned T, ShfNbr (&nb)[2])   
     // a column starts when the previous one is done: its recurrence depends on z alone and would otherwise be started early,
     // all 19 columns' worth of it, and held in registers; and the sums at the end of a column would be put off to the end of the kernel
     asm volatile("" : "+v"(nb[0].z), "+v"(nb[1].z), "+v"(nb[0].U), "+v"(nb[1].U), "+v"(nb[0].Ux), "+v"(nb[1].Ux), "+v"(nb[0].Uy), "+v"(nb[1].Uy),
-                      "+v"(nb[0].Uz), "+v"(nb[1].Uz), "+v"(nb[0].pc), "+v"(nb[1].pc), "+v"(nb[0].ps), "+v"(nb[1].ps),
-                      "+v"(nb[0].qc), "+v"(nb[1].qc), "+v"(nb[0].qs), "+v"(nb[1].qs));
+                      "+v"(nb[0].Uz), "+v"(nb[1].Uz), "+v"(nb[0].qc), "+v"(nb[1].qc), "+v"(nb[0].qs), "+v"(nb[1].qs));
     double bc[2] = {0.0, 0.0}, bs[2] = {0.0, 0.0}, dc[2] = {0.0, 0.0}, ds[2] = {0.0, 0.0};
     double P2[2] = {1.0, 1.0}, P1[2] = {nb[0].z, nb[1].z};
     // The coefficients of step k are requested SHF_AHEAD steps before they are used.  All 190 x 2 loads have known addresses and
@@ -570,20 +572,18 @@ __device__ __forceinline__ void shf_column(const unsigned T, ShfNbr (&nb)[2])   
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         ShfNbr &q = nb[u];
-        q.U = fma(bc[u], q.pc, q.U);
+        // (qc,qs) = (x+iy)^(M-1) is what is kept; (x+iy)^M is made from it where it is needed
+        const double wc = M == 0 ? 1.0 : fma(q.qc, q.ex, -(q.qs * q.ey)), ws = M == 0 ? 0.0 : fma(q.qc, q.ey, q.qs * q.ex);
+        q.U = fma(bc[u], wc, q.U);
         if (M > 0) {
-            q.U = fma(bs[u], q.ps, q.U);
+            q.U = fma(bs[u], ws, q.U);
             q.Uz = fma(dc[u], q.qc, q.Uz);
             if (M > 1) q.Uz = fma(ds[u], q.qs, q.Uz);
             const double tx = fma(bc[u], q.qc, bs[u] * q.qs), ty = fma(bs[u], q.qc, -(bc[u] * q.qs));
             q.Ux = fma((double)M, tx, q.Ux);
             q.Uy = fma((double)M, ty, q.Uy);
         }
-        if (M < SH_LMAX) {
-            q.qc = q.pc; q.qs = q.ps;
-            const double npc = fma(q.pc, q.ex, -(q.ps * q.ey)), nps = fma(q.pc, q.ey, q.ps * q.ex);
-            q.pc = npc; q.ps = nps;
-        }
+        q.qc = wc; q.qs = ws;
     }
 }
 template <int M>
@@ -599,27 +599,86 @@ struct ShfColumns<SH_LMAX + 1> {
     static __device__ __forceinline__ void run(const unsigned, ShfNbr (&)[2]) {}
 };
 
+// Forces leave through a table in LDS that the atoms of a workgroup share (8 waves = 8 consecutive atoms: neighbours in space,
+// whose ~900 (atom, neighbour) contributions fall on ~200 distinct atoms): open addressing on the atom index, LDS atomics, and one
+// global atomic per distinct atom and component when the workgroup is done.  The pass was bound by its 3 x 112 global
+// atomics per atom before: 12.0 ms per 1 M atoms with them, 7.4 without, 11.0 with them and without the arithmetic.
+constexpr int SHF_WAVES = 8;          // waves (atoms) per workgroup
+constexpr int SHF_TSLOTS = 512;       // slots of the workgroup's force table
+constexpr int SHF_TPROBE = 8;         // occupied slots tried before a contribution goes straight to global memory
+__host__ __device__ constexpr size_t shf_lds_table() { return (size_t)SHF_TSLOTS * (4 + 24); }
+__host__ __device__ constexpr size_t shf_lds_per_block();
+__host__ __device__ constexpr size_t shf_lds_per_block() { return shf_lds_table() + SHF_WAVES * shf_lds_per_wave(); }
+struct ShfTable {
+    int *key;          // [SHF_TSLOTS], -1 = free
+    double *acc;       // [SHF_TSLOTS][3]
+    double *f;
+    __device__ __forceinline__ void add(int j, double fx, double fy, double fz) const
+    {
+        unsigned sl = ((unsigned)j * 0x9E3779B1u) >> 23;
+#pragma unroll 1
+        for (int probe = 0; probe < SHF_TPROBE; probe++) {
+            const int old = atomicCAS(&key[sl], -1, j);
+            if (old == -1 || old == j) {
+                atomicAdd(&acc[3 * sl], fx); atomicAdd(&acc[3 * sl + 1], fy); atomicAdd(&acc[3 * sl + 2], fz);
+                return;
+            }
+            sl = (sl + 1) & (SHF_TSLOTS - 1);
+        }
+        atomicAdd(&f[3 * (size_t)j], fx); atomicAdd(&f[3 * (size_t)j + 1], fy); atomicAdd(&f[3 * (size_t)j + 2], fz);
+    }
+};
+
 template <int NP, int NT, bool VIRIAL>
-__global__ __launch_bounds__(256, 3) void annp_fe_force_sh(FeArgs p)
+__device__ __forceinline__ void shf_atom(const FeArgs &p, const int ii, const int lane, unsigned char *wbase, const ShfTable &tab)
 {
     static_assert(NT == SH_LMAX + 1 && NP + 2 * NT - 1 <= 48, "coefficient row");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = lane_id();
-    const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(xcd_block() * (int)(blockDim.x >> 6) + wave);
-    if (ii >= p.inum) return;
-    unsigned char *wbase = lds_raw + (size_t)wave * shf_lds_per_wave();
     double2 *recA = reinterpret_cast<double2 *>(wbase);           // stage A: raw entries [128] (dx,dy), [128] (dz,r^2), [128] j
     double2 *recB = recA + 128;
-    int *auxJ = reinterpret_cast<int *>(recB + 128);
+    int *auxJ = reinterpret_cast<int *>(wbase + (size_t)SHF_NE * 32 + 108 * 8);     // (behind the table: read again at the end)
     double2 *T = reinterpret_cast<double2 *>(wbase);              // then: the coefficient table [190][2]
-    double *cw = reinterpret_cast<double *>(wbase + (size_t)SHF_NE * 32);      // [0,48) coefficient row, [48,67) W_l
+    double *cw = reinterpret_cast<double *>(wbase + (size_t)SHF_NE * 32);      // [0,48) coefficient row, [48,108) W_l in three partial sums
     const int i = p.ilist ? p.ilist[ii] : ii;
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
     const double two_over_rcp = 2.0 / p.rc_par;
     const double *cf = p.coef + (size_t)ii * ANNP_CPAD;
 
     if (p.type && !type_mapped(p.active, p.type[i])) return;
+    // ---- everything that does not depend on the neighbour list is requested now and lands while the list is read: the
+    //      coefficient row, this lane's column of ml, and for its (up to) three table entries (m,k) the four scaled moments
+    //      kappa A of (l = m+k, m) and (l, m-1).  (Three dependent round trips through memory otherwise, behind the three the
+    //      list takes -- with half the arithmetic of the pair loop to hide them behind.)
+    const double cf_lane = cf[lane < 48 ? lane : 47];
+    // W_l: lane (l, part) = (lane % 19, lane / 19) sums every third k (57 lanes; three partial sums per l meet in LDS)
+    const int wl = lane % NT, wpart = lane / NT;
+    double mlv[(NT + 2) / 3];
+#pragma unroll
+    for (int t = 0; t < (NT + 2) / 3; t++) {
+        const int k = 3 * t + wpart;
+        mlv[t] = (wpart < 3 && k < NT) ? annp_sh_ml[k * NT + wl] : 0.0;
+    }
+    int te_l[3], te_k[3];
+    double te_a[3][4];
+    {
+        const double *Am = p.A + (size_t)ii * SH_MPAD;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            // entry e of the table = step k of column m: e = SHF_OFF[m] + k, SHF_OFF[m] = 19 m - m (m-1) / 2
+            const int e = min(lane + 64 * t, SHF_NE - 1);
+            int m = (int)((39.0f - __builtin_sqrtf(1521.0f - 8.0f * (float)e)) * 0.5f);
+            m = min(max(m, 0), SH_LMAX);
+            if (m < SH_LMAX && NT * (m + 1) - (m + 1) * m / 2 <= e) m++;
+            if (NT * m - m * (m - 1) / 2 > e) m--;
+            const int k = e - (NT * m - m * (m - 1) / 2), K = SH_LMAX + 1 - m;
+            te_l[t] = m + k; te_k[t] = k;
+            const int ic = sh_col_off(m) + k;
+            const int id = m > 0 ? sh_col_off(m - 1) + k + 1 : 0;
+            te_a[t][0] = Am[ic];
+            te_a[t][1] = m > 0 ? Am[ic + K] : 0.0;
+            te_a[t][2] = m > 0 ? Am[id] : 0.0;
+            te_a[t][3] = m > 1 ? Am[id + K + 1] : 0.0;
+        }
+    }
     const int n = fe_compact<true>(p, i, lane, recA, recB, auxJ, 128);
     if (n > p.n_cap) {            // no moments for this atom (or more neighbours than two per lane): the pair loop takes it
         if (lane == 0) {
@@ -629,13 +688,12 @@ __global__ __launch_bounds__(256, 3) void annp_fe_force_sh(FeArgs p)
         }
         return;
     }
-    if (lane < 48) cw[lane] = cf[lane];
+    if (lane < 48) cw[lane] = cf_lane;
     wave_lds_sync();
 
     // ---- this lane's two neighbours: geometry and the radial term (fe:648), kept in registers
     ShfNbr nb[2];
     double fc[2], dfc[2], rinv[2], rr[2];
-    int jn[2];
     {
         double cr[NP];
 #pragma unroll
@@ -645,7 +703,6 @@ __global__ __launch_bounds__(256, 3) void annp_fe_force_sh(FeArgs p)
             const int a = lane + 64 * u;
             const bool has = a < n;
             const double2 R0 = has ? recA[a] : make_double2(0.0, 0.0), R1 = has ? recB[a] : make_double2(1.0, 1.0);
-            jn[u] = has ? auxJ[a] : i;
             const FeNbr g = fe_geometry(R0, R1, pi_over_rc);
             const double xr = g.r * two_over_rcp - 1.0;
             const double y2 = 2.0 * xr;
@@ -662,52 +719,45 @@ __global__ __launch_bounds__(256, 3) void annp_fe_force_sh(FeArgs p)
             }
             const double R = fma(sd * two_over_rcp, g.fc, st * g.dfc);
             nb[u].z = g.ez; nb[u].ex = g.ex; nb[u].ey = g.ey;
-            nb[u].pc = 1.0; nb[u].ps = 0.0; nb[u].qc = 0.0; nb[u].qs = 0.0;
+            nb[u].qc = 0.0; nb[u].qs = 0.0;
             nb[u].U = 0.0; nb[u].Ux = 0.0; nb[u].Uy = 0.0; nb[u].Uz = 0.0;
             fc[u] = has ? g.fc : 0.0; dfc[u] = g.dfc; rinv[u] = g.rinv; rr[u] = -R * g.r;
         }
     }
     // ---- W_l = sum_k p_k ml[k][l], P(1) = sum_k p_k
-    double pone = 0.0;
-#pragma unroll
-    for (int k = 0; k < NT; k++) pone += cw[NP + k];
-    if (lane < NT) {
+    {
         double w = 0.0;
 #pragma unroll
-        for (int k = 0; k < NT; k++) w = fma(cw[NP + k], annp_sh_ml[k * NT + lane], w);
-        cw[48 + lane] = w;
+        for (int t = 0; t < (NT + 2) / 3; t++) {
+            const int k = 3 * t + wpart;
+            if (wpart < 3 && k < NT) w = fma(cw[NP + k], mlv[t], w);
+        }
+        if (wpart < 3) cw[48 + wpart * 20 + wl] = w;         // [48,67) [68,87) [88,107): the three partial sums
     }
-    wave_lds_sync();            // the raw records are in registers, W_l is there: the table may take the records' place
+    wave_lds_sync();            // the raw records are in registers, the W_l are there: the table may take the records' place
 
-    // ---- coefficient table: entry (m,k) = B^c, B^s of (l = m+k, m) and (k+1) B^c, (k+1) B^s of (l, m-1)
-    {
-        const double *Am = p.A + (size_t)ii * SH_MPAD;
-        for (int e = lane; e < SHF_NE; e += 64) {
-            const int mk = annp_shf_mk[e];
-            const int m = mk & 255, k = mk >> 8, K = SH_LMAX + 1 - m;
-            const double w = cw[48 + m + k];
-            const int ic = sh_col_off(m) + k;
-            const double Bc = w * annp_sh_kappa[ic] * Am[ic];
-            const double Bs = m > 0 ? w * annp_sh_kappa[ic + K] * Am[ic + K] : 0.0;
-            double Dc = 0.0, Ds = 0.0;
-            if (m > 0) {
-                const int id = sh_col_off(m - 1) + k + 1;
-                const double wk = w * (double)(k + 1);
-                Dc = wk * annp_sh_kappa[id] * Am[id];
-                if (m > 1) Ds = wk * annp_sh_kappa[id + K + 1] * Am[id + K + 1];
-            }
-            T[2 * e] = make_double2(Bc, Bs);
-            T[2 * e + 1] = make_double2(Dc, Ds);
+    // ---- coefficient table: entry (m,k) = B^c, B^s of (l = m+k, m) and (k+1) B^c, (k+1) B^s of (l, m-1);  B = W_l kappa A
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int e = lane + 64 * t;
+        if (e < SHF_NE) {
+            const double w = (cw[48 + te_l[t]] + cw[68 + te_l[t]]) + cw[88 + te_l[t]];
+            const double wk = w * (double)(te_k[t] + 1);
+            T[2 * e] = make_double2(w * te_a[t][0], w * te_a[t][1]);
+            T[2 * e + 1] = make_double2(wk * te_a[t][2], wk * te_a[t][3]);
         }
     }
     wave_lds_sync();
 
     // ---- value and gradient of U at the two neighbours
-    ShfColumns<0>::run((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)T, nb);
+    if (!(p.dbg & 2)) ShfColumns<0>::run((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)T, nb);
 
     // ---- finalize: Fn_a = sum_n c_n dG_n/dx_a ; F_a = -Fn_a to neighbour, +Fn_a to centre (fe:190-213), as annp_fe_force
     double fi0 = 0.0, fi1 = 0.0, fi2 = 0.0;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
+    double pone = 0.0;          // P(1) = sum_k p_k (the coefficient row is still in LDS)
+#pragma unroll
+    for (int k = 0; k < NT; k++) pone += cw[NP + k];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         if (lane + 64 * u < n) {
@@ -719,10 +769,8 @@ __global__ __launch_bounds__(256, 3) void annp_fe_force_sh(FeArgs p)
             const double g0 = fma(t, q.ex, -V0 * rinv[u]);
             const double g1 = fma(t, q.ey, -V1 * rinv[u]);
             const double g2 = fma(t, q.z, -V2 * rinv[u]);
-            const int j = jn[u];
-            atomicAdd(&p.f[3 * (size_t)j], -g0);
-            atomicAdd(&p.f[3 * (size_t)j + 1], -g1);
-            atomicAdd(&p.f[3 * (size_t)j + 2], -g2);
+            const int j = auxJ[lane + 64 * u];
+            if (!(p.dbg & 1)) tab.add(j, -g0, -g1, -g2);
             fi0 += g0; fi1 += g1; fi2 += g2;
             if (VIRIAL) {   // ev_tally_xyz(i,j,...,fx=-Fj, del = xi-xj = r e)   (fe:201-209)
                 const double r = 1.0 / rinv[u];
@@ -738,11 +786,7 @@ __global__ __launch_bounds__(256, 3) void annp_fe_force_sh(FeArgs p)
         }
     }
     fi0 = wave_sum(fi0); fi1 = wave_sum(fi1); fi2 = wave_sum(fi2);
-    if (lane == 0) {
-        atomicAdd(&p.f[3 * (size_t)i], fi0);
-        atomicAdd(&p.f[3 * (size_t)i + 1], fi1);
-        atomicAdd(&p.f[3 * (size_t)i + 2], fi2);
-    }
+    if (lane == 0) tab.add(i, fi0, fi1, fi2);
     if (VIRIAL) {
         v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
         v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
@@ -756,6 +800,33 @@ __global__ __launch_bounds__(256, 3) void annp_fe_force_sh(FeArgs p)
                 atomicAdd(vi + 0, 0.5 * v0); atomicAdd(vi + 1, 0.5 * v1); atomicAdd(vi + 2, 0.5 * v2);
                 atomicAdd(vi + 3, 0.5 * v3); atomicAdd(vi + 4, 0.5 * v4); atomicAdd(vi + 5, 0.5 * v5);
             }
+        }
+    }
+}
+
+template <int NP, int NT, bool VIRIAL>
+__global__ __launch_bounds__(64 * SHF_WAVES, 4) void annp_fe_force_sh(FeArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const int wave = uniform(threadIdx.x >> 6);
+    const int ii = uniform(xcd_block() * SHF_WAVES + wave);
+    ShfTable tab;
+    tab.key = reinterpret_cast<int *>(lds_raw + (size_t)SHF_TSLOTS * 24);
+    tab.acc = reinterpret_cast<double *>(lds_raw);
+    tab.f = p.f;
+    for (int sl = threadIdx.x; sl < SHF_TSLOTS; sl += 64 * SHF_WAVES) {
+        tab.key[sl] = -1; tab.acc[3 * sl] = 0.0; tab.acc[3 * sl + 1] = 0.0; tab.acc[3 * sl + 2] = 0.0;
+    }
+    __syncthreads();
+    if (ii < p.inum) shf_atom<NP, NT, VIRIAL>(p, ii, lane, lds_raw + shf_lds_table() + (size_t)wave * shf_lds_per_wave(), tab);
+    __syncthreads();
+    // the workgroup's table: one global atomic per distinct atom and component
+    for (int sl = threadIdx.x; sl < SHF_TSLOTS; sl += 64 * SHF_WAVES) {
+        const int j = tab.key[sl];
+        if (j >= 0) {
+            atomicAdd(&p.f[3 * (size_t)j], tab.acc[3 * sl]); atomicAdd(&p.f[3 * (size_t)j + 1], tab.acc[3 * sl + 1]);
+            atomicAdd(&p.f[3 * (size_t)j + 2], tab.acc[3 * sl + 2]);
         }
     }
 }

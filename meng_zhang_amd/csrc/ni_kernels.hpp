@@ -451,12 +451,16 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
             const int jn = __builtin_amdgcn_readlane(hjn, ga);
             const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)(hbase & 0xffffffffll), ga);
             const int bhi = __builtin_amdgcn_readlane((int)(hbase >> 32), ga);
-            const int *row = p.neigh + (((long long)bhi << 32) | (long long)blo);
+            // (loads unconditional, clamped to the row's last entry: a load under `valid ? .. : ..` becomes a branch with its own
+            // wait, a round trip through memory each; an empty row reads numneigh[0] and drops it)
+            const int *row = jn > 0 ? p.neigh + (((long long)bhi << 32) | (long long)blo) : p.numneigh;
+            const int last = max(jn, 1) - 1;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int jj = 64 * u + lane;
                 valid[ga][u] = jj < jn;
-                j[ga][u] = valid[ga][u] ? (row[jj] & ANNP_NEIGHMASK) : 0;
+                const int jr = row[min(jj, last)] & ANNP_NEIGHMASK;
+                j[ga][u] = valid[ga][u] ? jr : 0;
             }
         }
         if (p.type) {
@@ -515,7 +519,8 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
                 if (u < ngr) {
                     const int jj = c0 + 64 * u + lane;
                     valid[u] = jj < jn;
-                    j[u] = valid[u] ? (row[jj] & ANNP_NEIGHMASK) : 0;
+                    const int jr = row[min(jj, jn - 1)] & ANNP_NEIGHMASK;
+                    j[u] = valid[u] ? jr : 0;
                 }
             }
             if (p.type) {
