@@ -43,13 +43,22 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # Per-unit algorithmic work (fp64, FMA = 2 flop), derived line by line in DESIGN.md 4.5.
 # (a) what the implemented formulation needs -- the roofline numerator:
-FLOP_PAIR_DESC, FLOP_NBR_DESC = 76.0, 110.0       # pass 1: cos 5, weights 3, T_2..T_18 recurrence + accumulate 68
-FLOP_PAIR_FORCE, FLOP_NBR_FORCE = 88.0, 158.0     # pass 3: cos 5, Horner P 36 + dP 34, dP fc_b 1, a-side 8, b-side 4
+#     The Chebyshev passes work on the 361 moments of a neighbourhood (fe_sh_kernels.hpp), not on its pairs: per in-cutoff
+#     neighbour the 190 steps of the monic recurrences (mul + fma = 3 flop each) with 1-2 (descriptor) or 1-4 (force) FMAs
+#     behind each, the column ends, and what the pair-loop kernels also did per neighbour (geometry, cutoff function, radial
+#     functions, force assembly: 110 / 158); per atom the lane sums, power spectrum and 19 x 19 products of the descriptor pass
+#     and the coefficient table of the force pass.
+FLOP_PAIR_DESC, FLOP_NBR_DESC, FLOP_ATOM_DESC = 0.0, 19 * 5 + 171 * 7 + 18 * 6 + 110.0, 7000.0
+FLOP_PAIR_FORCE, FLOP_NBR_FORCE, FLOP_ATOM_FORCE = 0.0, 19 * 5 + 18 * 9 + 153 * 11 + 19 * 24 + 158.0, 1900.0
+#     ... and the pair-loop kernels they replaced (ANNP_HIP_FE_DESC=pairs ANNP_HIP_FE_FORCE=pairs, or a system with more than
+#     128 neighbours per atom): pass 1: cos 5, weights 3, T_2..T_18 recurrence + accumulate 68; pass 3: cos 5, Horner P 36 +
+#     dP 34, dP fc_b 1, a-side 8, b-side 4
+PAIRLOOP_FLOP = {"desc": (76.0, 110.0, 0.0), "force": (88.0, 158.0, 0.0)}
 FLOP_MLP = 2500.0
 # (b) SURVEY.md 8d's budget for the reference formulation (T and T' recurrences for every function in both
 #     passes): 350 flop per pair + 175 per neighbour + 1.6 k = 2.20 MFLOP per atom-step at n = 112
 SURVEY_FLOP_PAIR, SURVEY_FLOP_NBR, SURVEY_FLOP_MLP = 350.0, 175.0, 1600.0
-BYTES_ATOM_STEP = 9960.0                          # gathered bytes per atom-step
+BYTES_ATOM_STEP = 9960.0 + 2 * 368 * 8            # gathered bytes per atom-step + the moments written and read back
 PEAK_FP64_VECTOR = 78.6                           # TFLOP/s, MI355X (MI355X_MICROARCH.md: half of FP32 vector 157.3)
 PEAK_HBM = 8000.0                                 # GB/s spec
 # Ni (Behler G2/G4), counted from the kernels: per candidate (j,k) pair the distance pre-pass of the descriptor
@@ -434,8 +443,12 @@ def run_rank(args):
     n = counts.astype(np.float64)
     pairs = float((n * (n - 1) / 2).sum())
     nbrs = float(n.sum())
-    flop_force = pairs * FLOP_PAIR_FORCE + nbrs * FLOP_NBR_FORCE
-    flop_desc = pairs * FLOP_PAIR_DESC + nbrs * FLOP_NBR_DESC
+    pair_loop = (os.environ.get("ANNP_HIP_FE_FORCE") == "pairs" or os.environ.get("ANNP_HIP_FE_DESC") == "pairs" or
+                 (n.size and n.max() > 128))
+    fpd, fnd, fad = PAIRLOOP_FLOP["desc"] if (pair_loop or os.environ.get("ANNP_HIP_FE_DESC") == "pairs") else (FLOP_PAIR_DESC, FLOP_NBR_DESC, FLOP_ATOM_DESC)
+    fpf, fnf, faf = PAIRLOOP_FLOP["force"] if pair_loop else (FLOP_PAIR_FORCE, FLOP_NBR_FORCE, FLOP_ATOM_FORCE)
+    flop_force = pairs * fpf + nbrs * fnf + nlocal * faf
+    flop_desc = pairs * fpd + nbrs * fnd + nlocal * fad
     flop_eval = flop_force + flop_desc + nlocal * FLOP_MLP
     flop_survey = pairs * SURVEY_FLOP_PAIR + nbrs * SURVEY_FLOP_NBR + nlocal * SURVEY_FLOP_MLP
     if wl == "ni":
@@ -493,11 +506,11 @@ def run_rank(args):
             dist.destroy_process_group()
         return
     achieved = flop_force / (force_ms * 1e-3) / 1e12
-    traffic, traffic_src = _pmc_traffic("annp_fe_force", natoms if world == 1 else None)
+    traffic, traffic_src = _pmc_traffic("annp_fe_force<" if pair_loop else "annp_fe_force_sh", natoms if world == 1 else None)
     out["kernel_ms"] = {"descriptor": desc_ms, "network": mlp_ms, "force": force_ms, "evaluation": float(ms4[3]), "samples": int(ns.value),
                         "rank": 0}
     out["roofline"] = {
-            "kernel": "annp_fe_force<9,19>",
+            "kernel": "annp_fe_force<9,19> (pair loop)" if pair_loop else "annp_fe_force_sh<9,19>",
             "bound": "fp64_valu",
             "achieved": achieved,
             "peak": PEAK_FP64_VECTOR,
@@ -505,17 +518,18 @@ def run_rank(args):
             "frac": achieved / PEAK_FP64_VECTOR,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_flop_per_launch": flop_force,
-            "flop_per_unit": {"pair": FLOP_PAIR_FORCE, "neighbour": FLOP_NBR_FORCE},
+            "flop_per_unit": {"pair": fpf, "neighbour": fnf, "atom": faf},
             "descriptor_pass": {"achieved": flop_desc / (desc_ms * 1e-3) / 1e12, "frac": flop_desc / (desc_ms * 1e-3) / 1e12 / PEAK_FP64_VECTOR},
             "whole_evaluation": {"achieved": flop_eval / (float(ms4[3]) * 1e-3) / 1e12,
                                  "frac": flop_eval / (float(ms4[3]) * 1e-3) / 1e12 / PEAK_FP64_VECTOR,
                                  "flop_per_atom_step": flop_eval / nlocal},
             "survey_budget": {"flop_per_atom_step": flop_survey / nlocal,
                               "equivalent_TFLOPs": flop_survey / (float(ms4[3]) * 1e-3) / 1e12,
-                              "note": "SURVEY.md 8d prices the reference formulation (2.20 MFLOP per atom-step); the kernels reach "
-                                      "the same result with about half of that, so this figure is not a pipe utilisation"},
+                              "note": "SURVEY.md 8d prices the reference formulation (2.20 MFLOP per atom-step, O(n^2) pairs per atom); the "
+                                      "kernels reach the same result from the moments of the neighbourhood with about a fifth of that, so "
+                                      "this figure is not a pipe utilisation"},
             "hbm": {"achieved_GBps": nlocal * BYTES_ATOM_STEP / (float(ms4[3]) * 1e-3) / 1e9, "peak_GBps": PEAK_HBM,
-                    "note": "9.96 KB gathered per atom-step over the whole evaluation; the path is FP64-VALU bound, not HBM bound"},
+                    "note": "%.1f KB per atom-step over the whole evaluation; the path is FP64-VALU bound, not HBM bound" % (BYTES_ATOM_STEP / 1e3)},
     }
     if world > 1:
         out["roofline"]["note"] = "rank 0's launches (its %d owned atoms)" % nlocal
@@ -533,9 +547,9 @@ def run_rank(args):
     elif wl == "anna":
         dd = flop_desc / (desc_ms * 1e-3) / 1e12
         out["roofline"] = {
-            "kernel": "annp_fe_desc<9,19> (descriptor pass of pair_style anna_adp)", "bound": "fp64_valu",
+            "kernel": "annp_fe_desc_sh<9,19> (descriptor pass of pair_style anna_adp)", "bound": "fp64_valu",
             "achieved": dd, "peak": PEAK_FP64_VECTOR, "unit": "TFLOP/s", "frac": dd / PEAK_FP64_VECTOR, "traffic": None,
-            "algorithmic_flop_per_launch": flop_desc, "flop_per_unit": {"pair": FLOP_PAIR_DESC, "neighbour": FLOP_NBR_DESC},
+            "algorithmic_flop_per_launch": flop_desc, "flop_per_unit": {"pair": fpd, "neighbour": fnd, "atom": fad},
             "note": "the second kernel (network + ADP sums + forces, no pair loop) is bound by its scattered force atomics "
                     "and memory latency, not by arithmetic (DESIGN.md 4.4b)"}
     # ---- CPU baseline (rank 0, N = 1 only) ------------------------------------------------
