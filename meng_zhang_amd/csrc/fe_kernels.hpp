@@ -115,7 +115,7 @@ __device__ __forceinline__ int fe_compact(const FeArgs &p, int i, int lane, doub
         }
         if (p.type) {          // wave-uniform: only potentials with an unmapped type pay for the gather
 #pragma unroll
-            for (int u = 0; u < 4; u++) valid[u] = valid[u] && type_mapped(p.active, p.type[j[u]]);
+            for (int u = 0; u < 4; u++) { const int tj = p.type[j[u]]; valid[u] = valid[u] & type_mapped(p.active, tj); }      // (unconditional load)
         }
         double dx[4], dy[4], dz[4];
 #pragma unroll

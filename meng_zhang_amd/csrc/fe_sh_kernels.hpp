@@ -27,6 +27,8 @@
 // An atom with more in-cutoff neighbours than the state area holds (n_cap, at most 128) is queued for
 // annp_fe_desc_fixup (the pair-loop kernel with room for a whole list row) instead.
 #pragma once
+#include <type_traits>
+
 #include "fe_kernels.hpp"
 #include "sh_tables.hpp"
 
@@ -182,29 +184,29 @@ __device__ __forceinline__ void sh_column(const ShLane &w, ShRegs &st)
     const double *kp = annp_sh_kappa + SH_COL_OFF[M] + w.jrev;
     const double kap0 = kp[0], kap1 = NB > 1 ? kp[16] : 0.0, kap2 = NB > 2 ? kp[32] : 0.0;
     double ac[K], as[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) { ac[k] = 0.0; as[k] = 0.0; }
-    // one neighbour: Pm_k(z), k = 0..K-1, times its power (cx, cy) = fc (x+iy)^M into the accumulators
-    auto neighbour = [&](const double z, const double cx, const double cy) {
-        ac[0] += cx;
-        if (M > 0) as[0] += cy;
+    // one neighbour: Pm_k(z), k = 0..K-1, times its power (cx, cy) = fc (x+iy)^M into the accumulators (the first one sets them)
+    auto neighbour = [&](auto first, const double z, const double cx, const double cy) {
+        constexpr bool FIRST = decltype(first)::value;
+        ac[0] = FIRST ? cx : ac[0] + cx;
+        as[0] = (M > 0) ? (FIRST ? cy : as[0] + cy) : 0.0;
         if (K > 1) {
-            ac[1] = fma(z, cx, ac[1]);
-            if (M > 0) as[1] = fma(z, cy, as[1]);
+            ac[1] = FIRST ? z * cx : fma(z, cx, ac[1]);
+            as[1] = (M > 0) ? (FIRST ? z * cy : fma(z, cy, as[1])) : 0.0;
         }
         double P2 = 1.0, P1 = z;
 #pragma unroll
         for (int k = 2; k < K; k++) {
             const double P = fma(z, P1, -(sh_gamma(M, k) * P2));
-            ac[k] = fma(P, cx, ac[k]);
-            if (M > 0) as[k] = fma(P, cy, as[k]);
+            ac[k] = FIRST ? P * cx : fma(P, cx, ac[k]);
+            as[k] = (M > 0) ? (FIRST ? P * cy : fma(P, cy, as[k])) : 0.0;
             P2 = P1; P1 = P;
         }
     };
 #pragma unroll
     for (int r = 0; r < SH_R; r++) {
         const double cx = st.pc[r], cy = st.ps[r];
-        neighbour(st.z[r], cx, cy);
+        if (r == 0) neighbour(std::true_type{}, st.z[r], cx, cy);
+        else neighbour(std::false_type{}, st.z[r], cx, cy);
         if (M < SH_LMAX) {          // fc (x+iy)^(m+1)
             st.pc[r] = fma(cx, st.ex[r], -(cy * st.ey[r]));
             st.ps[r] = fma(cx, st.ey[r], cy * st.ex[r]);
@@ -214,17 +216,17 @@ __device__ __forceinline__ void sh_column(const ShLane &w, ShRegs &st)
     if (left > 0) {
         double2 *pa = w.SA, *pc = w.SC;
         double *pz = w.SZ;
-        // the next neighbour's state is requested before the current one is worked on.  (One slot past the last is read and
-        // dropped: it exists.)
-        double2 A = *pa, C = *pc;
+        // the next neighbour's z and power are requested before the current one is worked on (one slot past the last is read and
+        // dropped: it exists); (e_x,e_y) is only needed when the power is advanced, at the end
+        double2 C = *pc;
         double z = *pz;
         do {
-            const double2 An = pa[SH_GL], Cn = pc[SH_GL];
+            const double2 A = *pa, Cn = pc[SH_GL];
             const double zn = pz[SH_GL];
-            neighbour(z, C.x, C.y);
+            neighbour(std::false_type{}, z, C.x, C.y);
             if (M < SH_LMAX) *pc = make_double2(fma(C.x, A.x, -(C.y * A.y)), fma(C.x, A.y, C.y * A.x));
             pa += SH_GL; pc += SH_GL; pz += SH_GL;
-            A = An; C = Cn; z = zn;
+            C = Cn; z = zn;
         } while (--left > 0);
     }
     sh_batch<M, 0>(w, ac, as, kap0);
@@ -254,7 +256,7 @@ __device__ __forceinline__ FeNbr sh_geometry(double2 R0, double2 R1, double pi_o
     double sn, cs;
     sincos_0_pi_s(pi_over_rc * g.r, sn, cs);
     g.fc = 0.5 * (cs + 1.0);                    // fe:592
-    g.dfc = 0.0;
+    g.dfc = -0.5 * pi_over_rc * sn;             // fe:593
     return g;
 }
 
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
 #pragma unroll
             for (int ga = 0; ga < SH_GA; ga++)
 #pragma unroll
-                for (int u = 0; u < 4; u++) valid[ga][u] = valid[ga][u] && type_mapped(p.active, p.type[j[ga][u]]);
+                for (int u = 0; u < 4; u++) { const int tj = p.type[j[ga][u]]; valid[ga][u] = valid[ga][u] & type_mapped(p.active, tj); }
         }
         double qx[SH_GA][4], qy[SH_GA][4], qz[SH_GA][4];
 #pragma unroll
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
                 const int jj = c0 + lane;
                 bool ok = jj < jn;
                 const int jx = row[min(jj, jn - 1)] & ANNP_NEIGHMASK;
-                if (p.type) ok = ok && type_mapped(p.active, p.type[jx]);
+                if (p.type) { const int tj = p.type[jx]; ok = ok & type_mapped(p.active, tj); }
                 const double dx = xi - p.x[3 * (size_t)jx], dy = yi - p.x[3 * (size_t)jx + 1], dz = zi - p.x[3 * (size_t)jx + 2];
                 const double rsq = dx * dx + dy * dy + dz * dz;
                 const bool in = ok && !(rsq > p.cutsq) && !(rsq < 1.0e-12);

@@ -467,7 +467,7 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
 #pragma unroll
             for (int ga = 0; ga < NI_GA; ga++)
 #pragma unroll
-                for (int u = 0; u < 2; u++) valid[ga][u] = valid[ga][u] && type_mapped(p.active, p.type[j[ga][u]]);
+                for (int u = 0; u < 2; u++) { const int tj = p.type[j[ga][u]]; valid[ga][u] = valid[ga][u] & type_mapped(p.active, tj); }
         }
         double qx[NI_GA][2], qy[NI_GA][2], qz[NI_GA][2];
 #pragma unroll
@@ -525,7 +525,7 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
             }
             if (p.type) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) valid[u] = valid[u] && type_mapped(p.active, p.type[j[u]]);
+                for (int u = 0; u < 4; u++) { const int tj = p.type[j[u]]; valid[u] = valid[u] & type_mapped(p.active, tj); }      // (unconditional load)
             }
             double dx[4], dy[4], dz[4];
 #pragma unroll
