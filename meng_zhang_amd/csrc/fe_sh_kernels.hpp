@@ -1,4 +1,5 @@
-// fe_sh_kernels.hpp -- the Chebyshev descriptor pass (fe_v2/src/pair_annp.cpp:633-695, "fe:") without a pair loop.
+// fe_sh_kernels.hpp -- the Chebyshev passes (fe_v2/src/pair_annp.cpp:633-695 and 190-213, "fe:") without a pair loop:
+// annp_fe_desc_sh (descriptor pass) and annp_fe_force_sh (force pass, second half of this file).
 //
 // The angular functions are sums over the n(n-1)/2 neighbour pairs of a polynomial of cos(theta_ab) = e_a . e_b:
 //     G_{9+n} = sum_{a<b} fc_a fc_b T_n((e_a.e_b + 1)/2)                                                     (fe:671-678)
@@ -13,18 +14,18 @@
 // measured difference to the pair loop: a few 1e-13 relative), for 112 x 190 recurrence steps instead of 6 216 x 17.
 // The T_0 / T_1 closed forms of annp_fe_desc are the l = 0, 1 cases of this.
 //
-// Work decomposition: a wave takes FOUR atoms, 16 lanes each; a lane owns neighbours l, l+16, l+32, .. of its atom.
-//   stage A  the four list rows are filtered one after the other by the whole wave (fe_compact), raw entries straight into
-//            the atom's state area in LDS; then every lane turns its entries into (e_x,e_y), z, (fc,0) -- the running power
-//            fc (x+iy)^m starts at m = 0 -- and sums the radial functions.
-//   columns  m = 0..18, unrolled: a lane walks its neighbours (run-time loop, state from LDS), runs the recurrence in
-//            l = m..18 (2 instructions per step, the constant a literal) and adds Pm (x+iy)^m fc into its 2(19-m)
-//            accumulators (2 per step); the power is advanced and written back.  Then the accumulators are summed over the
-//            16 lanes -- a transposing butterfly on DPP moves: 16 registers x 16 lanes -> one register whose 16 lanes hold
-//            the 16 totals, ~5 instructions per total for four atoms at once -- scaled by sqrt(kappa), squared and added to
-//            pw_l in LDS.
+// Work decomposition of the descriptor pass: a wave takes FOUR atoms, 16 lanes each; a lane owns neighbours l, l+16, l+32, ..
+// of its atom, the first three in registers (ShRegs), the others in LDS.
+//   stage A  headers of the four atoms, the index loads of all four list rows, all coordinate gathers (two dependent round
+//            trips through memory for the wave), ballot compaction row by row; every lane turns its raw entries into
+//            (e_x,e_y), z, (fc,0) -- the running power fc (x+iy)^m starts at m = 0 -- and sums the radial functions.
+//   columns  m = 0..18, unrolled: a lane walks its neighbours, runs the recurrence in l = m..18 (2 instructions per step, the
+//            constant a literal) and adds Pm (x+iy)^m fc into its 2(19-m) accumulators (2 per step); the power is advanced.
+//            Then the accumulators are summed over the atom's 16 lanes -- a transposing butterfly: 16 registers x 16 lanes
+//            -> one register whose 16 lanes hold the 16 totals, ~3.6 instructions per total for four atoms at once -- and
+//            kappa |A|^2 is added to pw_l in LDS; the scaled moments go to HBM for the force pass.
 //   final    lane n of an atom: G_{9+n} from the 19 pw_l (q from constant memory), the radial sums, one 32-double row out.
-// An atom with more in-cutoff neighbours than the state area holds (n_cap, at most 128) is queued for
+// An atom with more in-cutoff neighbours than the launch has state for (n_cap, at most 128) is queued for
 // annp_fe_desc_fixup (the pair-loop kernel with room for a whole list row) instead.
 #pragma once
 #include <type_traits>
