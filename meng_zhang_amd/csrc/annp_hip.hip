@@ -147,7 +147,7 @@ struct annp_hip_handle {
     std::vector<double> sym_rad, sym_ang;
     // work buffers
     DevBuf<double> G, coef, x, f, eatom, vatom, mom;        // mom: moments of the neighbourhoods, descriptor pass -> force pass (fe_sh_kernels.hpp)
-    DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ni_npair, ni_fix_nbr, ovf, ovf_desc;
+    DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ni_npair, ni_fix_nbr, ovf, ovf_desc, fe_nbrs;
     DevBuf<unsigned short> ni_pairs;    // Behler: in-range (j,k) pairs per atom, descriptor pass -> force pass
     DevBuf<long long> first;
     double *d_scalars = nullptr;        // [0] energy, [1..6] virial
@@ -539,8 +539,8 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         const bool sh_force = !h->fe_desc_pairs && !h->fe_force_pairs && !h->fe_dense && fix_possible;
         h->fe_last_sh = sh_force; h->fe_last_inum = inum;
         if (sh_force) {
-            if ((rc = ensure(h, h->mom, (size_t)inum * SH_MPAD))) return rc;
-            a.A = h->mom.p;
+            if ((rc = ensure(h, h->mom, (size_t)inum * SH_MPAD)) || (rc = ensure(h, h->fe_nbrs, (size_t)inum * SH_CAP_MAX))) return rc;
+            a.A = h->mom.p; a.nbrs = h->fe_nbrs.p;
         }
         if ((rc = launch_fe_desc(h, a, inum, cap_list, max_numneigh, s))) return rc;
         hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);

@@ -62,6 +62,7 @@ struct FeArgs {
     // moment form (fe_sh_kernels.hpp): the 361 moments of every atom's neighbourhood, [inum][SH_MPAD]; written by
     // annp_fe_desc_sh when given, read by annp_fe_force_sh
     double *A;
+    int *nbrs;                 // nullable [inum][128]: the in-cutoff neighbours of every atom in list order, annp_fe_desc_sh -> annp_fe_force_sh
     int dbg;                   // developer switches (ANNP_HIP_DBG): 1 = annp_fe_force_sh skips the neighbour atomics, 2 = skips the columns
 };
 

@@ -303,7 +303,8 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int jn_all = max(max(__builtin_amdgcn_readlane(hjn, 0), __builtin_amdgcn_readlane(hjn, 1)),
                            max(__builtin_amdgcn_readlane(hjn, 2), __builtin_amdgcn_readlane(hjn, 3)));
-    auto keep = [&](int ga, int pos, double dx, double dy, double dz, double rsq) {      // entry `pos` of row ga
+    auto keep = [&](int ga, int pos, int jat, double dx, double dy, double dz, double rsq) {      // entry `pos` of row ga: atom jat
+        if (p.nbrs && pos < cap) p.nbrs[(size_t)(ii0 + ga) * SH_CAP_MAX + pos] = jat;      // (the force pass does not filter the row again)
         if (pos < SH_GL * SH_R) { stA[pos] = make_double2(dx, dy); stB[pos] = make_double2(dz, rsq); }
         else if (pos < cap) { SA[ga * PL + pos - SH_GL * SH_R] = make_double2(dx, dy); SC[ga * PL + pos - SH_GL * SH_R] = make_double2(dz, rsq); }
     };
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
                 const double rsq = dx * dx + dy * dy + dz * dz;
                 const bool in = valid[ga][u] && !(rsq > p.cutsq) && !(rsq < 1.0e-12);        // fe:144
                 const unsigned long long m = __ballot(in);
-                if (in) keep(ga, n + __popcll(m & lt), dx, dy, dz, rsq);
+                if (in) keep(ga, n + __popcll(m & lt), j[ga][u], dx, dy, dz, rsq);
                 n += __popcll(m);
             }
             settle(ga, uniform(n), __builtin_amdgcn_readlane(hjn, ga) < 0);
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
                 const double rsq = dx * dx + dy * dy + dz * dz;
                 const bool in = ok && !(rsq > p.cutsq) && !(rsq < 1.0e-12);
                 const unsigned long long m = __ballot(in);
-                if (in) keep(ga, n + __popcll(m & lt), dx, dy, dz, rsq);
+                if (in) keep(ga, n + __popcll(m & lt), jx, dx, dy, dz, rsq);
                 n += __popcll(m);
             }
             settle(ga, uniform(n), jn < 0);
@@ -682,7 +683,9 @@ __device__ __forceinline__ void shf_atom(const FeArgs &p, const int ii, const in
             te_a[t][3] = m > 1 ? Am[id + K + 1] : 0.0;
         }
     }
-    const int n = fe_compact<true>(p, i, lane, recA, recB, auxJ, 128);
+    // the in-cutoff neighbours: from the descriptor pass's list (count and indices, list order) or by filtering the row again
+    const bool listed = p.nbrs != nullptr;
+    const int n = listed ? uniform(p.ncount[ii]) : fe_compact<true>(p, i, lane, recA, recB, auxJ, 128);
     if (n > p.n_cap) {            // no moments for this atom (or more neighbours than two per lane): the pair loop takes it
         if (lane == 0) {
             const int k = p.ovf_list ? atomicAdd(p.ovf_count, 1) : p.ovf_cap;
@@ -701,11 +704,25 @@ __device__ __forceinline__ void shf_atom(const FeArgs &p, const int ii, const in
         double cr[NP];
 #pragma unroll
         for (int m = 0; m < NP; m++) cr[m] = cf[m];
+        const int *myrow = p.nbrs + (size_t)ii * SH_CAP_MAX;
+        int jl[2] = {i, i};
+        if (listed) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) jl[u] = myrow[min(lane + 64 * u, max(n, 1) - 1)];
+        }
+        const double xi = p.x[3 * (size_t)i], yi = p.x[3 * (size_t)i + 1], zi = p.x[3 * (size_t)i + 2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int a = lane + 64 * u;
             const bool has = a < n;
-            const double2 R0 = has ? recA[a] : make_double2(0.0, 0.0), R1 = has ? recB[a] : make_double2(1.0, 1.0);
+            double2 R0, R1;
+            if (listed) {
+                const double dx = xi - p.x[3 * (size_t)jl[u]], dy = yi - p.x[3 * (size_t)jl[u] + 1], dz = zi - p.x[3 * (size_t)jl[u] + 2];
+                R0 = make_double2(dx, dy); R1 = make_double2(dz, dx * dx + dy * dy + dz * dz);
+                if (!has) { R0 = make_double2(0.0, 0.0); R1 = make_double2(1.0, 1.0); }
+            } else {
+                R0 = has ? recA[a] : make_double2(0.0, 0.0); R1 = has ? recB[a] : make_double2(1.0, 1.0);
+            }
             const FeNbr g = fe_geometry(R0, R1, pi_over_rc);
             const double xr = g.r * two_over_rcp - 1.0;
             const double y2 = 2.0 * xr;
@@ -772,7 +789,7 @@ __device__ __forceinline__ void shf_atom(const FeArgs &p, const int ii, const in
             const double g0 = fma(t, q.ex, -V0 * rinv[u]);
             const double g1 = fma(t, q.ey, -V1 * rinv[u]);
             const double g2 = fma(t, q.z, -V2 * rinv[u]);
-            const int j = auxJ[lane + 64 * u];
+            const int j = listed ? p.nbrs[(size_t)ii * SH_CAP_MAX + lane + 64 * u] : auxJ[lane + 64 * u];
             if (!(p.dbg & 1)) tab.add(j, -g0, -g1, -g2);
             fi0 += g0; fi1 += g1; fi2 += g2;
             if (VIRIAL) {   // ev_tally_xyz(i,j,...,fx=-Fj, del = xi-xj = r e)   (fe:201-209)
