@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
             valid[u] = jj < jn;
             int raw;
             if (have_row && c0 == 0 && u < 3) raw = u == 0 ? pj0 : (u == 1 ? pj1 : pj2);
-            else raw = valid[u] ? row[jj] : 0;
+            else raw = row[min(jj, jn - 1)];        // (unconditional, clamped: a load under `valid ? .. : ..` becomes a branch with its own wait)
             j[u] = valid[u] ? (raw & ANNP_NEIGHMASK) : 0;
         }
         double dx[4], dy[4], dz[4];
