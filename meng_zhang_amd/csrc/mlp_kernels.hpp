@@ -210,7 +210,13 @@ __global__ __launch_bounds__(64 * MLP_WAVES_PER_BLOCK) void annp_mlp_mfma(MlpArg
     {
         const double2 *src = reinterpret_cast<const double2 *>(p.img);
         double2 *dst = reinterpret_cast<double2 *>(opnd);
-        for (int idx = threadIdx.x; idx < S::total * 32; idx += 64 * MLP_WAVES_PER_BLOCK) dst[idx] = src[idx];
+        // (all of a thread's loads first, then its stores: one round trip through memory, not one per 16 bytes)
+        constexpr int NT = 64 * MLP_WAVES_PER_BLOCK, PER = (S::total * 32 + NT - 1) / NT;
+        double2 tmp[PER];
+#pragma unroll
+        for (int t = 0; t < PER; t++) { const int idx = threadIdx.x + t * NT; tmp[t] = src[idx < S::total * 32 ? idx : 0]; }
+#pragma unroll
+        for (int t = 0; t < PER; t++) { const int idx = threadIdx.x + t * NT; if (idx < S::total * 32) dst[idx] = tmp[t]; }
     }
     __syncthreads();
     ActParam ap[NL];
@@ -371,8 +377,18 @@ __global__ __launch_bounds__(64 * MLP_WAVES_PER_BLOCK) void annp_mlp_mfma(MlpArg
         }
     }
     if (p.eng) {
+        // one atomic per workgroup on the energy word, not one per wave: thousands of atomics on a single address are served
+        // one after the other (40 us of a 73 us launch at 128 000 atoms)
         e_wave = wave_sum(e_wave);
-        if (lane == 0 && e_wave != 0.0) atomicAdd(p.eng, e_wave);
+        __syncthreads();                    // every wave is done with the operand image: its first doubles carry the sums
+        if (lane == 0) opnd[wave] = e_wave;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double e = 0.0;
+#pragma unroll
+            for (int w = 0; w < MLP_WAVES_PER_BLOCK; w++) e += opnd[w];
+            if (e != 0.0) atomicAdd(p.eng, e);
+        }
     }
 }
 
