@@ -349,8 +349,9 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
         v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
         if (lane == 0) {
             if (p.virial) {
-                atomicAdd(&p.virial[0], v0); atomicAdd(&p.virial[1], v1); atomicAdd(&p.virial[2], v2);
-                atomicAdd(&p.virial[3], v3); atomicAdd(&p.virial[4], v4); atomicAdd(&p.virial[5], v5);
+                double *vr = virial_row(p.virial);          // (annp_common.hpp: the global virial)
+                atomicAdd(&vr[0], v0); atomicAdd(&vr[1], v1); atomicAdd(&vr[2], v2);
+                atomicAdd(&vr[3], v3); atomicAdd(&vr[4], v4); atomicAdd(&vr[5], v5);
             }
             if (p.vatom) {
                 double *vi = p.vatom + 6 * (size_t)i;

@@ -150,6 +150,7 @@ struct annp_hip_handle {
     DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ni_npair, ni_fix_nbr, ovf, ovf_desc, fe_nbrs;
     DevBuf<unsigned short> ni_pairs;    // Behler: in-range (j,k) pairs per atom, descriptor pass -> force pass
     DevBuf<long long> first;
+    double *d_vslots = nullptr;         // [ANNP_VSLOTS][8]: where the kernels tally the global virial (annp_common.hpp), folded per evaluation
     double *d_scalars = nullptr;        // [0] energy, [1..6] virial
     int *d_flags = nullptr;             // [0] capacity error: max n of the atoms that were skipped (stays set until the host has
                                         //     seen it), [1] max in-cutoff n, [2] length of the force fix-up queue, [3] of the descriptor fix-up queue; [1..3] per evaluation
@@ -512,6 +513,11 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     }
 
     const int cap_list = std::max(16, round_up(max_numneigh, 16));
+    double *vtab = nullptr;             // the global virial is tallied here and folded into d_virial at the end
+    if (d_virial) {
+        vtab = h->d_vslots;
+        HIP_TRY(h, hipMemsetAsync(vtab, 0, sizeof(double) * 8 * ANNP_VSLOTS, s));
+    }
 
     if (h->multi && !d_type)
         return fail(h, ANNP_HIP_EARG, "this potential distinguishes atom types (several elements or an unmapped type): d_type is required");
@@ -530,7 +536,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
         a.cutsq = h->cutsq; a.rc_list = std::sqrt(h->cutsq); a.rc_par = h->cut;
         a.type = types; a.active = h->active;
-        a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.vatom = d_vatom; a.ncount = h->ncount.p;
+        a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = vtab; a.vatom = d_vatom; a.ncount = h->ncount.p;
         a.errflag = h->d_flags;
         a.dbg = h->fe_dbg;
         // pass 1 (and, for the force pass on the moments, their buffer; that pass needs the fix-up launch behind it)
@@ -629,7 +635,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         for (int l = 0; l < h->nl; l++) q.actp |= (unsigned)(h->flagact[l] & 15) << (4 * l);
         for (int k = 0; k < 17; k++) q.gp[k] = h->gp[k];
         q.e_base = h->e_base;
-        q.f = d_f; q.eatom = d_eatom; q.eng = d_eng; q.virial = d_virial; q.vatom = d_vatom; q.errflag = h->d_flags;
+        q.f = d_f; q.eatom = d_eatom; q.eng = d_eng; q.virial = vtab; q.vatom = d_vatom; q.errflag = h->d_flags;
         const size_t lds2 = anna_lds_per_wave(q.n_cap) * ANNP_WAVES_PER_BLOCK + anna_lds_net(h->net_doubles);
         if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
         if (d_virial || d_vatom) hipLaunchKernelGGL((annp_anna_adp<true>), dim3(anna_blocks(inum)), dim3(256), lds2, s, q);
@@ -645,7 +651,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.type = types; a.active = h->active;
         a.rc_rad = h->sym_rad[2]; a.rc_ang = h->sym_ang[3];
         a.rad_em = h->ni_rad_em;
-        a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = d_virial; a.vatom = d_vatom; a.ncount = h->ncount.p; a.errflag = h->d_flags;
+        a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = vtab; a.vatom = d_vatom; a.ncount = h->ncount.p; a.errflag = h->d_flags;
         if (a.npsf > NI_MAXP || a.ntsf > NI_MAXT)
             return fail(h, ANNP_HIP_ESHAPE, "Behler kernels support npsf<=%d ntsf<=%d", NI_MAXP, NI_MAXT);
         const int cap_max = ni_max_cap(true, h->nsf);
@@ -707,6 +713,10 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         ni_launch_force(a, h->ni_shape, d_virial != nullptr || d_vatom != nullptr, s);
         HIP_TRY(h, hipGetLastError());
         if (fixup) { ni_launch_force_fix(b, h->ni_shape, d_virial != nullptr || d_vatom != nullptr, s); HIP_TRY(h, hipGetLastError()); }
+    }
+    if (vtab) {
+        hipLaunchKernelGGL(annp_virial_fold, dim3(1), dim3(1024), 0, s, vtab, d_virial);
+        HIP_TRY(h, hipGetLastError());
     }
     // flag words of this evaluation, for whoever looks next (poll_flags)
     HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -831,6 +841,7 @@ void annp_hip_clear(annp_hip_handle *h)
     release(h, h->first);
     neigh_release(h->nb);
     if (h->d_scalars) (void)hipFree(h->d_scalars);
+    if (h->d_vslots) (void)hipFree(h->d_vslots);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     if (h->ev_flags) (void)hipEventDestroy(h->ev_flags);
@@ -1135,11 +1146,12 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         h->bytes += sizeof(double) * t.size() + sizeof(int) * it.size();
     }
     INIT_TRY(hipMalloc((void **)&h->d_scalars, 8 * sizeof(double)));
+    INIT_TRY(hipMalloc((void **)&h->d_vslots, sizeof(double) * 8 * ANNP_VSLOTS));
     INIT_TRY(hipMalloc((void **)&h->d_flags, 4 * sizeof(int)));
     INIT_TRY(hipMemset(h->d_flags, 0, 4 * sizeof(int)));
     INIT_TRY(hipHostMalloc((void **)&h->h_flags, 4 * sizeof(int)));
     INIT_TRY(hipHostMalloc((void **)&h->h_scalars, 8 * sizeof(double)));
-    h->bytes += 8 * sizeof(double) + 4 * sizeof(int);
+    h->bytes += 8 * sizeof(double) + 4 * sizeof(int) + sizeof(double) * 8 * ANNP_VSLOTS;
     // kernels may ask for the whole LDS
     {
         const int full = 160 * 1024;

@@ -50,7 +50,7 @@ struct FeArgs {
     double *G;                 // [inum][ANNP_GPAD] raw sums (pass 1 out)
     const double *coef;        // [inum][ANNP_CPAD] (pass 2 in)
     double *f;                 // [nall][3] accumulated
-    double *virial;            // nullable, 6 doubles accumulated
+    double *virial;            // nullable: the evaluation's virial table [ANNP_VSLOTS][8] (annp_common.hpp), accumulated into
     double *vatom;             // nullable, [nall][6] accumulated (needs the VIRIAL kernel variant)
     int *ncount;               // nullable [inum]: in-cutoff neighbour count
     int *errflag;              // device int: max n seen when n > n_cap and nothing can take the atom over
@@ -619,8 +619,9 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
         v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
         if (lane == 0) {
             if (p.virial) {
-                atomicAdd(&p.virial[0], v0); atomicAdd(&p.virial[1], v1); atomicAdd(&p.virial[2], v2);
-                atomicAdd(&p.virial[3], v3); atomicAdd(&p.virial[4], v4); atomicAdd(&p.virial[5], v5);
+                double *vr = virial_row(p.virial);          // (annp_common.hpp: the global virial)
+                atomicAdd(&vr[0], v0); atomicAdd(&vr[1], v1); atomicAdd(&vr[2], v2);
+                atomicAdd(&vr[3], v3); atomicAdd(&vr[4], v4); atomicAdd(&vr[5], v5);
             }
             if (p.vatom) {
                 double *vi = p.vatom + 6 * (size_t)i;

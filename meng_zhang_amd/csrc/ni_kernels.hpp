@@ -1090,8 +1090,9 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
                 v3 += __shfl_xor(v3, off, 64); v4 += __shfl_xor(v4, off, 64); v5 += __shfl_xor(v5, off, 64);
             }
             if (lane == 0) {
-                atomicAdd(&p.virial[0], v0); atomicAdd(&p.virial[1], v1); atomicAdd(&p.virial[2], v2);
-                atomicAdd(&p.virial[3], v3); atomicAdd(&p.virial[4], v4); atomicAdd(&p.virial[5], v5);
+                double *vr = virial_row(p.virial);          // (annp_common.hpp: the global virial)
+                atomicAdd(&vr[0], v0); atomicAdd(&vr[1], v1); atomicAdd(&vr[2], v2);
+                atomicAdd(&vr[3], v3); atomicAdd(&vr[4], v4); atomicAdd(&vr[5], v5);
             }
         }
     }

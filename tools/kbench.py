@@ -2,7 +2,8 @@
 """Developer tool: kernel timings (HIP events) of one force evaluation for a synthetic box.
    python tools/kbench.py fe 80      # bcc Fe, 80^3 cells
    python tools/kbench.py ni 40 40 80  # fcc Ni 40x40x80 cells (512 000 atoms)
-   python tools/kbench.py anna 80      # bcc Fe, pair_style anna_adp (list cutoff 5.055 + 2 A)"""
+   python tools/kbench.py anna 80      # bcc Fe, pair_style anna_adp (list cutoff 5.055 + 2 A)
+   KBENCH_VIRIAL=1 python tools/kbench.py fe 80     # with the global virial tallied (vflag_global of an NPT step)"""
 import ctypes as C
 import os
 import sys
@@ -58,11 +59,12 @@ def main():
         tb.append((time.perf_counter() - t0) * 1e3)
     print("list builds (host clock, ms): first %.2f, rebuilds %s" % (tb[0], " ".join("%.2f" % v for v in tb[1:])))
     eng = torch.zeros(1, dtype=torch.float64, device=dev)
+    vir = torch.zeros(6, dtype=torch.float64, device=dev) if os.environ.get("KBENCH_VIRIAL") else None
     lib.annp_hip_set_timing(h, 1)
     for _ in range(reps + 1):
         dom.f.zero_()
         eng.zero_()
-        rc = lib.annp_hip_compute_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value, dom.f.data_ptr(), None, eng.data_ptr(), None, None, st)
+        rc = lib.annp_hip_compute_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value, dom.f.data_ptr(), None, eng.data_ptr(), vir.data_ptr() if vir is not None else None, None, st)
         assert rc == 0, lib.annp_hip_last_error(h)
     ms = np.zeros(4)
     ns = C.c_int(0)
