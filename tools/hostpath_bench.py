@@ -51,6 +51,17 @@ def main():
             e = p.compute_n(cutneigh=8.5, eflag=1, vflag=0, eflag_atom=False)
             dt += (time.perf_counter() - t) / k
         print("%-20s %.1f ms per call -> %.2f M atom-steps/s   E/atom %.6f" % (label, dt * 1e3, s.nlocal / dt / 1e6, e / s.nlocal))
+    # what an NPT step asks for (global virial) and what a step with per-atom energies asks for
+    for label, kw in (("compute_n ago>0 vflag", dict(vflag=1, eflag_atom=False)), ("compute_n ago>0 eatom", dict(vflag=0, eflag_atom=True))):
+        dt = 0.0
+        for _ in range(4):
+            p.atom.f[:] = 0.0
+            if p.eatom is not None:
+                p.eatom[:] = 0.0
+            t = time.perf_counter()
+            e = p.compute_n(cutneigh=8.5, eflag=1, **kw)
+            dt += (time.perf_counter() - t) / 4
+        print("%-22s %.1f ms per call -> %.2f M atom-steps/s   E/atom %.6f" % (label, dt * 1e3, s.nlocal / dt / 1e6, e / s.nlocal))
     if os.environ.get("ANNP_HIP_REGISTER") != "0":
         print("(caller's x and f page-locked in place; ANNP_HIP_REGISTER=0 for the staging route)")
     p.close()
