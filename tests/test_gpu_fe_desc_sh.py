@@ -147,3 +147,21 @@ def test_list_rows_longer_than_256_entries(fe_pot):
     assert (np.abs(ra["rows"] - rb["rows"]) / scale).max() < 2e-12
     o = oracle_compute(fe_pot, s, KIND_FE, FAST)
     assert abs(ra["e"] - o["energy"]) < 1e-6 and np.abs(ra["f"] - o["f"]).max() < 1e-9 * max(1.0, np.abs(o["f"]).max())
+
+
+@pytest.mark.parametrize("env", [dict(ANNP_HIP_FE_FORCE="pairs"), dict(ANNP_HIP_FE_DESC="pairs")])
+def test_one_pass_on_the_moments_the_other_on_the_pairs(fe_pot, env):
+    """the switches are independent: moment descriptor pass + pair-loop force pass, and the pair-loop descriptor pass (which
+    leaves no moments, so the force pass is the pair loop too)"""
+    x0, box = bcc(6, 5, 4, A_FE)
+    s = System(perturb(x0, 5, 0.15), box)
+    a = make_pair(**env)
+    try:
+        r1 = evaluate(a, s)
+        a.eatom[:] = 0.0
+        r2 = evaluate(a, s)
+    finally:
+        a.close()
+    o = oracle_compute(fe_pot, s, KIND_FE, FAST)
+    for r in (r1, r2):
+        assert abs(r["e"] - o["energy"]) < 1e-6 and np.abs(r["f"] - o["f"]).max() < 1e-9 * max(1.0, np.abs(o["f"]).max())
