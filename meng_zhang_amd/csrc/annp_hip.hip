@@ -581,40 +581,40 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
                 HIP_TRY(h, hipGetLastError());
             }
             h->cap_last = cap;
-        } else {
-        int cap3;
-        // first evaluation on this handle: read the maximum just measured, once.  Also whenever a whole list row would not
-        // fit the fix-up launch's LDS (very long rows): nothing would stand behind a stale capacity then
-        if (h->fe_cap == 0 || (!fix_possible && h->fe_cap < cap_list)) {
-            HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-            HIP_TRY(h, hipStreamSynchronize(s));
-            if (h->h_flags[0] > 0) {
-                h->reset_err = true;
-                return fail(h, ANNP_HIP_ENEIGHCAP, "in-cutoff neighbours %d exceed capacity %d", h->h_flags[0], a.n_cap);
+        } else {        // the pair-loop force pass (rounds 1-2): a dense system, ANNP_HIP_FE_FORCE=pairs, or no room for the fix-up launch
+            int cap3;
+            // first evaluation on this handle: read the maximum just measured, once.  Also whenever a whole list row would not
+            // fit the fix-up launch's LDS (very long rows): nothing would stand behind a stale capacity then
+            if (h->fe_cap == 0 || (!fix_possible && h->fe_cap < cap_list)) {
+                HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+                HIP_TRY(h, hipStreamSynchronize(s));
+                if (h->h_flags[0] > 0) {
+                    h->reset_err = true;
+                    return fail(h, ANNP_HIP_ENEIGHCAP, "in-cutoff neighbours %d exceed capacity %d", h->h_flags[0], a.n_cap);
+                }
+                cap3 = std::max(16, round_up(h->h_flags[1], 16));
+                h->fe_cap = fe_next_cap(h->h_flags[1]);
+            } else {
+                cap3 = std::min(h->fe_cap, cap_list);
             }
-            cap3 = std::max(16, round_up(h->h_flags[1], 16));
-            h->fe_cap = fe_next_cap(h->h_flags[1]);
-        } else {
-            cap3 = std::min(h->fe_cap, cap_list);
-        }
-        if ((rc = ensure(h, h->ovf, (size_t)inum))) return rc;
-        a.n_cap = cap3;
-        const bool fixup = cap3 < cap_list && fix_possible;
-        a.ovf_count = h->d_flags + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
-        if (fe_force_lds_per_wave(cap3) * fe_wpb_force() > 160 * 1024)
-            return fail(h, ANNP_HIP_ENEIGHCAP, "too many in-cutoff neighbours for LDS (%d)", cap3);
-        if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
-        if (vir) launch_fe_force<true>(a, s); else launch_fe_force<false>(a, s);
-        HIP_TRY(h, hipGetLastError());
-        if (fixup) {
-            FeArgs b = a;
-            b.n_cap = cap_list;
-            const int fblocks = std::min(inum, 1024);
-            if (vir) hipLaunchKernelGGL((annp_fe_force_fixup<FE_NP, FE_NT, true>), dim3(fblocks), dim3(64), lds_fix, s, b);
-            else hipLaunchKernelGGL((annp_fe_force_fixup<FE_NP, FE_NT, false>), dim3(fblocks), dim3(64), lds_fix, s, b);
+            if ((rc = ensure(h, h->ovf, (size_t)inum))) return rc;
+            a.n_cap = cap3;
+            const bool fixup = cap3 < cap_list && fix_possible;
+            a.ovf_count = h->d_flags + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
+            if (fe_force_lds_per_wave(cap3) * fe_wpb_force() > 160 * 1024)
+                return fail(h, ANNP_HIP_ENEIGHCAP, "too many in-cutoff neighbours for LDS (%d)", cap3);
+            if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
+            if (vir) launch_fe_force<true>(a, s); else launch_fe_force<false>(a, s);
             HIP_TRY(h, hipGetLastError());
-        }
-        h->cap_last = cap3;
+            if (fixup) {
+                FeArgs b = a;
+                b.n_cap = cap_list;
+                const int fblocks = std::min(inum, 1024);
+                if (vir) hipLaunchKernelGGL((annp_fe_force_fixup<FE_NP, FE_NT, true>), dim3(fblocks), dim3(64), lds_fix, s, b);
+                else hipLaunchKernelGGL((annp_fe_force_fixup<FE_NP, FE_NT, false>), dim3(fblocks), dim3(64), lds_fix, s, b);
+                HIP_TRY(h, hipGetLastError());
+            }
+            h->cap_last = cap3;
         }
     } else if (h->descriptor == ANNP_HIP_DESC_ANNA_ADP) {
         // pass 1: the same Chebyshev descriptor kernel, raw sums (adp:584-612 has no normalisation)
