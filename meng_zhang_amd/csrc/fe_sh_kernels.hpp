@@ -528,7 +528,7 @@ struct ShfNbr {
 
 typedef double shf_v2d __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) shf_v2d *shf_lds_ptr;
-constexpr int SHF_AHEAD = 2;
+constexpr int SHF_AHEAD = 3;
 template <int M>
 __device__ __forceinline__ void shf_column(const unsigned T, ShfNbr (&nb)[2])      // T: the table's byte address in LDS
 {
