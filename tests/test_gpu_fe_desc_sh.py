@@ -165,3 +165,29 @@ def test_one_pass_on_the_moments_the_other_on_the_pairs(fe_pot, env):
     o = oracle_compute(fe_pot, s, KIND_FE, FAST)
     for r in (r1, r2):
         assert abs(r["e"] - o["energy"]) < 1e-6 and np.abs(r["f"] - o["f"]).max() < 1e-9 * max(1.0, np.abs(o["f"]).max())
+
+
+def test_rows_do_not_depend_on_the_orientation(fe_pot):
+    """the moments single out the z axis (and x + iy), the sums they stand for do not: the same cluster in three orientations --
+    as built (lattice directions along the axes: neighbours exactly on the poles and on the equator), rotated by a random
+    matrix, and with x, y, z permuted -- gives the same rows and the same energy"""
+    x0, _ = bcc(5, 5, 5, A_FE)
+    x0 = perturb(x0, 9, 0.02) - x0.mean(axis=0)
+    rng = np.random.default_rng(12)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    box = np.array([0, 0, 0, 60.0, 60.0, 60.0])
+    rows, energies = [], []
+    a = make_pair()
+    try:
+        for rot in (np.eye(3), q, np.eye(3)[[2, 0, 1]]):
+            s = System(x0 @ rot.T + 30.0, box, periodic=(0, 0, 0))
+            a.eatom = None
+            r = evaluate(a, s)
+            rows.append(r["rows"])
+            energies.append(r["e"])
+    finally:
+        a.close()
+    scale = np.maximum(np.abs(rows[0]).max(axis=0), 1.0)
+    for other in rows[1:]:
+        assert (np.abs(other - rows[0]) / scale).max() < 2e-12
+    assert max(abs(e - energies[0]) for e in energies) < 1e-9 * abs(energies[0])
