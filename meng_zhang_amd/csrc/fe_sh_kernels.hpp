@@ -706,9 +706,9 @@ __device__ __forceinline__ void shf_atom(const FeArgs &p, const int ii, const in
         for (int m = 0; m < NP; m++) cr[m] = cf[m];
         const int *myrow = p.nbrs + (size_t)ii * SH_CAP_MAX;
         int jl[2] = {i, i};
-        if (listed) {
+        if (listed && n > 0) {          // (an atom without neighbours has no row: nothing was written there)
 #pragma unroll
-            for (int u = 0; u < 2; u++) jl[u] = myrow[min(lane + 64 * u, max(n, 1) - 1)];
+            for (int u = 0; u < 2; u++) jl[u] = myrow[min(lane + 64 * u, n - 1)];
         }
         const double xi = p.x[3 * (size_t)i], yi = p.x[3 * (size_t)i + 1], zi = p.x[3 * (size_t)i + 2];
 #pragma unroll
