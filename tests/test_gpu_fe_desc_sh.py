@@ -191,3 +191,22 @@ def test_rows_do_not_depend_on_the_orientation(fe_pot):
     for other in rows[1:]:
         assert (np.abs(other - rows[0]) / scale).max() < 2e-12
     assert max(abs(e - energies[0]) for e in energies) < 1e-9 * abs(energies[0])
+
+
+def test_atoms_without_neighbours(fe_pot):
+    """isolated atoms (and a dimer, and a small cluster) on a fresh handle: an atom without neighbours has no row in the list the
+    descriptor pass hands to the force pass, no moments worth the name, zero force and the energy of an empty environment"""
+    rng = np.random.default_rng(3)
+    cluster = rng.uniform(0, 6.0, (23, 3))
+    x = np.vstack([cluster + 40.0, [[10.0, 10.0, 10.0]], [[70.0, 12.0, 33.0]], [[20.0, 60.0, 60.0], [22.4, 60.0, 60.0]]])
+    s = System(x, np.array([0, 0, 0, 90.0, 90.0, 90.0]), periodic=(0, 0, 0))
+    assert s.numneigh[: s.nlocal].min() == 0
+    a = make_pair()
+    try:
+        r = evaluate(a, s)
+    finally:
+        a.close()
+    o = oracle_compute(fe_pot, s, KIND_FE, FAST)
+    assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6 * max(1.0, np.abs(o["eatom"]).max())
+    assert np.abs(r["f"] - o["f"]).max() < 1e-9 * max(1.0, np.abs(o["f"]).max())
+    assert np.abs(r["f"][23:25]).max() == 0.0 and (r["rows"][23:25] == 0.0).all()
