@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 for step in "$@"; do
     echo "=== $step $(date +%T)"
     case $step in
-    newtests) timeout -k 10 900 python -m pytest tests/test_gpu_step_kernels.py tests/test_gpu_ilist.py tests/test_gpu_hostpath.py tests/test_compat_boundary.py -m gpu -x -q > $out/newtests.log 2>&1 || { tail -40 $out/newtests.log; exit 1; } ; tail -3 $out/newtests.log ;;
+    newtests) timeout -k 10 900 python -m pytest tests/test_gpu_fe_desc_sh.py tests/test_gpu_cpp_md.py tests/test_gpu_step_kernels.py tests/test_gpu_ilist.py tests/test_gpu_hostpath.py tests/test_compat_boundary.py -m gpu -x -q > $out/newtests.log 2>&1 || { tail -40 $out/newtests.log; exit 1; } ; tail -3 $out/newtests.log ;;
     alltests) timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $out/alltests.log 2>&1 || { tail -40 $out/alltests.log; exit 1; } ; tail -3 $out/alltests.log ;;
     kbench)   timeout -k 10 300 python tools/kbench.py ni 40 40 80 > $out/kbench_ni.log 2>&1 || { tail -20 $out/kbench_ni.log; exit 1; }; tail -1 $out/kbench_ni.log
               timeout -k 10 300 python tools/kbench.py anna 80 > $out/kbench_anna.log 2>&1 || { tail -20 $out/kbench_anna.log; exit 1; }; tail -1 $out/kbench_anna.log ;;
