@@ -29,6 +29,7 @@
 #include "../../include/annp_hip.h"
 #include "annp_common.hpp"
 #include "fe_sh_kernels.hpp"
+#include "fe_shf_kernels.hpp"
 #include "mlp_kernels.hpp"
 #include "neigh_kernels.hpp"
 #include "ni_kernels.hpp"
@@ -124,6 +125,7 @@ struct annp_hip_handle {
     int sh_cap = SH_CAP_MAX;            // Chebyshev descriptor pass (annp_fe_desc_sh): state slots per atom for the next evaluation
     bool fe_desc_pairs = false;         // ANNP_HIP_FE_DESC=pairs: the pair-loop descriptor kernel (annp_fe_desc) for every atom
     bool fe_force_pairs = false;        // ANNP_HIP_FE_FORCE=pairs: the pair-loop force kernel (annp_fe_force) for every atom
+    bool fe_force_sh3 = false;          // ANNP_HIP_FE_FORCE=sh3: round 3's force pass on the moments (recurrences per neighbour), for A/B runs
     int sh_cap_used = 0;                // state slots the last annp_fe_desc_sh launch had (= atoms with moments have at most that many neighbours)
     bool fe_dense = false;              // most atoms have more neighbours than the moment kernels take (128): the pair-loop kernels for all
     bool fe_last_sh = false;            // the last Chebyshev evaluation ran the moment kernels
@@ -568,9 +570,15 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             a.n_cap = cap;
             a.ovf_count = h->d_flags + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
             if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
-            const int wpb = SHF_WAVES;
-            if (vir) hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, true>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), shf_lds_per_block(), s, a);
-            else hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, false>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), shf_lds_per_block(), s, a);
+            if (h->fe_force_sh3) {
+                const int wpb = SH3_WAVES;
+                if (vir) hipLaunchKernelGGL((annp_fe_force_sh3<FE_NP, FE_NT, true>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), sh3_lds_per_block(), s, a);
+                else hipLaunchKernelGGL((annp_fe_force_sh3<FE_NP, FE_NT, false>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), sh3_lds_per_block(), s, a);
+            } else {
+                const int apb = SHF_WAVES * SHF_GA;         // atoms per workgroup
+                if (vir) hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, true>), dim3((inum + apb - 1) / apb), dim3(64 * SHF_WAVES), shf_lds_per_block(), s, a);
+                else hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, false>), dim3((inum + apb - 1) / apb), dim3(64 * SHF_WAVES), shf_lds_per_block(), s, a);
+            }
             HIP_TRY(h, hipGetLastError());
             if (fixup) {
                 FeArgs b = a;
@@ -838,6 +846,7 @@ void annp_hip_clear(annp_hip_handle *h)
     if (h->d_net) (void)hipFree(h->d_net);
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom); release(h, h->vatom);
     release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr); release(h, h->ni_npair); release(h, h->ni_fix_nbr); release(h, h->ni_pairs); release(h, h->ovf);
+    release(h, h->mom); release(h, h->fe_nbrs); release(h, h->ovf_desc);
     release(h, h->first);
     neigh_release(h->nb);
     if (h->d_scalars) (void)hipFree(h->d_scalars);
@@ -947,7 +956,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (const char *e = std::getenv("ANNP_HIP_NI_PAIRS")) h->ni_no_pairs = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_NI_FIXUP")) h->ni_no_fixup = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_FE_DESC")) h->fe_desc_pairs = std::strcmp(e, "pairs") == 0;
-    if (const char *e = std::getenv("ANNP_HIP_FE_FORCE")) h->fe_force_pairs = std::strcmp(e, "pairs") == 0;
+    if (const char *e = std::getenv("ANNP_HIP_FE_FORCE")) { h->fe_force_pairs = std::strcmp(e, "pairs") == 0; h->fe_force_sh3 = std::strcmp(e, "sh3") == 0; }
     if (const char *e = std::getenv("ANNP_HIP_DBG")) h->fe_dbg = std::atoi(e);
     if (const char *e = std::getenv("ANNP_HIP_SH_WPB")) h->sh_wpb = std::min(4, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("ANNP_HIP_SH_CAP")) h->sh_cap = std::min((int)SH_CAP_MAX, std::max((int)SH_CAP_MIN, round_up(std::atoi(e), 16)));
@@ -1160,6 +1169,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc_fixup<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh<FE_NP, FE_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh<FE_NP, FE_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh3<FE_NP, FE_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh3<FE_NP, FE_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));

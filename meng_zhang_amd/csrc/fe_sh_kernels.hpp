@@ -43,7 +43,8 @@ static_assert(SH_LMAX == FE_NT - 1, "tables are generated for T_0..T_18");
 __constant__ double annp_sh_q[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_Q_INIT;
 __constant__ double annp_sh_kappa[SH_NMOM + 16] = ANNP_SH_KAPPA_INIT;      // (+16: a lane past the last batch's end reads a zero)
 __constant__ double annp_sh_ml[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_ML_INIT;
-constexpr int SH_MPAD = 368;      // doubles per atom in the moment buffer (361 moments in the order of annp_sh_kappa)
+constexpr int SH_MPAD = 384;      // doubles per atom in the moment buffer: (cosine, sine) of (l = m+k, m) at 2 (shf_toff(m) + 18-m-k), sh_tables.hpp
+__host__ __device__ constexpr int sh_apos(int m, int k) { return 2 * (shf_toff(m) + SH_LMAX - m - k); }
 
 constexpr int SH_R = 3;           // neighbours per lane whose state stays in registers (ShRegs)
 constexpr int SH_CAP_MIN = SH_GL * SH_R + 16;
@@ -170,7 +171,10 @@ __device__ __forceinline__ void sh_batch(const ShLane &w, const double *ac, cons
     const int ll = M + (vv < K ? vv : vv - K);
     if ((w.jrev & (16 - RP)) == 0 && j < R) {       // one lane per moment
         atomicAdd(w.pwg + ll, kap * (t * t));
-        if (w.Aout) w.Aout[SH_COL_OFF[M] + vv] = kap * t;        // kappa_lm A_lm: what annp_fe_force_sh multiplies W_l with
+        if (w.Aout) {                     // kappa_lm A_lm: what annp_fe_force_sh multiplies W_l with
+            w.Aout[sh_apos(M, ll - M) + (vv < K ? 0 : 1)] = kap * t;
+            if (M == 0) w.Aout[sh_apos(M, ll - M) + 1] = 0.0;            // (column 0 has no sine moments: the pair's other half)
+        }
     }
 }
 
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(64) void annp_fe_desc_fixup(FeArgs p)
 // One wave per atom, a lane owns neighbours lane and lane + 64 (registers); the atom's 190 x 4 coefficients sit in LDS (every lane
 // reads the same address: a broadcast) and serve both neighbours of a lane at once.  Atoms with more neighbours than the
 // descriptor pass had state for (no moments) or than 128 go to annp_fe_force_fixup, as before.
-__host__ __device__ constexpr size_t shf_lds_per_wave() { return (size_t)SHF_NE * 32 + 108 * 8 + 128 * 4; }
+__host__ __device__ constexpr size_t sh3_lds_per_wave() { return (size_t)SHF_NE * 32 + 108 * 8 + 128 * 4; }
 static_assert(SHF_NE * 32 >= 128 * 32, "the coefficient table takes the place of the staging records");
 __host__ __device__ constexpr int sh_col_off(int m) { return m == 0 ? 0 : 19 + 38 * (m - 1) - (m - 1) * m; }   // = SH_COL_OFF[m]
 static_assert(sh_col_off(1) == SH_COL_OFF[1] && sh_col_off(7) == SH_COL_OFF[7] && sh_col_off(18) == SH_COL_OFF[18], "moment order");
@@ -607,34 +611,34 @@ struct ShfColumns<SH_LMAX + 1> {
 // whose ~900 (atom, neighbour) contributions fall on ~200 distinct atoms): open addressing on the atom index, LDS atomics, and one
 // global atomic per distinct atom and component when the workgroup is done.  The pass was bound by its 3 x 112 global
 // atomics per atom before: 12.0 ms per 1 M atoms with them, 7.4 without, 11.0 with them and without the arithmetic.
-constexpr int SHF_WAVES = 8;          // waves (atoms) per workgroup
-constexpr int SHF_TSLOTS = 512;       // slots of the workgroup's force table
-constexpr int SHF_TPROBE = 8;         // occupied slots tried before a contribution goes straight to global memory
-__host__ __device__ constexpr size_t shf_lds_table() { return (size_t)SHF_TSLOTS * (4 + 24); }
-__host__ __device__ constexpr size_t shf_lds_per_block();
-__host__ __device__ constexpr size_t shf_lds_per_block() { return shf_lds_table() + SHF_WAVES * shf_lds_per_wave(); }
-struct ShfTable {
-    int *key;          // [SHF_TSLOTS], -1 = free
-    double *acc;       // [SHF_TSLOTS][3]
+constexpr int SH3_WAVES = 8;          // waves (atoms) per workgroup
+constexpr int SH3_TSLOTS = 512;       // slots of the workgroup's force table
+constexpr int SH3_TPROBE = 8;         // occupied slots tried before a contribution goes straight to global memory
+__host__ __device__ constexpr size_t sh3_lds_table() { return (size_t)SH3_TSLOTS * (4 + 24); }
+__host__ __device__ constexpr size_t sh3_lds_per_block();
+__host__ __device__ constexpr size_t sh3_lds_per_block() { return sh3_lds_table() + SH3_WAVES * sh3_lds_per_wave(); }
+struct Sh3Table {
+    int *key;          // [SH3_TSLOTS], -1 = free
+    double *acc;       // [SH3_TSLOTS][3]
     double *f;
     __device__ __forceinline__ void add(int j, double fx, double fy, double fz) const
     {
         unsigned sl = ((unsigned)j * 0x9E3779B1u) >> 23;
 #pragma unroll 1
-        for (int probe = 0; probe < SHF_TPROBE; probe++) {
+        for (int probe = 0; probe < SH3_TPROBE; probe++) {
             const int old = atomicCAS(&key[sl], -1, j);
             if (old == -1 || old == j) {
                 atomicAdd(&acc[3 * sl], fx); atomicAdd(&acc[3 * sl + 1], fy); atomicAdd(&acc[3 * sl + 2], fz);
                 return;
             }
-            sl = (sl + 1) & (SHF_TSLOTS - 1);
+            sl = (sl + 1) & (SH3_TSLOTS - 1);
         }
         atomicAdd(&f[3 * (size_t)j], fx); atomicAdd(&f[3 * (size_t)j + 1], fy); atomicAdd(&f[3 * (size_t)j + 2], fz);
     }
 };
 
 template <int NP, int NT, bool VIRIAL>
-__device__ __forceinline__ void shf_atom(const FeArgs &p, const int ii, const int lane, unsigned char *wbase, const ShfTable &tab)
+__device__ __forceinline__ void shf_atom(const FeArgs &p, const int ii, const int lane, unsigned char *wbase, const Sh3Table &tab)
 {
     static_assert(NT == SH_LMAX + 1 && NP + 2 * NT - 1 <= 48, "coefficient row");
     double2 *recA = reinterpret_cast<double2 *>(wbase);           // stage A: raw entries [128] (dx,dy), [128] (dz,r^2), [128] j
@@ -675,12 +679,12 @@ __device__ __forceinline__ void shf_atom(const FeArgs &p, const int ii, const in
             if (NT * m - m * (m - 1) / 2 > e) m--;
             const int k = e - (NT * m - m * (m - 1) / 2), K = SH_LMAX + 1 - m;
             te_l[t] = m + k; te_k[t] = k;
-            const int ic = sh_col_off(m) + k;
-            const int id = m > 0 ? sh_col_off(m - 1) + k + 1 : 0;
+            const int ic = sh_apos(m, k);
+            const int id = m > 0 ? sh_apos(m - 1, k + 1) : 0;
             te_a[t][0] = Am[ic];
-            te_a[t][1] = m > 0 ? Am[ic + K] : 0.0;
+            te_a[t][1] = m > 0 ? Am[ic + 1] : 0.0;
             te_a[t][2] = m > 0 ? Am[id] : 0.0;
-            te_a[t][3] = m > 1 ? Am[id + K + 1] : 0.0;
+            te_a[t][3] = m > 1 ? Am[id + 1] : 0.0;
         }
     }
     // the in-cutoff neighbours: from the descriptor pass's list (count and indices, list order) or by filtering the row again
@@ -826,24 +830,24 @@ __device__ __forceinline__ void shf_atom(const FeArgs &p, const int ii, const in
 }
 
 template <int NP, int NT, bool VIRIAL>
-__global__ __launch_bounds__(64 * SHF_WAVES, 4) void annp_fe_force_sh(FeArgs p)
+__global__ __launch_bounds__(64 * SH3_WAVES, 4) void annp_fe_force_sh3(FeArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(xcd_block() * SHF_WAVES + wave);
-    ShfTable tab;
-    tab.key = reinterpret_cast<int *>(lds_raw + (size_t)SHF_TSLOTS * 24);
+    const int ii = uniform(xcd_block() * SH3_WAVES + wave);
+    Sh3Table tab;
+    tab.key = reinterpret_cast<int *>(lds_raw + (size_t)SH3_TSLOTS * 24);
     tab.acc = reinterpret_cast<double *>(lds_raw);
     tab.f = p.f;
-    for (int sl = threadIdx.x; sl < SHF_TSLOTS; sl += 64 * SHF_WAVES) {
+    for (int sl = threadIdx.x; sl < SH3_TSLOTS; sl += 64 * SH3_WAVES) {
         tab.key[sl] = -1; tab.acc[3 * sl] = 0.0; tab.acc[3 * sl + 1] = 0.0; tab.acc[3 * sl + 2] = 0.0;
     }
     __syncthreads();
-    if (ii < p.inum) shf_atom<NP, NT, VIRIAL>(p, ii, lane, lds_raw + shf_lds_table() + (size_t)wave * shf_lds_per_wave(), tab);
+    if (ii < p.inum) shf_atom<NP, NT, VIRIAL>(p, ii, lane, lds_raw + sh3_lds_table() + (size_t)wave * sh3_lds_per_wave(), tab);
     __syncthreads();
     // the workgroup's table: one global atomic per distinct atom and component
-    for (int sl = threadIdx.x; sl < SHF_TSLOTS; sl += 64 * SHF_WAVES) {
+    for (int sl = threadIdx.x; sl < SH3_TSLOTS; sl += 64 * SH3_WAVES) {
         const int j = tab.key[sl];
         if (j >= 0) {
             atomicAdd(&p.f[3 * (size_t)j], tab.acc[3 * sl]); atomicAdd(&p.f[3 * (size_t)j + 1], tab.acc[3 * sl + 1]);

@@ -1,0 +1,464 @@
+// fe_shf_kernels.hpp -- annp_fe_force_sh, the Chebyshev force pass (fe_v2/src/pair_annp.cpp:190-213 with the angular derivatives of
+// fe:658-695, "fe:") on the moments of the neighbourhood, round 4: Horner's rule in z and in w = x + iy.
+//
+// What is computed is what fe_sh_kernels.hpp's header derives: with P(c) = sum_l W_l P_l(c) the atom's angular polynomial,
+//     U(e) = sum_b fc_b P(e.e_b) = sum_m Re[ (beta^c_m(z) - i beta^s_m(z)) w^m ],   beta_m(z) = sum_k B_(m+k,m) Pm^(m)_k(z),  B = W kappa A
+// and the force on neighbour a needs U(e_a) and grad U(e_a).  Round 3 ran the three-term recurrence of Pm^(m)_k for every
+// neighbour and column (2 instructions per step) and four sums behind it (4): 6 x 190 per neighbour.  Here beta_m is handed
+// over in powers of z,
+//     beta_m(z) = sum_j b_mj z^j,      b_mj = sum_{k >= j, k = j mod 2} M^(m)_kj B_(m+k,m)      (Pm^(m)_k = sum_j M_kj z^j, exact rationals),
+// built once per atom (1 430 multiply-adds), and a neighbour evaluates value and derivative by Horner's rule,
+//     d <- d z + p,   p <- p z + b_mj        (j = K-1 .. 0):      4 instructions per step for beta^c, beta^s, beta'^c, beta'^s
+// -- no basis to generate, half the table (the derivative needs no coefficients of its own: 3 040 B per atom).  The columns are
+// summed by Horner's rule in w, from m = 18 down:
+//     D <- D w + F,   F <- F w + (beta^c_m - i beta^s_m),   H <- H w + (beta'^c_m - i beta'^s_m)         (complex: 12 FMAs per column)
+// so that U = Re F, (dU/dx, dU/dy) = (Re D, -Im D) (D = dF/dw), dU/dz = Re H, and no power of w is kept.
+// Conditioning: |z| <= 1 and the b_mj of a degree-18 column alternate with magnitudes up to ~1e5 |B|; measured on bcc-Fe
+// neighbourhoods with the potential's own coefficients the forces differ from the recurrence form by <= 1e-14 eV/A
+// (tests/test_sh_tables.py::test_force_form_on_monomials, against long double).
+//
+// Work decomposition: a wave takes FOUR atoms, 16 lanes each (as annp_fe_desc_sh does); a lane owns neighbours l, l+16, ..
+// of its atom and walks them in two turns of up to four (bcc Fe: 112 = 16 x (4 + 3), every lane slot used; round 3 gave a
+// wave one atom and 128 slots).  The 16 lanes of an atom read the same table entry: a ds_read_b128 with four distinct
+// addresses per wave serves 16 FMAs.  A workgroup is 4 waves = 16 consecutive atoms sharing the LDS force table that
+// round 3 introduced (open addressing on the atom index, one global atomic per distinct atom and component at the end).
+#pragma once
+#include "fe_sh_kernels.hpp"
+
+namespace annp {
+
+constexpr int SHF_GA = 4;             // atoms per wave
+constexpr int SHF_GL = 16;            // lanes per atom
+constexpr int SHF_TURN = 4;           // neighbours of a lane in registers at a time
+constexpr int SHF_WAVES = 4;          // waves per workgroup
+constexpr int SHF_TSLOTS = 1024;      // slots of the workgroup's force table (16 atoms of a bcc row reach ~410 distinct atoms)
+constexpr int SHF_TPROBE = 8;         // occupied slots tried before a contribution goes straight to global memory
+constexpr int SHF_TBYTES = SHF_NE * 16;       // an atom's table: 190 x (b^c, b^s)
+static_assert((SHF_TBYTES / 4) % 64 >= 4 && (SHF_TBYTES / 4) % 64 <= 60, "two atoms' entries of one read must not share banks");
+
+__constant__ unsigned char annp_shf_l[SHF_NE + 2] = ANNP_SHF_L_INIT;
+__constant__ double annp_shf_conv[SHF_CONV_NREC * 16] = ANNP_SHF_CONV_INIT;
+
+// LDS of one wave: the four tables, 32 bytes of slack (the last column's look-ahead reads them), W_l [4][20]
+__host__ __device__ constexpr size_t shf_lds_per_wave() { return (size_t)SHF_GA * SHF_TBYTES + 32 + SHF_GA * 20 * 8; }
+__host__ __device__ constexpr size_t shf_lds_table() { return (size_t)SHF_TSLOTS * (4 + 24); }
+__host__ __device__ constexpr size_t shf_lds_per_block() { return shf_lds_table() + SHF_WAVES * shf_lds_per_wave(); }
+static_assert(shf_lds_per_wave() % 16 == 0 && shf_lds_table() % 16 == 0, "b128 alignment of every wave's tables");
+
+struct ShfTable {
+    int *key;          // [SHF_TSLOTS], -1 = free
+    double *acc;       // [SHF_TSLOTS][3]
+    double *f;
+    __device__ __forceinline__ void add(int j, double fx, double fy, double fz) const
+    {
+        unsigned sl = ((unsigned)j * 0x9E3779B1u) >> 22;
+        static_assert(SHF_TSLOTS == 1024, "hash width");
+#pragma unroll 1
+        for (int probe = 0; probe < SHF_TPROBE; probe++) {
+            const int old = atomicCAS(&key[sl], -1, j);
+            if (old == -1 || old == j) {
+                atomicAdd(&acc[3 * sl], fx); atomicAdd(&acc[3 * sl + 1], fy); atomicAdd(&acc[3 * sl + 2], fz);
+                return;
+            }
+            sl = (sl + 1) & (SHF_TSLOTS - 1);
+        }
+        atomicAdd(&f[3 * (size_t)j], fx); atomicAdd(&f[3 * (size_t)j + 1], fy); atomicAdd(&f[3 * (size_t)j + 2], fz);
+    }
+};
+
+// a * b + c in the three-address form.  Left to itself the compiler writes the steps below as v_fmac_f64 (d += a * b) on a copy of the
+// table entry -- a v_mov_b64 per multiply-add whose addend is shared by the neighbours of a lane, a quarter of the inner loop.
+__device__ __forceinline__ double fma3(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ double fma3n(double a, double b, double c)         // a * b - c
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, -%3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ double fnma3(double a, double b, double c)         // c - a * b
+{
+    double r;
+    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+typedef const __attribute__((address_space(3))) shf_v2d *shf_tab_ptr;
+__device__ __forceinline__ shf_v2d shf_entry(unsigned tb, int e) { return *(shf_tab_ptr)(uintptr_t)(tb + 16u * (unsigned)e); }
+
+// ---- the change of basis of one column, in place: entry (m, j) <- sum_t M_(j+2t, j) B_(m, j+2t).  Lane l of an atom takes
+// the powers j = l and (K > 16) j = 16 + l; every read of a block of 16 powers is issued before its writes (LDS operations of a
+// wave execute in order), and the second block only reads entries the first has not written.
+template <int M, int BLK>
+__device__ __forceinline__ void shf_convert_block(double2 *T, const int l)
+{
+    constexpr int K = SH_LMAX + 1 - M;
+    constexpr int base = shf_toff(M);
+    constexpr int first = SHF_CONV_FIRST[M][BLK / 16];
+    constexpr int nt = (K - BLK + 1) / 2;
+    const int j = BLK + l;
+    double ax = 0.0, ay = 0.0;
+#pragma unroll
+    for (int t = 0; t < nt; t++) {
+        const double mv = annp_shf_conv[(first + t) * 16 + l];        // 0 where j + 2t > K-1
+        const int k = min(j + 2 * t, K - 1);
+        const double2 b = T[base + K - 1 - k];
+        ax = fma(mv, b.x, ax); ay = fma(mv, b.y, ay);
+    }
+    if (j < K) T[base + K - 1 - j] = make_double2(ax, ay);
+}
+template <int M>
+__device__ __forceinline__ void shf_convert_column(double2 *T, const int l)
+{
+    shf_convert_block<M, 0>(T, l);
+    if (SH_LMAX + 1 - M > 16) shf_convert_block<M, (SH_LMAX + 1 - M > 16 ? 16 : 0)>(T, l);
+}
+template <int M>
+struct ShfConvert {
+    static __device__ __forceinline__ void run(double2 *T, const int l)
+    {
+        shf_convert_column<M>(T, l);
+        ShfConvert<M + 1>::run(T, l);
+    }
+};
+template <>
+struct ShfConvert<SH_LMAX + 1> {
+    static __device__ __forceinline__ void run(double2 *, const int) {}
+};
+
+// ---- value and gradient of U at CC neighbours of this lane.  tb = LDS byte address of the atom's table.
+template <int CC>
+__device__ __forceinline__ void shf_evaluate(const unsigned tb, const double (&z)[CC], const double (&wx)[CC], const double (&wy)[CC],
+                                             double (&U)[CC], double (&Ux)[CC], double (&Uy)[CC], double (&Uz)[CC])
+{
+    double Fx[CC], Fy[CC], Dx[CC], Dy[CC], Hx[CC], Hy[CC];
+    double pc[CC], ps[CC], dc[CC], ds[CC];
+    // a column is done: D <- D w + F, F <- F w + (pc - i ps), H <- H w + (dc - i ds)
+    auto column_end = [&]() {
+#pragma unroll
+        for (int u = 0; u < CC; u++) {
+            const double ndx = fma3(Dx[u], wx[u], fnma3(Dy[u], wy[u], Fx[u]));
+            const double ndy = fma3(Dx[u], wy[u], fma3(Dy[u], wx[u], Fy[u]));
+            const double nfx = fma3(Fx[u], wx[u], fnma3(Fy[u], wy[u], pc[u]));
+            const double nfy = fma3(Fx[u], wy[u], fma3n(Fy[u], wx[u], ps[u]));
+            const double nhx = fma3(Hx[u], wx[u], fnma3(Hy[u], wy[u], dc[u]));
+            const double nhy = fma3(Hx[u], wy[u], fma3n(Hy[u], wx[u], ds[u]));
+            Dx[u] = ndx; Dy[u] = ndy; Fx[u] = nfx; Fy[u] = nfy; Hx[u] = nhx; Hy[u] = nhy;
+        }
+    };
+    // one step of Horner's rule with derivative (the derivative first: it does not wait for the entry)
+    auto step = [&](const shf_v2d b) {
+#pragma unroll
+        for (int u = 0; u < CC; u++) { dc[u] = fma3(dc[u], z[u], pc[u]); ds[u] = fma3(ds[u], z[u], ps[u]); }
+#pragma unroll
+        for (int u = 0; u < CC; u++) { pc[u] = fma3(pc[u], z[u], b.x); ps[u] = fma3(ps[u], z[u], b.y); }
+    };
+    // the first three entries of a column at once: p = (b1 z + b2) z + b3, d = b1 z + (b1 z + b2)
+    auto start3 = [&](const shf_v2d b1, const shf_v2d b2, const shf_v2d b3) {
+#pragma unroll
+        for (int u = 0; u < CC; u++) {
+            const double qc = fma3(b1.x, z[u], b2.x), qs = fma3(b1.y, z[u], b2.y);
+            dc[u] = fma3(b1.x, z[u], qc); ds[u] = fma3(b1.y, z[u], qs);
+            pc[u] = fma3(qc, z[u], b3.x); ps[u] = fma3(qs, z[u], b3.y);
+        }
+    };
+    // ---- m = 18 (one entry) and m = 17 (two): no loop to speak of
+    {
+        const shf_v2d b0 = shf_entry(tb, 0), b1 = shf_entry(tb, 1), b2 = shf_entry(tb, 2);
+#pragma unroll
+        for (int u = 0; u < CC; u++) {
+            Dx[u] = 0.0; Dy[u] = 0.0; Hx[u] = 0.0; Hy[u] = 0.0;
+            Fx[u] = b0.x; Fy[u] = -b0.y;                                  // F = beta_18
+            pc[u] = fma3(b1.x, z[u], b2.x); ps[u] = fma3(b1.y, z[u], b2.y); // beta_17 = b1 z + b2
+            dc[u] = b1.x; ds[u] = b1.y;
+        }
+        column_end();
+    }
+    // ---- m = 16 .. 1: K = 3 .. 18 entries, two columns per trip (K odd: start3 + pairs; K even: start3 + one step + pairs).
+    // The entries a column starts with are requested before the previous column's closing arithmetic, the pairs' one step ahead.
+    int e = 3;                               // next entry of the table
+    shf_v2d s1 = shf_entry(tb, 3), s2 = shf_entry(tb, 4), s3 = shf_entry(tb, 5);
+    shf_v2d qa = shf_entry(tb, 6), qb = shf_entry(tb, 7);
+#pragma unroll 1
+    for (int i = 0; i < 8; i++) {
+        // K = 3 + 2i: i pairs behind the start; qa, qb hold entries e+3, e+4
+        start3(s1, s2, s3);
+        e += 3;
+#pragma unroll 1
+        for (int r = 0; r < i; r++) {
+            step(qa); qa = shf_entry(tb, e + 2);
+            step(qb); qb = shf_entry(tb, e + 3);
+            e += 2;
+        }
+        // next column (K = 4 + 2i) starts at e: qa, qb hold entries e, e+1
+        s1 = qa; s2 = qb; s3 = shf_entry(tb, e + 2);
+        qa = shf_entry(tb, e + 3); qb = shf_entry(tb, e + 4);
+        const shf_v2d qc = shf_entry(tb, e + 5);
+        column_end();
+        start3(s1, s2, s3);
+        step(qa);                         // the odd one
+        e += 4;
+        qa = qb; qb = qc;                 // entries e, e+1
+#pragma unroll 1
+        for (int r = 0; r < i; r++) {
+            step(qa); qa = shf_entry(tb, e + 2);
+            step(qb); qb = shf_entry(tb, e + 3);
+            e += 2;
+        }
+        // next column (K = 5 + 2i, or the last one) starts at e: qa, qb hold entries e, e+1
+        s1 = qa; s2 = qb; s3 = shf_entry(tb, e + 2);
+        qa = shf_entry(tb, e + 3); qb = shf_entry(tb, e + 4);
+        column_end();
+    }
+    // ---- m = 0: 19 entries, cosine only (the sine moments of m = 0 are zero), and only the real parts are wanted at the end
+    {
+#pragma unroll
+        for (int u = 0; u < CC; u++) {
+            const double qc = fma3(s1.x, z[u], s2.x);
+            dc[u] = fma3(s1.x, z[u], qc);
+            pc[u] = fma3(qc, z[u], s3.x);
+        }
+        e += 3;
+#pragma unroll 1
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int u = 0; u < CC; u++) { dc[u] = fma3(dc[u], z[u], pc[u]); pc[u] = fma3(pc[u], z[u], qa.x); }
+            qa = shf_entry(tb, e + 2);
+#pragma unroll
+            for (int u = 0; u < CC; u++) { dc[u] = fma3(dc[u], z[u], pc[u]); pc[u] = fma3(pc[u], z[u], qb.x); }
+            qb = shf_entry(tb, e + 3);
+            e += 2;
+        }
+#pragma unroll
+        for (int u = 0; u < CC; u++) {
+            Ux[u] = fma3(Dx[u], wx[u], fnma3(Dy[u], wy[u], Fx[u]));
+            Uy[u] = -fma3(Dx[u], wy[u], fma3(Dy[u], wx[u], Fy[u]));
+            U[u] = fma3(Fx[u], wx[u], fnma3(Fy[u], wy[u], pc[u]));
+            Uz[u] = fma3(Hx[u], wx[u], fnma3(Hy[u], wy[u], dc[u]));
+        }
+    }
+}
+
+struct ShfAtom {            // what a lane knows of its atom
+    int ii, i, n;           // list entry, atom index, in-cutoff neighbours (0: nothing to do)
+    double xi, yi, zi;
+    double pone;            // P(1) = sum_k p_k
+    const double *cf;       // the atom's coefficient row
+    const int *row;         // its in-cutoff neighbours (annp_fe_desc_sh's hand-over)
+};
+
+// one turn: neighbours u0 .. u0+CC-1 of this lane (a = l + 16 u): geometry and radial term (fe:648), U and grad U, force assembly
+template <int NP, int CC, bool VIRIAL>
+__device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, const int l, const int u0, const unsigned tb, const ShfTable &tab,
+                                         double (&fi)[3], double (&vs)[6])
+{
+    const double pi_over_rc = ANNP_MY_PI / p.rc_list;
+    const double two_over_rcp = 2.0 / p.rc_par;
+    int jn[CC];
+    double z[CC], wx[CC], wy[CC], al[CC], be[CC], g0[CC], rr[VIRIAL ? CC : 1];
+    {
+#pragma unroll
+        for (int u = 0; u < CC; u++) jn[u] = at.n > 0 ? at.row[min(l + SHF_GL * (u0 + u), at.n - 1)] : at.i;
+        double cr[NP];
+#pragma unroll
+        for (int m = 0; m < NP; m++) cr[m] = at.cf[m];
+        double dx[CC], dy[CC], dz[CC];
+#pragma unroll
+        for (int u = 0; u < CC; u++) {
+            dx[u] = at.xi - p.x[3 * (size_t)jn[u]]; dy[u] = at.yi - p.x[3 * (size_t)jn[u] + 1]; dz[u] = at.zi - p.x[3 * (size_t)jn[u] + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < CC; u++) {
+            const bool has = l + SHF_GL * (u0 + u) < at.n;
+            double2 R0 = make_double2(dx[u], dy[u]), R1 = make_double2(dz[u], dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u]);
+            if (!has) { R0 = make_double2(0.0, 0.0); R1 = make_double2(1.0, 1.0); }
+            const FeNbr g = sh_geometry(R0, R1, pi_over_rc);
+            const double xr = g.r * two_over_rcp - 1.0;
+            const double y2 = 2.0 * xr;
+            double tm2 = 1.0, tm1 = xr, dm2 = 0.0, dm1 = 1.0;
+            double st = cr[0], sd = 0.0;              // sum c T, sum c T'
+            if (NP > 1) { st = fma(cr[1], xr, st); sd = cr[1]; }
+#pragma unroll
+            for (int mm = 2; mm < NP; mm++) {
+                const double t = fma(y2, tm1, -tm2);
+                const double d = fma(y2, dm1, fma(2.0, tm1, -dm2));
+                st = fma(cr[mm], t, st);
+                sd = fma(cr[mm], d, sd);
+                tm2 = tm1; tm1 = t; dm2 = dm1; dm1 = d;
+            }
+            const double R = fma(sd * two_over_rcp, g.fc, st * g.dfc);        // d/dr of the radial part
+            z[u] = g.ez; wx[u] = g.ex; wy[u] = g.ey;
+            // F_n = e [ al (e . grad U) - be U + g0 ] - al grad U:  al = fc / r, be = fc', g0 = -R + P(1) fc fc'
+            al[u] = has ? g.fc * g.rinv : 0.0;
+            be[u] = has ? g.dfc : 0.0;
+            g0[u] = has ? fma(at.pone * g.fc, g.dfc, -R) : 0.0;
+            if (VIRIAL) rr[u] = g.r;
+        }
+    }
+    double U[CC], Ux[CC], Uy[CC], Uz[CC];
+    shf_evaluate<CC>(tb, z, wx, wy, U, Ux, Uy, Uz);
+#pragma unroll
+    for (int u = 0; u < CC; u++) {
+        if (l + SHF_GL * (u0 + u) < at.n) {
+            const double ed = fma(wx[u], Ux[u], fma(wy[u], Uy[u], z[u] * Uz[u]));
+            const double t = fma(al[u], ed, fma(-be[u], U[u], g0[u]));
+            const double f0 = fma(t, wx[u], -al[u] * Ux[u]);
+            const double f1 = fma(t, wy[u], -al[u] * Uy[u]);
+            const double f2 = fma(t, z[u], -al[u] * Uz[u]);
+            tab.add(jn[u], -f0, -f1, -f2);                    // F_a = -Fn_a to the neighbour, +Fn_a to the centre (fe:199-211)
+            fi[0] += f0; fi[1] += f1; fi[2] += f2;
+            if (VIRIAL) {   // ev_tally_xyz(i,j,...,fx=-Fj, del = xi-xj = r e)   (fe:201-209)
+                const double d0 = rr[u] * wx[u], d1 = rr[u] * wy[u], d2 = rr[u] * z[u];
+                const double w0 = d0 * f0, w1 = d1 * f1, w2 = d2 * f2, w3 = d0 * f1, w4 = d0 * f2, w5 = d1 * f2;
+                vs[0] += w0; vs[1] += w1; vs[2] += w2; vs[3] += w3; vs[4] += w4; vs[5] += w5;
+                if (p.vatom) {
+                    double *vj = p.vatom + 6 * (size_t)jn[u];
+                    atomicAdd(vj + 0, 0.5 * w0); atomicAdd(vj + 1, 0.5 * w1); atomicAdd(vj + 2, 0.5 * w2);
+                    atomicAdd(vj + 3, 0.5 * w3); atomicAdd(vj + 4, 0.5 * w4); atomicAdd(vj + 5, 0.5 * w5);
+                }
+            }
+        }
+    }
+}
+
+template <int NP, bool VIRIAL>
+__device__ __forceinline__ void shf_turns(const FeArgs &p, const ShfAtom &at, const int l, const int u0, const int cc, const unsigned tb,
+                                          const ShfTable &tab, double (&fi)[3], double (&vs)[6])
+{
+    switch (cc) {           // (uniform)
+    case 1: shf_turn<NP, 1, VIRIAL>(p, at, l, u0, tb, tab, fi, vs); break;
+    case 2: shf_turn<NP, 2, VIRIAL>(p, at, l, u0, tb, tab, fi, vs); break;
+    case 3: shf_turn<NP, 3, VIRIAL>(p, at, l, u0, tb, tab, fi, vs); break;
+    case 4: shf_turn<NP, 4, VIRIAL>(p, at, l, u0, tb, tab, fi, vs); break;
+    default: break;
+    }
+}
+
+template <int NP, int NT, bool VIRIAL>
+__global__ __launch_bounds__(64 * SHF_WAVES, 2) void annp_fe_force_sh(FeArgs p)
+{
+    static_assert(NT == SH_LMAX + 1 && NP + 2 * NT - 1 <= ANNP_CPAD, "coefficient row");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const int wave = uniform(threadIdx.x >> 6);
+    ShfTable tab;
+    tab.key = reinterpret_cast<int *>(lds_raw + (size_t)SHF_TSLOTS * 24);
+    tab.acc = reinterpret_cast<double *>(lds_raw);
+    tab.f = p.f;
+    for (int sl = threadIdx.x; sl < SHF_TSLOTS; sl += 64 * SHF_WAVES) {
+        tab.key[sl] = -1; tab.acc[3 * sl] = 0.0; tab.acc[3 * sl + 1] = 0.0; tab.acc[3 * sl + 2] = 0.0;
+    }
+    __syncthreads();
+
+    unsigned char *wbase = lds_raw + shf_lds_table() + (size_t)wave * shf_lds_per_wave();
+    const int g = lane >> 4, l = lane & 15;
+    double2 *T = reinterpret_cast<double2 *>(wbase + (size_t)g * SHF_TBYTES);
+    double *Wl = reinterpret_cast<double *>(wbase + (size_t)SHF_GA * SHF_TBYTES + 32) + g * 20;
+
+    // ---- this lane's atom
+    ShfAtom at;
+    at.ii = (xcd_block() * SHF_WAVES + wave) * SHF_GA + g;
+    at.n = 0; at.i = 0;
+    if (at.ii < p.inum) {
+        at.i = p.ilist ? p.ilist[at.ii] : at.ii;
+        at.n = p.ncount[at.ii];
+        if (p.type && !type_mapped(p.active, p.type[at.i])) at.n = 0;
+        if (at.n > p.n_cap) {            // no moments for this atom: the pair loop takes it (annp_fe_force_fixup)
+            if (l == 0) {
+                const int k = p.ovf_list ? atomicAdd(p.ovf_count, 1) : p.ovf_cap;
+                if (k < p.ovf_cap) p.ovf_list[k] = at.ii;
+                else atomicMax(p.errflag, at.n);
+            }
+            at.n = 0;
+        }
+    }
+    const int nmax = max(max(__builtin_amdgcn_readlane(at.n, 0), __builtin_amdgcn_readlane(at.n, 16)),
+                         max(__builtin_amdgcn_readlane(at.n, 32), __builtin_amdgcn_readlane(at.n, 48)));
+    if (nmax > 0) {
+        const size_t iis = at.n > 0 ? (size_t)at.ii : 0;            // (an atom with nothing to do reads row 0 and ignores it)
+        at.cf = p.coef + iis * ANNP_CPAD;
+        at.row = p.nbrs + iis * SH_CAP_MAX;
+        at.xi = p.x[3 * (size_t)at.i]; at.yi = p.x[3 * (size_t)at.i + 1]; at.zi = p.x[3 * (size_t)at.i + 2];
+        // ---- the moments of the atom, requested first: entries l, l+16, .. of its 190 (cosine, sine) pairs
+        const double2 *Am = reinterpret_cast<const double2 *>(p.A + iis * SH_MPAD);
+        constexpr int NR = (SHF_NE + SHF_GL - 1) / SHF_GL;
+        double2 am[NR];
+        int lw[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int e = min(l + SHF_GL * r, SHF_NE - 1);
+            am[r] = Am[e];
+            lw[r] = annp_shf_l[e];
+        }
+        // ---- W_l = sum_k p_k ml[k][l] (lane l: W_l, lanes 0..2 also W_(16+l)); P(1) = sum_k p_k
+        {
+            double pk[NT];
+#pragma unroll
+            for (int k = 0; k < NT; k++) pk[k] = at.cf[NP + k];
+            double w0 = 0.0, w1 = 0.0, s = 0.0;
+            const int l1 = min(l + 16, NT - 1);
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                w0 = fma(pk[k], annp_sh_ml[k * NT + l], w0);
+                if (k >= 16) w1 = fma(pk[k], annp_sh_ml[k * NT + l1], w1);
+                s += pk[k];
+            }
+            at.pone = s;
+            Wl[l] = w0;
+            if (l + 16 < NT) Wl[l + 16] = w1;
+        }
+        wave_lds_sync();
+        // ---- B = W kappa A into the table, then its change of basis in place
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int e = l + SHF_GL * r;
+            const double w = at.n > 0 ? Wl[lw[r]] : 0.0;
+            if (e < SHF_NE) T[e] = at.n > 0 ? make_double2(w * am[r].x, w * am[r].y) : make_double2(0.0, 0.0);
+        }
+        wave_lds_sync();
+        ShfConvert<0>::run(T, l);
+        wave_lds_sync();
+
+        // ---- two turns over the lane's neighbours
+        const unsigned tb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)T;
+        const int C = (nmax + SHF_GL - 1) / SHF_GL;              // neighbours per lane (uniform), 1 .. 8
+        const int c1 = C <= SHF_TURN ? C : (C + 1) / 2;
+        double fi[3] = {0.0, 0.0, 0.0}, vs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        shf_turns<NP, VIRIAL>(p, at, l, 0, c1, tb, tab, fi, vs);
+        if (C > c1) shf_turns<NP, VIRIAL>(p, at, l, c1, C - c1, tb, tab, fi, vs);
+        // ---- the centre's share: sums over the atom's 16 lanes end up in the row's last lane
+#pragma unroll
+        for (int k = 0; k < 3; k++) fi[k] = row16_sum_to_last(fi[k]);
+        if (l == 15 && at.n > 0) tab.add(at.i, fi[0], fi[1], fi[2]);
+        if (VIRIAL) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) vs[k] = row16_sum_to_last(vs[k]);
+            if (l == 15 && at.n > 0) {
+                if (p.virial) {
+                    double *vr = virial_row(p.virial);          // (annp_common.hpp: the global virial)
+#pragma unroll
+                    for (int k = 0; k < 6; k++) atomicAdd(&vr[k], vs[k]);
+                }
+                if (p.vatom) {
+                    double *vi = p.vatom + 6 * (size_t)at.i;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) atomicAdd(vi + k, 0.5 * vs[k]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // the workgroup's table: one global atomic per distinct atom and component
+    for (int sl = threadIdx.x; sl < SHF_TSLOTS; sl += 64 * SHF_WAVES) {
+        const int j = tab.key[sl];
+        if (j >= 0) {
+            atomicAdd(&p.f[3 * (size_t)j], tab.acc[3 * sl]); atomicAdd(&p.f[3 * (size_t)j + 1], tab.acc[3 * sl + 1]);
+            atomicAdd(&p.f[3 * (size_t)j + 2], tab.acc[3 * sl + 2]);
+        }
+    }
+}
+
+}  // namespace annp
