@@ -527,7 +527,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     MlpArgs m{};
     m.type = types; m.map = h->d_map; m.elem = 0; m.active = h->active;
     m.inum = inum; m.ilist = d_ilist; m.nsf = h->nsf_dev; m.nnod = h->nnod; m.nl = h->nl;
-    m.ncoef = h->descriptor == ANNP_HIP_DESC_CHEBYSHEV ? FE_NP + 2 * FE_NT - 1 : h->nsf_dev;
+    m.ncoef = h->descriptor == ANNP_HIP_DESC_CHEBYSHEV ? FE_NP + 2 * FE_NT + 1 : h->nsf_dev;
     for (int l = 0; l < std::min(h->nl, (int)MLP_MAXL); l++) m.act[l] = h->flagact[l];      // (anna_adp may have more layers; it does not use m)
     m.nmul = h->d_norm; m.nsub = h->d_norm + ANNP_GPAD; m.nden = h->d_norm + 2 * ANNP_GPAD; m.img = h->d_mlp_img;
     m.e_scale = h->e_scale; m.e_shift = h->e_shift; m.e_atom = h->e_atom;
@@ -1027,7 +1027,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         // T: rows of coef as linear forms of c_k = cmul_k dE/dGhat_k
         std::vector<long double> T((size_t)ANNP_CPAD * nsf, 0.0L);
         if (cheb) {
-            if (np_ + 2 * nt - 1 > ANNP_CPAD) { fail(h, 0, "descriptor too large for the coefficient buffer"); return bail(ANNP_HIP_ESHAPE); }
+            if (np_ + 2 * nt + 1 > ANNP_CPAD) { fail(h, 0, "descriptor too large for the coefficient buffer"); return bail(ANNP_HIP_ESHAPE); }
             // coefficients of z^k in T_n((z+1)/2): T_0 = 1, T_1 = (1+z)/2, T_n = (1+z) T_{n-1} - T_{n-2}.
             // All entries are dyadic rationals below 2^53, so this recurrence is exact.
             std::vector<double> M((size_t)nt * nt, 0.0), a(nt, 0.0), b(nt, 0.0), tt(nt, 0.0);
@@ -1042,8 +1042,14 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
             for (int m = 0; m < np_; m++) T[(size_t)m * nsf + m] = 1.0L;                          // radial c_m
             for (int k = 0; k < nt; k++)                                                          // p_k
                 for (int n = 0; n < nt; n++) T[(size_t)(np_ + k) * nsf + np_ + n] = M[(size_t)k * nt + n];
-            for (int k = 0; k + 1 < nt; k++)                                                      // d_k = (k+1) p_{k+1}
-                for (int n = 0; n < nt; n++) T[(size_t)(np_ + nt + k) * nsf + np_ + n] = (long double)(k + 1) * M[(size_t)(k + 1) * nt + n];
+            // W_l, the same polynomial in Legendre polynomials (T_n((z+1)/2) = sum_l q_nl P_l(z), sh_tables.hpp), and P(1) = sum_n c_n:
+            // what the force pass on the moments wants (fe_shf_kernels.hpp).  (The pair-loop force kernel makes its derivative
+            // coefficients (k+1) p_(k+1) itself; rounds 1-3 shipped them in these rows.)
+            static const double shq[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_Q_INIT;
+            static_assert(FE_NT == SH_LMAX + 1 && FE_NP + 2 * FE_NT + 1 <= ANNP_CPAD, "coefficient row: c_m | p_k | W_l | P(1)");
+            for (int l = 0; l < nt; l++)
+                for (int n = 0; n < nt; n++) T[(size_t)(np_ + nt + l) * nsf + np_ + n] = shq[n * nt + l];
+            for (int n = 0; n < nt; n++) T[(size_t)(np_ + 2 * nt) * nsf + np_ + n] = 1.0L;
         } else {
             for (int k = 0; k < nsf; k++) T[(size_t)k * nsf + k] = 1.0L;
         }

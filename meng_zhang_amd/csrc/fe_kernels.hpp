@@ -472,7 +472,7 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
 #pragma unroll
     for (int m = 0; m < NT; m++) ce[m] = cf[NP + m];
 #pragma unroll
-    for (int m = 0; m < NT - 1; m++) cd[m] = cf[NP + NT + m];
+    for (int m = 0; m < NT - 1; m++) cd[m] = (double)(m + 1) * ce[m + 1];        // P'(z): d_k = (k+1) p_(k+1)
     cd[NT - 1] = 0.0;
     // the two Horner chains start from a register, not from a second SGPR operand per step
     double ce_top = ce[NT - 1], cd_top = cd[NT - 2];

@@ -30,39 +30,72 @@ namespace annp {
 constexpr int SHF_GA = 4;             // atoms per wave
 constexpr int SHF_GL = 16;            // lanes per atom
 constexpr int SHF_TURN = 4;           // neighbours of a lane in registers at a time
-constexpr int SHF_WAVES = 4;          // waves per workgroup
-constexpr int SHF_TSLOTS = 1024;      // slots of the workgroup's force table (16 atoms of a bcc row reach ~410 distinct atoms)
-constexpr int SHF_TPROBE = 8;         // occupied slots tried before a contribution goes straight to global memory
-constexpr int SHF_TBYTES = SHF_NE * 16;       // an atom's table: 190 x (b^c, b^s)
+#ifndef ANNP_SHF_WAVES
+#define ANNP_SHF_WAVES 4
+#endif
+constexpr int SHF_WAVES = ANNP_SHF_WAVES;          // waves per workgroup (4: two workgroups per CU)
+constexpr int SHF_BBITS = SHF_WAVES > 4 ? 8 : SHF_WAVES == 4 ? 7 : SHF_WAVES == 2 ? 6 : 5;
+constexpr int SHF_NBUCK = 1 << SHF_BBITS;          // buckets of the workgroup's force table
+constexpr int SHF_BATOMS = 8;                      // atoms per bucket: 8 x 24 B = 192 B = three 64-byte lines of f
+constexpr int SHF_TPROBE = 8;                      // occupied buckets tried before a contribution goes straight to global memory
+constexpr int SHF_TBYTES = SHF_NE * 16;            // an atom's coefficient table: 190 x (b^c, b^s)
 static_assert((SHF_TBYTES / 4) % 64 >= 4 && (SHF_TBYTES / 4) % 64 <= 60, "two atoms' entries of one read must not share banks");
 
 __constant__ unsigned char annp_shf_l[SHF_NE + 2] = ANNP_SHF_L_INIT;
 __constant__ double annp_shf_conv[SHF_CONV_NREC * 16] = ANNP_SHF_CONV_INIT;
 
-// LDS of one wave: the four tables, 32 bytes of slack (the last column's look-ahead reads them), W_l [4][20]
-__host__ __device__ constexpr size_t shf_lds_per_wave() { return (size_t)SHF_GA * SHF_TBYTES + 32 + SHF_GA * 20 * 8; }
-__host__ __device__ constexpr size_t shf_lds_table() { return (size_t)SHF_TSLOTS * (4 + 24); }
+// LDS of one wave: the four tables, 32 bytes of slack (the last column's look-ahead reads them), then per atom W_l [19], P(1), c_m [9]
+constexpr int SHF_WPAD = 30;
+__host__ __device__ constexpr size_t shf_lds_per_wave() { return (size_t)SHF_GA * SHF_TBYTES + 32 + SHF_GA * SHF_WPAD * 8; }
+__host__ __device__ constexpr size_t shf_lds_table() { return (size_t)SHF_NBUCK * (SHF_BATOMS * 24 + 16); }
 __host__ __device__ constexpr size_t shf_lds_per_block() { return shf_lds_table() + SHF_WAVES * shf_lds_per_wave(); }
 static_assert(shf_lds_per_wave() % 16 == 0 && shf_lds_table() % 16 == 0, "b128 alignment of every wave's tables");
 
+// Forces leave through a table in LDS that the atoms of a workgroup share (round 3), and the table leaves through as few
+// memory requests as it can.  A float atomic is executed at the memory side, one request per 64-byte line a wave-instruction
+// touches (MI355X_MICROARCH.md, Global float atomics): with one lane per (atom, component) scattered over the force array the
+// pass issued ~76 requests per atom and ran at their rate -- 4.6 ms per 1 M atoms with the arithmetic switched off, of 6.1.
+// A bucket therefore holds EIGHT atoms with consecutive indices (24 doubles = three lines), open addressing is on index >> 3,
+// and the flush walks the table in memory order: a wave-instruction writes 64 consecutive doubles of the table = 2.7 buckets
+// = 8-9 lines.  Atoms that are neighbours in space are neighbours in index wherever the caller sorts its atoms (LAMMPS:
+// atom_modify sort, on by default); where they are not, a bucket holds one atom, the table fills up (SHF_NBUCK buckets) and the
+// contributions beyond it go to memory one by one -- slower, never wrong.  Untouched slots hold +0.0 and are skipped.
 struct ShfTable {
-    int *key;          // [SHF_TSLOTS], -1 = free
-    double *acc;       // [SHF_TSLOTS][3]
+    int *key;          // [SHF_NBUCK]: index >> 3 of the bucket's atoms, -1 = free
+    double *acc;       // [SHF_NBUCK][8][3]
     double *f;
     __device__ __forceinline__ void add(int j, double fx, double fy, double fz) const
     {
-        unsigned sl = ((unsigned)j * 0x9E3779B1u) >> 22;
-        static_assert(SHF_TSLOTS == 1024, "hash width");
+        const int b = j >> 3;
+        unsigned h = ((unsigned)b * 0x9E3779B1u) >> (32 - SHF_BBITS);
 #pragma unroll 1
         for (int probe = 0; probe < SHF_TPROBE; probe++) {
-            const int old = atomicCAS(&key[sl], -1, j);
-            if (old == -1 || old == j) {
-                atomicAdd(&acc[3 * sl], fx); atomicAdd(&acc[3 * sl + 1], fy); atomicAdd(&acc[3 * sl + 2], fz);
+            // most contributions find their bucket taken by an earlier one: a plain read settles those, the compare-and-swap
+            // (an atomic with a return value) is for the free ones only
+            int old = __hip_atomic_load(&key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == -1) old = atomicCAS(&key[h], -1, b);
+            if (old == -1 || old == b) {
+                double *a = acc + (h * SHF_BATOMS + (j & 7)) * 3;
+                atomicAdd(a, fx); atomicAdd(a + 1, fy); atomicAdd(a + 2, fz);
                 return;
             }
-            sl = (sl + 1) & (SHF_TSLOTS - 1);
+            h = (h + 1) & (SHF_NBUCK - 1);
         }
         atomicAdd(&f[3 * (size_t)j], fx); atomicAdd(&f[3 * (size_t)j + 1], fy); atomicAdd(&f[3 * (size_t)j + 2], fz);
+    }
+    __device__ __forceinline__ void clear(int tid, int nthreads) const
+    {
+        for (int k = tid; k < SHF_NBUCK * SHF_BATOMS * 3; k += nthreads) acc[k] = 0.0;
+        for (int k = tid; k < SHF_NBUCK; k += nthreads) key[k] = -1;
+    }
+    __device__ __forceinline__ void flush(int tid, int nthreads) const
+    {
+        for (int k = tid; k < SHF_NBUCK * SHF_BATOMS * 3; k += nthreads) {
+            const int h = k / (SHF_BATOMS * 3), r = k - h * (SHF_BATOMS * 3);
+            const int b = key[h];
+            const double v = acc[k];
+            if (b >= 0 && v != 0.0) atomicAdd(&f[(size_t)b * (SHF_BATOMS * 3) + r], v);
+        }
     }
 };
 
@@ -93,7 +126,7 @@ __device__ __forceinline__ shf_v2d shf_entry(unsigned tb, int e) { return *(shf_
 // the powers j = l and (K > 16) j = 16 + l; every read of a block of 16 powers is issued before its writes (LDS operations of a
 // wave execute in order), and the second block only reads entries the first has not written.
 template <int M, int BLK>
-__device__ __forceinline__ void shf_convert_block(double2 *T, const int l)
+__device__ __forceinline__ void shf_convert_block(double2 *T, double2 *dump, const double *conv, const int l)
 {
     constexpr int K = SH_LMAX + 1 - M;
     constexpr int base = shf_toff(M);
@@ -103,30 +136,32 @@ __device__ __forceinline__ void shf_convert_block(double2 *T, const int l)
     double ax = 0.0, ay = 0.0;
 #pragma unroll
     for (int t = 0; t < nt; t++) {
-        const double mv = annp_shf_conv[(first + t) * 16 + l];        // 0 where j + 2t > K-1
+        const double mv = conv[(first + t) * 16 + l];        // 0 where j + 2t > K-1
         const int k = min(j + 2 * t, K - 1);
         const double2 b = T[base + K - 1 - k];
         ax = fma(mv, b.x, ax); ay = fma(mv, b.y, ay);
     }
-    if (j < K) T[base + K - 1 - j] = make_double2(ax, ay);
+    // (no branch around the block: with one, the compiler sinks the block's loads into it and waits for them there, a round trip
+    // through the cache per block and 22 blocks; a lane without a power writes the slack behind the wave's tables)
+    *(j < K ? T + (base + K - 1 - j) : dump) = make_double2(ax, ay);
 }
 template <int M>
-__device__ __forceinline__ void shf_convert_column(double2 *T, const int l)
+__device__ __forceinline__ void shf_convert_column(double2 *T, double2 *dump, const double *conv, const int l)
 {
-    shf_convert_block<M, 0>(T, l);
-    if (SH_LMAX + 1 - M > 16) shf_convert_block<M, (SH_LMAX + 1 - M > 16 ? 16 : 0)>(T, l);
+    shf_convert_block<M, 0>(T, dump, conv, l);
+    if (SH_LMAX + 1 - M > 16) shf_convert_block<M, (SH_LMAX + 1 - M > 16 ? 16 : 0)>(T, dump, conv, l);
 }
 template <int M>
 struct ShfConvert {
-    static __device__ __forceinline__ void run(double2 *T, const int l)
+    static __device__ __forceinline__ void run(double2 *T, double2 *dump, const double *conv, const int l)
     {
-        shf_convert_column<M>(T, l);
-        ShfConvert<M + 1>::run(T, l);
+        shf_convert_column<M>(T, dump, conv, l);
+        ShfConvert<M + 1>::run(T, dump, conv, l);
     }
 };
 template <>
 struct ShfConvert<SH_LMAX + 1> {
-    static __device__ __forceinline__ void run(double2 *, const int) {}
+    static __device__ __forceinline__ void run(double2 *, double2 *, const double *, const int) {}
 };
 
 // ---- value and gradient of U at CC neighbours of this lane.  tb = LDS byte address of the atom's table.
@@ -147,6 +182,8 @@ __device__ __forceinline__ void shf_evaluate(const unsigned tb, const double (&z
             const double nhx = fma3(Hx[u], wx[u], fnma3(Hy[u], wy[u], dc[u]));
             const double nhy = fma3(Hx[u], wy[u], fma3n(Hy[u], wx[u], ds[u]));
             Dx[u] = ndx; Dy[u] = ndy; Fx[u] = nfx; Fy[u] = nfy; Hx[u] = nhx; Hy[u] = nhy;
+            // one neighbour after the other: interleaved, the four neighbours' twelve intermediate values each are what spills
+            asm volatile("" : "+v"(Dx[u]), "+v"(Dy[u]), "+v"(Fx[u]), "+v"(Fy[u]), "+v"(Hx[u]), "+v"(Hy[u]));
         }
     };
     // one step of Horner's rule with derivative (the derivative first: it does not wait for the entry)
@@ -246,76 +283,78 @@ struct ShfAtom {            // what a lane knows of its atom
     int ii, i, n;           // list entry, atom index, in-cutoff neighbours (0: nothing to do)
     double xi, yi, zi;
     double pone;            // P(1) = sum_k p_k
-    const double *cf;       // the atom's coefficient row
-    const int *row;         // its in-cutoff neighbours (annp_fe_desc_sh's hand-over)
+};
+constexpr int SHF_SLOTS = 2 * SHF_TURN;          // neighbours of a lane: a = l + 16 u, u < 8
+struct ShfNbrs {            // the lane's neighbours: index and r_i - r_j (requested together, before anything is computed)
+    int j[SHF_SLOTS];
+    double dx[SHF_SLOTS], dy[SHF_SLOTS], dz[SHF_SLOTS];
 };
 
-// one turn: neighbours u0 .. u0+CC-1 of this lane (a = l + 16 u): geometry and radial term (fe:648), U and grad U, force assembly
-template <int NP, int CC, bool VIRIAL>
-__device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, const int l, const int u0, const unsigned tb, const ShfTable &tab,
-                                         double (&fi)[3], double (&vs)[6])
+// one turn: neighbour slots U0 .. U0+CC-1 of this lane: geometry and radial term (fe:648), U and grad U from the table, force
+// assembly (fe:190-213), into the force table.  Nothing in here waits for memory.
+template <int NP, int U0, int CC, bool VIRIAL>
+__device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, const int l, const ShfNbrs &nb, const double *crl,
+                                         const double pi_over_rc, const double two_over_rcp, const unsigned tb,
+                                         const ShfTable &tab, double (&fi)[3], double (&vs)[6])
 {
-    const double pi_over_rc = ANNP_MY_PI / p.rc_list;
-    const double two_over_rcp = 2.0 / p.rc_par;
-    int jn[CC];
+    // F_n = e [ al (e . grad U) - be U + g0 ] - al grad U  with e = (wx, wy, z), al = fc / r, be = fc', g0 = -R + P(1) fc fc'
     double z[CC], wx[CC], wy[CC], al[CC], be[CC], g0[CC], rr[VIRIAL ? CC : 1];
-    {
-#pragma unroll
-        for (int u = 0; u < CC; u++) jn[u] = at.n > 0 ? at.row[min(l + SHF_GL * (u0 + u), at.n - 1)] : at.i;
-        double cr[NP];
-#pragma unroll
-        for (int m = 0; m < NP; m++) cr[m] = at.cf[m];
-        double dx[CC], dy[CC], dz[CC];
-#pragma unroll
-        for (int u = 0; u < CC; u++) {
-            dx[u] = at.xi - p.x[3 * (size_t)jn[u]]; dy[u] = at.yi - p.x[3 * (size_t)jn[u] + 1]; dz[u] = at.zi - p.x[3 * (size_t)jn[u] + 2];
-        }
-#pragma unroll
-        for (int u = 0; u < CC; u++) {
-            const bool has = l + SHF_GL * (u0 + u) < at.n;
-            double2 R0 = make_double2(dx[u], dy[u]), R1 = make_double2(dz[u], dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u]);
-            if (!has) { R0 = make_double2(0.0, 0.0); R1 = make_double2(1.0, 1.0); }
-            const FeNbr g = sh_geometry(R0, R1, pi_over_rc);
-            const double xr = g.r * two_over_rcp - 1.0;
-            const double y2 = 2.0 * xr;
-            double tm2 = 1.0, tm1 = xr, dm2 = 0.0, dm1 = 1.0;
-            double st = cr[0], sd = 0.0;              // sum c T, sum c T'
-            if (NP > 1) { st = fma(cr[1], xr, st); sd = cr[1]; }
-#pragma unroll
-            for (int mm = 2; mm < NP; mm++) {
-                const double t = fma(y2, tm1, -tm2);
-                const double d = fma(y2, dm1, fma(2.0, tm1, -dm2));
-                st = fma(cr[mm], t, st);
-                sd = fma(cr[mm], d, sd);
-                tm2 = tm1; tm1 = t; dm2 = dm1; dm1 = d;
-            }
-            const double R = fma(sd * two_over_rcp, g.fc, st * g.dfc);        // d/dr of the radial part
-            z[u] = g.ez; wx[u] = g.ex; wy[u] = g.ey;
-            // F_n = e [ al (e . grad U) - be U + g0 ] - al grad U:  al = fc / r, be = fc', g0 = -R + P(1) fc fc'
-            al[u] = has ? g.fc * g.rinv : 0.0;
-            be[u] = has ? g.dfc : 0.0;
-            g0[u] = has ? fma(at.pone * g.fc, g.dfc, -R) : 0.0;
-            if (VIRIAL) rr[u] = g.r;
-        }
-    }
-    double U[CC], Ux[CC], Uy[CC], Uz[CC];
-    shf_evaluate<CC>(tb, z, wx, wy, U, Ux, Uy, Uz);
 #pragma unroll
     for (int u = 0; u < CC; u++) {
-        if (l + SHF_GL * (u0 + u) < at.n) {
+        const bool has = l + SHF_GL * (U0 + u) < at.n;
+        const double dx = nb.dx[U0 + u], dy = nb.dy[U0 + u], dz = nb.dz[U0 + u];
+        double2 R0 = make_double2(dx, dy), R1 = make_double2(dz, dx * dx + dy * dy + dz * dz);
+        if (!has) { R0 = make_double2(0.0, 0.0); R1 = make_double2(1.0, 1.0); }
+        const FeNbr g = sh_geometry(R0, R1, pi_over_rc);
+        const double xr = g.r * two_over_rcp - 1.0;
+        const double y2 = 2.0 * xr;
+        double tm2 = 1.0, tm1 = xr, dm2 = 0.0, dm1 = 1.0;
+        double st = crl[0], sd = 0.0;              // sum c T, sum c T'  (c_m from LDS: the atom's lanes read the same words)
+        if (NP > 1) { const double c1 = crl[1]; st = fma(c1, xr, st); sd = c1; }
+#pragma unroll
+        for (int mm = 2; mm < NP; mm++) {
+            const double cm = crl[mm];
+            const double t = fma(y2, tm1, -tm2);
+            const double d = fma(y2, dm1, fma(2.0, tm1, -dm2));
+            st = fma(cm, t, st);
+            sd = fma(cm, d, sd);
+            tm2 = tm1; tm1 = t; dm2 = dm1; dm1 = d;
+        }
+        const double R = fma(sd * two_over_rcp, g.fc, st * g.dfc);        // d/dr of the radial part
+        z[u] = g.ez; wx[u] = g.ex; wy[u] = g.ey;
+        al[u] = has ? g.fc * g.rinv : 0.0;
+        be[u] = has ? g.dfc : 0.0;
+        g0[u] = has ? fma(at.pone * g.fc, g.dfc, -R) : 0.0;
+        if (VIRIAL) rr[u] = g.r;
+        // one neighbour after the other (the sine and cosine series of one are two independent chains: enough to keep the pipe
+        // busy); four at once is where the register file runs out
+        asm volatile("" : "+v"(z[u]), "+v"(wx[u]), "+v"(wy[u]), "+v"(al[u]), "+v"(be[u]), "+v"(g0[u]));
+    }
+    double U[CC], Ux[CC], Uy[CC], Uz[CC];
+#ifdef ANNP_SHF_SKIP_EVAL       // developer timing builds only: everything but the columns
+#pragma unroll
+    for (int u = 0; u < CC; u++) { U[u] = z[u]; Ux[u] = wx[u]; Uy[u] = wy[u]; Uz[u] = z[u] * wx[u]; }
+#else
+    shf_evaluate<CC>(tb, z, wx, wy, U, Ux, Uy, Uz);
+#endif
+#pragma unroll
+    for (int u = 0; u < CC; u++) {
+        if (l + SHF_GL * (U0 + u) < at.n) {
             const double ed = fma(wx[u], Ux[u], fma(wy[u], Uy[u], z[u] * Uz[u]));
             const double t = fma(al[u], ed, fma(-be[u], U[u], g0[u]));
             const double f0 = fma(t, wx[u], -al[u] * Ux[u]);
             const double f1 = fma(t, wy[u], -al[u] * Uy[u]);
             const double f2 = fma(t, z[u], -al[u] * Uz[u]);
-            tab.add(jn[u], -f0, -f1, -f2);                    // F_a = -Fn_a to the neighbour, +Fn_a to the centre (fe:199-211)
+#ifndef ANNP_SHF_SKIP_ADD
+            tab.add(nb.j[U0 + u], -f0, -f1, -f2);                    // F_a = -Fn_a to the neighbour, +Fn_a to the centre (fe:199-211)
+#endif
             fi[0] += f0; fi[1] += f1; fi[2] += f2;
             if (VIRIAL) {   // ev_tally_xyz(i,j,...,fx=-Fj, del = xi-xj = r e)   (fe:201-209)
                 const double d0 = rr[u] * wx[u], d1 = rr[u] * wy[u], d2 = rr[u] * z[u];
                 const double w0 = d0 * f0, w1 = d1 * f1, w2 = d2 * f2, w3 = d0 * f1, w4 = d0 * f2, w5 = d1 * f2;
                 vs[0] += w0; vs[1] += w1; vs[2] += w2; vs[3] += w3; vs[4] += w4; vs[5] += w5;
                 if (p.vatom) {
-                    double *vj = p.vatom + 6 * (size_t)jn[u];
+                    double *vj = p.vatom + 6 * (size_t)nb.j[U0 + u];
                     atomicAdd(vj + 0, 0.5 * w0); atomicAdd(vj + 1, 0.5 * w1); atomicAdd(vj + 2, 0.5 * w2);
                     atomicAdd(vj + 3, 0.5 * w3); atomicAdd(vj + 4, 0.5 * w4); atomicAdd(vj + 5, 0.5 * w5);
                 }
@@ -324,93 +363,111 @@ __device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, con
     }
 }
 
-template <int NP, bool VIRIAL>
-__device__ __forceinline__ void shf_turns(const FeArgs &p, const ShfAtom &at, const int l, const int u0, const int cc, const unsigned tb,
-                                          const ShfTable &tab, double (&fi)[3], double (&vs)[6])
-{
-    switch (cc) {           // (uniform)
-    case 1: shf_turn<NP, 1, VIRIAL>(p, at, l, u0, tb, tab, fi, vs); break;
-    case 2: shf_turn<NP, 2, VIRIAL>(p, at, l, u0, tb, tab, fi, vs); break;
-    case 3: shf_turn<NP, 3, VIRIAL>(p, at, l, u0, tb, tab, fi, vs); break;
-    case 4: shf_turn<NP, 4, VIRIAL>(p, at, l, u0, tb, tab, fi, vs); break;
-    default: break;
-    }
-}
+// developer timing builds (tools/shf_stamps.py): -DANNP_SHF_STAMPS writes s_memtime at a few points of a wave's life into the
+// descriptor row of its first atom (the descriptor buffer is dead by then); no stamp is compiled into the library
+#ifdef ANNP_SHF_STAMPS
+#define SHF_STAMP(k) do { if (stamp_row && lane_id() == 0) stamp_row[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SHF_STAMP(k) do { } while (0)
+#endif
 
+// A wave's life is one stretch of waiting (the count and the candidates, then the positions; the moments arrive behind the
+// geometry), one stretch of arithmetic (the table, then both turns back to back) and the hand-over of the forces.  Two waves
+// share a SIMD: with the arithmetic in ONE stretch the partner's waiting falls beside it.  (With a stretch of waiting in front
+// of each turn -- positions and geometry of the turn's own neighbours -- the two waves of a SIMD settled half a life apart,
+// turn beside turn and wait beside wait: 5.8 ms per 1 M atoms for 4.1 ms of issue slots; tools/shf_stamps.py.)
 template <int NP, int NT, bool VIRIAL>
 __global__ __launch_bounds__(64 * SHF_WAVES, 2) void annp_fe_force_sh(FeArgs p)
 {
-    static_assert(NT == SH_LMAX + 1 && NP + 2 * NT - 1 <= ANNP_CPAD, "coefficient row");
+    static_assert(NT == SH_LMAX + 1 && NP + 2 * NT + 1 <= ANNP_CPAD && NP + 1 <= SHF_GL, "coefficient row: c_m | p_k | W_l | P(1)");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
     ShfTable tab;
-    tab.key = reinterpret_cast<int *>(lds_raw + (size_t)SHF_TSLOTS * 24);
+    tab.key = reinterpret_cast<int *>(lds_raw + (size_t)SHF_NBUCK * SHF_BATOMS * 24);
     tab.acc = reinterpret_cast<double *>(lds_raw);
     tab.f = p.f;
-    for (int sl = threadIdx.x; sl < SHF_TSLOTS; sl += 64 * SHF_WAVES) {
-        tab.key[sl] = -1; tab.acc[3 * sl] = 0.0; tab.acc[3 * sl + 1] = 0.0; tab.acc[3 * sl + 2] = 0.0;
+#ifdef ANNP_SHF_STAMPS
+    unsigned long long *stamp_row = nullptr;
+    {
+        const int ii0 = (xcd_block() * SHF_WAVES + (int)(threadIdx.x >> 6)) * SHF_GA;
+        if (ii0 < p.inum) stamp_row = reinterpret_cast<unsigned long long *>(p.G + (size_t)ii0 * ANNP_GPAD);
+        if (stamp_row && lane_id() == 0) { stamp_row[15] = __builtin_amdgcn_s_getreg(0xF804); stamp_row[14] = blockIdx.x; stamp_row[13] = __builtin_amdgcn_s_getreg(0xF814); }
     }
-    __syncthreads();
-
+#endif
+    SHF_STAMP(0);
+#ifdef ANNP_SHF_STAGGER         // developer experiment: the two workgroups of a CU's first generation start apart
+    if (p.dbg > 0 && blockIdx.x < 512 && ((blockIdx.x >> 8) & 1))
+        for (int k = 0; k < p.dbg; k++) __builtin_amdgcn_s_sleep(127);
+#endif
     unsigned char *wbase = lds_raw + shf_lds_table() + (size_t)wave * shf_lds_per_wave();
     const int g = lane >> 4, l = lane & 15;
     double2 *T = reinterpret_cast<double2 *>(wbase + (size_t)g * SHF_TBYTES);
-    double *Wl = reinterpret_cast<double *>(wbase + (size_t)SHF_GA * SHF_TBYTES + 32) + g * 20;
+    double *Wl = reinterpret_cast<double *>(wbase + (size_t)SHF_GA * SHF_TBYTES + 32) + g * SHF_WPAD;      // W_l [19], P(1), c_m [9]
+    const double pi_over_rc = ANNP_MY_PI / p.rc_list;
+    const double two_over_rcp = 2.0 / p.rc_par;
 
-    // ---- this lane's atom
+    // ---- this lane's atom.  Everything whose address follows from the list entry alone is requested at once: the count, the
+    //      eight candidate neighbours of the lane, the moments (entries l, l+16, .. of the 190 pairs), and from the coefficient
+    //      row W_l, c_m and P(1), which the network pass leaves there.
     ShfAtom at;
     at.ii = (xcd_block() * SHF_WAVES + wave) * SHF_GA + g;
-    at.n = 0; at.i = 0;
-    if (at.ii < p.inum) {
-        at.i = p.ilist ? p.ilist[at.ii] : at.ii;
-        at.n = p.ncount[at.ii];
-        if (p.type && !type_mapped(p.active, p.type[at.i])) at.n = 0;
-        if (at.n > p.n_cap) {            // no moments for this atom: the pair loop takes it (annp_fe_force_fixup)
-            if (l == 0) {
-                const int k = p.ovf_list ? atomicAdd(p.ovf_count, 1) : p.ovf_cap;
-                if (k < p.ovf_cap) p.ovf_list[k] = at.ii;
-                else atomicMax(p.errflag, at.n);
-            }
-            at.n = 0;
-        }
-    }
-    const int nmax = max(max(__builtin_amdgcn_readlane(at.n, 0), __builtin_amdgcn_readlane(at.n, 16)),
-                         max(__builtin_amdgcn_readlane(at.n, 32), __builtin_amdgcn_readlane(at.n, 48)));
-    if (nmax > 0) {
-        const size_t iis = at.n > 0 ? (size_t)at.ii : 0;            // (an atom with nothing to do reads row 0 and ignores it)
-        at.cf = p.coef + iis * ANNP_CPAD;
-        at.row = p.nbrs + iis * SH_CAP_MAX;
-        at.xi = p.x[3 * (size_t)at.i]; at.yi = p.x[3 * (size_t)at.i + 1]; at.zi = p.x[3 * (size_t)at.i + 2];
-        // ---- the moments of the atom, requested first: entries l, l+16, .. of its 190 (cosine, sine) pairs
-        const double2 *Am = reinterpret_cast<const double2 *>(p.A + iis * SH_MPAD);
-        constexpr int NR = (SHF_NE + SHF_GL - 1) / SHF_GL;
-        double2 am[NR];
-        int lw[NR];
+    const bool exists = at.ii < p.inum;
+    const size_t iic = (size_t)min(at.ii, p.inum - 1);
+    at.i = p.ilist ? p.ilist[iic] : (int)iic;
+    at.n = p.ncount[iic];
+    const double *cf = p.coef + iic * ANNP_CPAD;
+    int jall[SHF_SLOTS];
+#pragma unroll
+    for (int u = 0; u < SHF_SLOTS; u++) jall[u] = p.nbrs[iic * SH_CAP_MAX + l + SHF_GL * u];
+    constexpr int NR = (SHF_NE + SHF_GL - 1) / SHF_GL;
+    double2 am[NR];
+    int lw[NR];
+    {
+        const double2 *Am = reinterpret_cast<const double2 *>(p.A + iic * SH_MPAD);
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             const int e = min(l + SHF_GL * r, SHF_NE - 1);
             am[r] = Am[e];
             lw[r] = annp_shf_l[e];
         }
-        // ---- W_l = sum_k p_k ml[k][l] (lane l: W_l, lanes 0..2 also W_(16+l)); P(1) = sum_k p_k
-        {
-            double pk[NT];
-#pragma unroll
-            for (int k = 0; k < NT; k++) pk[k] = at.cf[NP + k];
-            double w0 = 0.0, w1 = 0.0, s = 0.0;
-            const int l1 = min(l + 16, NT - 1);
-#pragma unroll
-            for (int k = 0; k < NT; k++) {
-                w0 = fma(pk[k], annp_sh_ml[k * NT + l], w0);
-                if (k >= 16) w1 = fma(pk[k], annp_sh_ml[k * NT + l1], w1);
-                s += pk[k];
-            }
-            at.pone = s;
-            Wl[l] = w0;
-            if (l + 16 < NT) Wl[l + 16] = w1;
+    }
+    const double w_lo = cf[NP + NT + l];                               // W_l, l = lane
+    const double w_hi = cf[NP + NT + min(l + SHF_GL, NT)];             // W_(16+l) for l < 3; lane 3: P(1)
+    const double c_l = cf[min(l, NP - 1)];                             // c_m, m = lane
+    at.xi = p.x[3 * (size_t)at.i]; at.yi = p.x[3 * (size_t)at.i + 1]; at.zi = p.x[3 * (size_t)at.i + 2];
+    tab.clear(threadIdx.x, 64 * SHF_WAVES);
+    __syncthreads();                                         // the force table is clear (the requests above are on their way)
+    if (!exists) at.n = 0;
+    if (p.type && !type_mapped(p.active, p.type[at.i])) at.n = 0;
+    if (at.n > p.n_cap) {            // no moments for this atom: the pair loop takes it (annp_fe_force_fixup)
+        if (l == 0) {
+            const int k = p.ovf_list ? atomicAdd(p.ovf_count, 1) : p.ovf_cap;
+            if (k < p.ovf_cap) p.ovf_list[k] = at.ii;
+            else atomicMax(p.errflag, at.n);
         }
+        at.n = 0;
+    }
+    const int nmax = max(max(__builtin_amdgcn_readlane(at.n, 0), __builtin_amdgcn_readlane(at.n, 16)),
+                         max(__builtin_amdgcn_readlane(at.n, 32), __builtin_amdgcn_readlane(at.n, 48)));
+    const int C = (nmax + SHF_GL - 1) / SHF_GL;              // neighbours per lane (uniform), 0 .. 8
+    SHF_STAMP(1);
+    if (nmax > 0) {
+        // ---- positions of all the lane's neighbours (a slot without one reads the centre's own)
+        ShfNbrs nb;
+#pragma unroll
+        for (int u = 0; u < SHF_SLOTS; u++) {
+            nb.j[u] = (l + SHF_GL * u < at.n) ? jall[u] : at.i;
+            if (u < C) {
+                nb.dx[u] = at.xi - p.x[3 * (size_t)nb.j[u]]; nb.dy[u] = at.yi - p.x[3 * (size_t)nb.j[u] + 1]; nb.dz[u] = at.zi - p.x[3 * (size_t)nb.j[u] + 2];
+            } else { nb.dx[u] = 0.0; nb.dy[u] = 0.0; nb.dz[u] = 0.0; }
+        }
+        Wl[l] = w_lo;
+        if (l + SHF_GL <= NT) Wl[l + SHF_GL] = w_hi;         // [16..18] W, [19] P(1)
+        if (l < NP) Wl[20 + l] = c_l;
         wave_lds_sync();
+        at.pone = Wl[NT];
+        SHF_STAMP(2);
         // ---- B = W kappa A into the table, then its change of basis in place
 #pragma unroll
         for (int r = 0; r < NR; r++) {
@@ -419,16 +476,29 @@ __global__ __launch_bounds__(64 * SHF_WAVES, 2) void annp_fe_force_sh(FeArgs p)
             if (e < SHF_NE) T[e] = at.n > 0 ? make_double2(w * am[r].x, w * am[r].y) : make_double2(0.0, 0.0);
         }
         wave_lds_sync();
-        ShfConvert<0>::run(T, l);
+        SHF_STAMP(3);
+#ifndef ANNP_SHF_SKIP_BUILD
+        ShfConvert<0>::run(T, reinterpret_cast<double2 *>(wbase + (size_t)SHF_GA * SHF_TBYTES) + 1, annp_shf_conv, l);
+#endif
         wave_lds_sync();
-
-        // ---- two turns over the lane's neighbours
+        SHF_STAMP(4);
+        // ---- the turns, back to back: 7 = 3 + 4 neighbours per lane
         const unsigned tb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)T;
-        const int C = (nmax + SHF_GL - 1) / SHF_GL;              // neighbours per lane (uniform), 1 .. 8
-        const int c1 = C <= SHF_TURN ? C : (C + 1) / 2;
+        const double *crl = Wl + 20;
         double fi[3] = {0.0, 0.0, 0.0}, vs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        shf_turns<NP, VIRIAL>(p, at, l, 0, c1, tb, tab, fi, vs);
-        if (C > c1) shf_turns<NP, VIRIAL>(p, at, l, c1, C - c1, tb, tab, fi, vs);
+#define SHF_T(U0, CC) shf_turn<NP, U0, CC, VIRIAL>(p, at, l, nb, crl, pi_over_rc, two_over_rcp, tb, tab, fi, vs)
+        switch (C) {            // (uniform)
+        case 1: SHF_T(0, 1); break;
+        case 2: SHF_T(0, 2); break;
+        case 3: SHF_T(0, 3); break;
+        case 4: SHF_T(0, 4); break;
+        case 5: SHF_T(0, 2); SHF_T(2, 3); break;
+        case 6: SHF_T(0, 3); SHF_T(3, 3); break;
+        case 7: SHF_T(0, 3); SHF_T(3, 4); break;
+        default: SHF_T(0, 4); SHF_T(4, 4); break;
+        }
+#undef SHF_T
+        SHF_STAMP(5);
         // ---- the centre's share: sums over the atom's 16 lanes end up in the row's last lane
 #pragma unroll
         for (int k = 0; k < 3; k++) fi[k] = row16_sum_to_last(fi[k]);
@@ -450,15 +520,13 @@ __global__ __launch_bounds__(64 * SHF_WAVES, 2) void annp_fe_force_sh(FeArgs p)
             }
         }
     }
+    SHF_STAMP(6);
     __syncthreads();
-    // the workgroup's table: one global atomic per distinct atom and component
-    for (int sl = threadIdx.x; sl < SHF_TSLOTS; sl += 64 * SHF_WAVES) {
-        const int j = tab.key[sl];
-        if (j >= 0) {
-            atomicAdd(&p.f[3 * (size_t)j], tab.acc[3 * sl]); atomicAdd(&p.f[3 * (size_t)j + 1], tab.acc[3 * sl + 1]);
-            atomicAdd(&p.f[3 * (size_t)j + 2], tab.acc[3 * sl + 2]);
-        }
-    }
+    SHF_STAMP(7);
+#ifndef ANNP_SHF_SKIP_FLUSH
+    tab.flush(threadIdx.x, 64 * SHF_WAVES);          // the workgroup's table, in memory order
+#endif
+    SHF_STAMP(8);
 }
 
 }  // namespace annp
