@@ -575,7 +575,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
                 if (vir) hipLaunchKernelGGL((annp_fe_force_sh3<FE_NP, FE_NT, true>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), sh3_lds_per_block(), s, a);
                 else hipLaunchKernelGGL((annp_fe_force_sh3<FE_NP, FE_NT, false>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), sh3_lds_per_block(), s, a);
             } else {
-                const int apb = SHF_WAVES * SHF_GA;         // atoms per workgroup
+                const int apb = SHF_GROUPS * SHF_GA;        // atoms per workgroup
                 if (vir) hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, true>), dim3((inum + apb - 1) / apb), dim3(64 * SHF_WAVES), shf_lds_per_block(), s, a);
                 else hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, false>), dim3((inum + apb - 1) / apb), dim3(64 * SHF_WAVES), shf_lds_per_block(), s, a);
             }

@@ -17,39 +17,46 @@
 // neighbourhoods with the potential's own coefficients the forces differ from the recurrence form by <= 1e-14 eV/A
 // (tests/test_sh_tables.py::test_force_form_on_monomials, against long double).
 //
-// Work decomposition: a wave takes FOUR atoms, 16 lanes each (as annp_fe_desc_sh does); a lane owns neighbours l, l+16, ..
-// of its atom and walks them in two turns of up to four (bcc Fe: 112 = 16 x (4 + 3), every lane slot used; round 3 gave a
-// wave one atom and 128 slots).  The 16 lanes of an atom read the same table entry: a ds_read_b128 with four distinct
-// addresses per wave serves 16 FMAs.  A workgroup is 4 waves = 16 consecutive atoms sharing the LDS force table that
-// round 3 introduced (open addressing on the atom index, one global atomic per distinct atom and component at the end).
+// Work decomposition: a GROUP is four atoms, 16 lanes each (as in annp_fe_desc_sh), and four waves work for it: wave q of the
+// group takes neighbours a = l + 16 u, u = 2q, 2q+1 of every lane (bcc Fe: 112 = 16 x (2+2+2+1), every lane slot used; round 3
+// gave a wave one atom and 128 slots) and a quarter of the table's columns to build.  Two neighbours per lane in registers
+// are 120 VGPRs: four waves per SIMD -- a wave by itself issues at most every other slot of the FP64 pipe (measured: the
+// same arithmetic in waves of 250 VGPRs, two per SIMD, one of them waiting half of its life, ran 5.8 ms per 1 M atoms for
+// 4.1 ms of issue slots; tools/shf_stamps.py).  The 16 lanes of an atom read the same table entry: a ds_read_b128 with four
+// distinct addresses per wave serves 8 FMAs.  A workgroup is two groups = 8 waves sharing the LDS force table.
 #pragma once
 #include "fe_sh_kernels.hpp"
 
 namespace annp {
 
-constexpr int SHF_GA = 4;             // atoms per wave
+constexpr int SHF_GA = 4;             // atoms per group
 constexpr int SHF_GL = 16;            // lanes per atom
-constexpr int SHF_TURN = 4;           // neighbours of a lane in registers at a time
-#ifndef ANNP_SHF_WAVES
-#define ANNP_SHF_WAVES 4
+constexpr int SHF_GW = 4;             // waves per group
+constexpr int SHF_CC = 2;             // neighbours of a lane in a wave's registers: SHF_GW * SHF_CC * 16 = 128 slots per atom
+#ifndef ANNP_SHF_GROUPS
+#define ANNP_SHF_GROUPS 2
 #endif
-constexpr int SHF_WAVES = ANNP_SHF_WAVES;          // waves per workgroup (4: two workgroups per CU)
-constexpr int SHF_BBITS = SHF_WAVES > 4 ? 8 : SHF_WAVES == 4 ? 7 : SHF_WAVES == 2 ? 6 : 5;
+constexpr int SHF_GROUPS = ANNP_SHF_GROUPS;        // groups per workgroup
+constexpr int SHF_WAVES = SHF_GW * SHF_GROUPS;     // waves per workgroup
+constexpr int SHF_BBITS = SHF_GROUPS >= 2 ? 7 : 6;
 constexpr int SHF_NBUCK = 1 << SHF_BBITS;          // buckets of the workgroup's force table
 constexpr int SHF_BATOMS = 8;                      // atoms per bucket: 8 x 24 B = 192 B = three 64-byte lines of f
 constexpr int SHF_TPROBE = 8;                      // occupied buckets tried before a contribution goes straight to global memory
 constexpr int SHF_TBYTES = SHF_NE * 16;            // an atom's coefficient table: 190 x (b^c, b^s)
 static_assert((SHF_TBYTES / 4) % 64 >= 4 && (SHF_TBYTES / 4) % 64 <= 60, "two atoms' entries of one read must not share banks");
+static_assert(SHF_GW * SHF_CC * SHF_GL == SH_CAP_MAX, "the waves of a group cover the neighbour slots of an atom");
 
 __constant__ unsigned char annp_shf_l[SHF_NE + 2] = ANNP_SHF_L_INIT;
 __constant__ double annp_shf_conv[SHF_CONV_NREC * 16] = ANNP_SHF_CONV_INIT;
 
-// LDS of one wave: the four tables, 32 bytes of slack (the last column's look-ahead reads them), then per atom W_l [19], P(1), c_m [9]
-constexpr int SHF_WPAD = 30;
-__host__ __device__ constexpr size_t shf_lds_per_wave() { return (size_t)SHF_GA * SHF_TBYTES + 32 + SHF_GA * SHF_WPAD * 8; }
+// LDS of a workgroup: the force table | per group: the four tables + 32 bytes of slack (look-ahead reads, idle lanes' writes) |
+// per wave: c_m [9] and P(1) of its four atoms
+constexpr int SHF_WPAD = 10;
 __host__ __device__ constexpr size_t shf_lds_table() { return (size_t)SHF_NBUCK * (SHF_BATOMS * 24 + 16); }
-__host__ __device__ constexpr size_t shf_lds_per_block() { return shf_lds_table() + SHF_WAVES * shf_lds_per_wave(); }
-static_assert(shf_lds_per_wave() % 16 == 0 && shf_lds_table() % 16 == 0, "b128 alignment of every wave's tables");
+__host__ __device__ constexpr size_t shf_lds_per_group() { return (size_t)SHF_GA * SHF_TBYTES + 32; }
+__host__ __device__ constexpr size_t shf_lds_per_wave() { return (size_t)SHF_GA * SHF_WPAD * 8; }
+__host__ __device__ constexpr size_t shf_lds_per_block() { return shf_lds_table() + SHF_GROUPS * shf_lds_per_group() + SHF_WAVES * shf_lds_per_wave(); }
+static_assert(shf_lds_per_group() % 16 == 0 && shf_lds_table() % 16 == 0, "b128 alignment of every group's tables");
 
 // Forces leave through a table in LDS that the atoms of a workgroup share (round 3), and the table leaves through as few
 // memory requests as it can.  A float atomic is executed at the memory side, one request per 64-byte line a wave-instruction
@@ -83,18 +90,31 @@ struct ShfTable {
         }
         atomicAdd(&f[3 * (size_t)j], fx); atomicAdd(&f[3 * (size_t)j + 1], fy); atomicAdd(&f[3 * (size_t)j + 2], fz);
     }
-    __device__ __forceinline__ void clear(int tid, int nthreads) const
+    // (both walk the table with compile-time strides: a handful of instructions per pass instead of an index computation per
+    // element -- four waves work for four atoms here, and what a wave does per workgroup it does per atom)
+    __device__ __forceinline__ void clear(int tid) const
     {
-        for (int k = tid; k < SHF_NBUCK * SHF_BATOMS * 3; k += nthreads) acc[k] = 0.0;
-        for (int k = tid; k < SHF_NBUCK; k += nthreads) key[k] = -1;
+        constexpr int NT2 = SHF_NBUCK * SHF_BATOMS * 3 / 2, TH = 64 * SHF_WAVES;
+        double2 *a2 = reinterpret_cast<double2 *>(acc);
+#pragma unroll
+        for (int k = 0; k < (NT2 + TH - 1) / TH; k++)
+            if (k * TH + TH <= NT2 || tid + k * TH < NT2) a2[tid + k * TH] = make_double2(0.0, 0.0);
+        if (tid < SHF_NBUCK) key[tid] = -1;
     }
-    __device__ __forceinline__ void flush(int tid, int nthreads) const
+    // thread t < 384 takes double t % 24 of buckets t / 24, t / 24 + 16, ..: a wave-instruction still writes 64 consecutive doubles of
+    // the table (2.7 buckets = 8-9 lines of f)
+    __device__ __forceinline__ void flush(int tid) const
     {
-        for (int k = tid; k < SHF_NBUCK * SHF_BATOMS * 3; k += nthreads) {
-            const int h = k / (SHF_BATOMS * 3), r = k - h * (SHF_BATOMS * 3);
-            const int b = key[h];
-            const double v = acc[k];
-            if (b >= 0 && v != 0.0) atomicAdd(&f[(size_t)b * (SHF_BATOMS * 3) + r], v);
+        constexpr int PB = 64 * SHF_WAVES >= 16 * SHF_BATOMS * 3 ? 16 : 8;         // buckets per pass
+        static_assert(64 * SHF_WAVES >= PB * SHF_BATOMS * 3 && SHF_NBUCK % PB == 0, "whole buckets per pass");
+        if (tid < PB * SHF_BATOMS * 3) {
+            const int h0 = tid / (SHF_BATOMS * 3), r = tid - h0 * (SHF_BATOMS * 3);
+#pragma unroll
+            for (int it = 0; it < SHF_NBUCK / PB; it++) {
+                const int b = key[h0 + PB * it];
+                const double v = acc[tid + PB * SHF_BATOMS * 3 * it];
+                if (b >= 0 && v != 0.0) atomicAdd(&f[(size_t)b * (SHF_BATOMS * 3) + r], v);
+            }
         }
     }
 };
@@ -126,44 +146,35 @@ __device__ __forceinline__ shf_v2d shf_entry(unsigned tb, int e) { return *(shf_
 // the powers j = l and (K > 16) j = 16 + l; every read of a block of 16 powers is issued before its writes (LDS operations of a
 // wave execute in order), and the second block only reads entries the first has not written.
 template <int M, int BLK>
-__device__ __forceinline__ void shf_convert_block(double2 *T, double2 *dump, const double *conv, const int l)
+__device__ __forceinline__ void shf_convert_block(const unsigned tcol, const unsigned dump, const double *conv, const int l)
 {
+    // tcol: LDS byte address of the column's first entry (power K-1) in this lane's table.  Power k sits at tcol + 16 (K-1-k); lane l
+    // reads the powers l + 2t, t = 0, 1, .. (clamped to the column: the record holds a zero there) and writes power l.
     constexpr int K = SH_LMAX + 1 - M;
-    constexpr int base = shf_toff(M);
     constexpr int first = SHF_CONV_FIRST[M][BLK / 16];
     constexpr int nt = (K - BLK + 1) / 2;
-    const int j = BLK + l;
+    const unsigned p0 = tcol + 16u * (unsigned)(K - 1 - BLK) - 16u * (unsigned)l;        // (wraps below tcol for lanes without a power)
     double ax = 0.0, ay = 0.0;
 #pragma unroll
     for (int t = 0; t < nt; t++) {
-        const double mv = conv[(first + t) * 16 + l];        // 0 where j + 2t > K-1
-        const int k = min(j + 2 * t, K - 1);
-        const double2 b = T[base + K - 1 - k];
+        const double mv = conv[(first + t) * 16 + l];        // 0 where l + 2t > K-1
+        const unsigned a = (unsigned)max((int)(p0 - 32u * (unsigned)t), (int)tcol);
+        const shf_v2d b = *(shf_tab_ptr)(uintptr_t)a;
         ax = fma(mv, b.x, ax); ay = fma(mv, b.y, ay);
     }
     // (no branch around the block: with one, the compiler sinks the block's loads into it and waits for them there, a round trip
-    // through the cache per block and 22 blocks; a lane without a power writes the slack behind the wave's tables)
-    *(j < K ? T + (base + K - 1 - j) : dump) = make_double2(ax, ay);
+    // through the cache per block; a lane without a power writes the slack behind the group's tables)
+    typedef __attribute__((address_space(3))) shf_v2d *wptr;
+    shf_v2d r; r.x = ax; r.y = ay;
+    *(wptr)(uintptr_t)(BLK + l < K ? p0 : dump) = r;
 }
 template <int M>
-__device__ __forceinline__ void shf_convert_column(double2 *T, double2 *dump, const double *conv, const int l)
+__device__ __forceinline__ void shf_convert_column(const unsigned tb, const unsigned dump, const double *conv, const int l)
 {
-    shf_convert_block<M, 0>(T, dump, conv, l);
-    if (SH_LMAX + 1 - M > 16) shf_convert_block<M, (SH_LMAX + 1 - M > 16 ? 16 : 0)>(T, dump, conv, l);
+    const unsigned tcol = tb + 16u * (unsigned)shf_toff(M);
+    shf_convert_block<M, 0>(tcol, dump, conv, l);
+    if (SH_LMAX + 1 - M > 16) shf_convert_block<M, (SH_LMAX + 1 - M > 16 ? 16 : 0)>(tcol, dump, conv, l);
 }
-template <int M>
-struct ShfConvert {
-    static __device__ __forceinline__ void run(double2 *T, double2 *dump, const double *conv, const int l)
-    {
-        shf_convert_column<M>(T, dump, conv, l);
-        ShfConvert<M + 1>::run(T, dump, conv, l);
-    }
-};
-template <>
-struct ShfConvert<SH_LMAX + 1> {
-    static __device__ __forceinline__ void run(double2 *, double2 *, const double *, const int) {}
-};
-
 // ---- value and gradient of U at CC neighbours of this lane.  tb = LDS byte address of the atom's table.
 template <int CC>
 __device__ __forceinline__ void shf_evaluate(const unsigned tb, const double (&z)[CC], const double (&wx)[CC], const double (&wy)[CC],
@@ -215,59 +226,59 @@ __device__ __forceinline__ void shf_evaluate(const unsigned tb, const double (&z
         column_end();
     }
     // ---- m = 16 .. 1: K = 3 .. 18 entries, two columns per trip (K odd: start3 + pairs; K even: start3 + one step + pairs).
-    // The entries a column starts with are requested before the previous column's closing arithmetic, the pairs' one step ahead.
-    int e = 3;                               // next entry of the table
-    shf_v2d s1 = shf_entry(tb, 3), s2 = shf_entry(tb, 4), s3 = shf_entry(tb, 5);
-    shf_v2d qa = shf_entry(tb, 6), qb = shf_entry(tb, 7);
+    // qa, qb always hold the next two entries of the table; a column's third (s3) and an even column's fourth entry (sx) are
+    // requested before the closing arithmetic of the column before, the pairs' entries one step ahead.  Every request has a
+    // register of its own: no moves.
+    unsigned tp = tb + 16u * 3u;             // byte address of the next entry of the table
+    shf_v2d qa = shf_entry(tp, 0), qb = shf_entry(tp, 1), s3 = shf_entry(tp, 2);
 #pragma unroll 1
     for (int i = 0; i < 8; i++) {
-        // K = 3 + 2i: i pairs behind the start; qa, qb hold entries e+3, e+4
-        start3(s1, s2, s3);
-        e += 3;
+        // K = 3 + 2i: i pairs behind the start
+        start3(qa, qb, s3);
+        qa = shf_entry(tp, 3); qb = shf_entry(tp, 4);
+        tp += 16u * 3u;
 #pragma unroll 1
         for (int r = 0; r < i; r++) {
-            step(qa); qa = shf_entry(tb, e + 2);
-            step(qb); qb = shf_entry(tb, e + 3);
-            e += 2;
+            step(qa); qa = shf_entry(tp, 2);
+            step(qb); qb = shf_entry(tp, 3);
+            tp += 16u * 2u;
         }
-        // next column (K = 4 + 2i) starts at e: qa, qb hold entries e, e+1
-        s1 = qa; s2 = qb; s3 = shf_entry(tb, e + 2);
-        qa = shf_entry(tb, e + 3); qb = shf_entry(tb, e + 4);
-        const shf_v2d qc = shf_entry(tb, e + 5);
+        // K = 4 + 2i starts at tp (qa, qb): start3, the odd step, i pairs
+        s3 = shf_entry(tp, 2);
+        const shf_v2d sx = shf_entry(tp, 3);
         column_end();
-        start3(s1, s2, s3);
-        step(qa);                         // the odd one
-        e += 4;
-        qa = qb; qb = qc;                 // entries e, e+1
+        start3(qa, qb, s3);
+        qa = shf_entry(tp, 4); qb = shf_entry(tp, 5);
+        step(sx);
+        tp += 16u * 4u;
 #pragma unroll 1
         for (int r = 0; r < i; r++) {
-            step(qa); qa = shf_entry(tb, e + 2);
-            step(qb); qb = shf_entry(tb, e + 3);
-            e += 2;
+            step(qa); qa = shf_entry(tp, 2);
+            step(qb); qb = shf_entry(tp, 3);
+            tp += 16u * 2u;
         }
-        // next column (K = 5 + 2i, or the last one) starts at e: qa, qb hold entries e, e+1
-        s1 = qa; s2 = qb; s3 = shf_entry(tb, e + 2);
-        qa = shf_entry(tb, e + 3); qb = shf_entry(tb, e + 4);
+        s3 = shf_entry(tp, 2);               // the next column's third entry
         column_end();
     }
     // ---- m = 0: 19 entries, cosine only (the sine moments of m = 0 are zero), and only the real parts are wanted at the end
     {
 #pragma unroll
         for (int u = 0; u < CC; u++) {
-            const double qc = fma3(s1.x, z[u], s2.x);
-            dc[u] = fma3(s1.x, z[u], qc);
+            const double qc = fma3(qa.x, z[u], qb.x);
+            dc[u] = fma3(qa.x, z[u], qc);
             pc[u] = fma3(qc, z[u], s3.x);
         }
-        e += 3;
+        qa = shf_entry(tp, 3); qb = shf_entry(tp, 4);
+        tp += 16u * 3u;
 #pragma unroll 1
         for (int r = 0; r < 8; r++) {
 #pragma unroll
             for (int u = 0; u < CC; u++) { dc[u] = fma3(dc[u], z[u], pc[u]); pc[u] = fma3(pc[u], z[u], qa.x); }
-            qa = shf_entry(tb, e + 2);
+            qa = shf_entry(tp, 2);
 #pragma unroll
             for (int u = 0; u < CC; u++) { dc[u] = fma3(dc[u], z[u], pc[u]); pc[u] = fma3(pc[u], z[u], qb.x); }
-            qb = shf_entry(tb, e + 3);
-            e += 2;
+            qb = shf_entry(tp, 3);
+            tp += 16u * 2u;
         }
 #pragma unroll
         for (int u = 0; u < CC; u++) {
@@ -284,26 +295,65 @@ struct ShfAtom {            // what a lane knows of its atom
     double xi, yi, zi;
     double pone;            // P(1) = sum_k p_k
 };
-constexpr int SHF_SLOTS = 2 * SHF_TURN;          // neighbours of a lane: a = l + 16 u, u < 8
-struct ShfNbrs {            // the lane's neighbours: index and r_i - r_j (requested together, before anything is computed)
-    int j[SHF_SLOTS];
-    double dx[SHF_SLOTS], dy[SHF_SLOTS], dz[SHF_SLOTS];
+
+// ---- the table's columns are built by the four waves of the group, a quarter each (26 of the 104 change-of-basis records)
+constexpr int SHF_WCOLS[SHF_GW][8] = {{0, 5, 9, 15, -1, -1, -1, -1}, {1, 4, 10, 13, -1, -1, -1, -1},
+                                      {2, 3, 11, 12, -1, -1, -1, -1}, {6, 7, 8, 14, 16, 17, 18, -1}};
+// entries of a wave's columns a lane stages: position p = l of every column, then p = 16 + l of the columns longer than 16
+// (m = 0, 1, 2: one each in waves 0, 1, 2, always their first column)
+constexpr int SHF_NSTAGE = 8;
+template <int WQ, int IDX>
+struct ShfBuild {
+    static constexpr int M = SHF_WCOLS[WQ][IDX];
+    static constexpr int K = SH_LMAX + 1 - (M >= 0 ? M : 0);
+    // request this lane's moments of the wave's columns
+    static __device__ __forceinline__ void load(const double2 *Am, const int l, double2 (&am)[SHF_NSTAGE])
+    {
+        if constexpr (M >= 0) {
+            // (Am: this lane's pointer into the row, entry l.  A lane beyond the column's end reads the next column's entries, which it
+            // does not use; only the second round of a long column could leave the row)
+            am[IDX] = Am[shf_toff(M)];
+            if (K > 16) am[SHF_NSTAGE - 1] = Am[shf_toff(M) + min(16, K - 1 - l)];
+            ShfBuild<WQ, IDX + 1>::load(Am, l, am);
+        }
+    }
+    // B = W kappa A into the table: position p of any column belongs to l = 18 - p
+    static __device__ __forceinline__ void stage(double2 *T, double2 *dump, const int l, const double (&am_w)[2], const double2 (&am)[SHF_NSTAGE])
+    {
+        if constexpr (M >= 0) {
+            *(l < K ? T + shf_toff(M) + l : dump) = make_double2(am_w[0] * am[IDX].x, am_w[0] * am[IDX].y);
+            if (K > 16) *(16 + l < K ? T + shf_toff(M) + 16 + l : dump) = make_double2(am_w[1] * am[SHF_NSTAGE - 1].x, am_w[1] * am[SHF_NSTAGE - 1].y);
+            ShfBuild<WQ, IDX + 1>::stage(T, dump, l, am_w, am);
+        }
+    }
+    static __device__ __forceinline__ void convert(const unsigned tb, const unsigned dump, const double *conv, const int l)
+    {
+        if constexpr (M >= 0) {
+            shf_convert_column<M>(tb, dump, conv, l);
+            ShfBuild<WQ, IDX + 1>::convert(tb, dump, conv, l);
+        }
+    }
+};
+template <int WQ>
+struct ShfBuild<WQ, 8> {
+    static __device__ __forceinline__ void load(const double2 *, const int, double2 (&)[SHF_NSTAGE]) {}
+    static __device__ __forceinline__ void stage(double2 *, double2 *, const int, const double (&)[2], const double2 (&)[SHF_NSTAGE]) {}
+    static __device__ __forceinline__ void convert(const unsigned, const unsigned, const double *, const int) {}
 };
 
-// one turn: neighbour slots U0 .. U0+CC-1 of this lane: geometry and radial term (fe:648), U and grad U from the table, force
-// assembly (fe:190-213), into the force table.  Nothing in here waits for memory.
-template <int NP, int U0, int CC, bool VIRIAL>
-__device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, const int l, const ShfNbrs &nb, const double *crl,
-                                         const double pi_over_rc, const double two_over_rcp, const unsigned tb,
-                                         const ShfTable &tab, double (&fi)[3], double (&vs)[6])
+// a wave's neighbours of a lane: geometry and radial term (fe:648), U and grad U from the table, force assembly (fe:190-213),
+// into the force table.  Nothing in here waits for memory.
+template <int NP, int CC, bool VIRIAL>
+__device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, const int a0, const int (&jn)[SHF_CC], const double (&dx)[SHF_CC],
+                                         const double (&dy)[SHF_CC], const double (&dz)[SHF_CC], const double *crl, const double pi_over_rc,
+                                         const double two_over_rcp, const unsigned tb, const ShfTable &tab, double (&fi)[3], double (&vs)[6])
 {
     // F_n = e [ al (e . grad U) - be U + g0 ] - al grad U  with e = (wx, wy, z), al = fc / r, be = fc', g0 = -R + P(1) fc fc'
     double z[CC], wx[CC], wy[CC], al[CC], be[CC], g0[CC], rr[VIRIAL ? CC : 1];
 #pragma unroll
     for (int u = 0; u < CC; u++) {
-        const bool has = l + SHF_GL * (U0 + u) < at.n;
-        const double dx = nb.dx[U0 + u], dy = nb.dy[U0 + u], dz = nb.dz[U0 + u];
-        double2 R0 = make_double2(dx, dy), R1 = make_double2(dz, dx * dx + dy * dy + dz * dz);
+        const bool has = a0 + SHF_GL * u < at.n;
+        double2 R0 = make_double2(dx[u], dy[u]), R1 = make_double2(dz[u], dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u]);
         if (!has) { R0 = make_double2(0.0, 0.0); R1 = make_double2(1.0, 1.0); }
         const FeNbr g = sh_geometry(R0, R1, pi_over_rc);
         const double xr = g.r * two_over_rcp - 1.0;
@@ -326,8 +376,8 @@ __device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, con
         be[u] = has ? g.dfc : 0.0;
         g0[u] = has ? fma(at.pone * g.fc, g.dfc, -R) : 0.0;
         if (VIRIAL) rr[u] = g.r;
-        // one neighbour after the other (the sine and cosine series of one are two independent chains: enough to keep the pipe
-        // busy); four at once is where the register file runs out
+        // one neighbour after the other (the sine and cosine series of one are two independent chains, and three other waves share
+        // the SIMD); both at once is where the 128 registers of a wave run out
         asm volatile("" : "+v"(z[u]), "+v"(wx[u]), "+v"(wy[u]), "+v"(al[u]), "+v"(be[u]), "+v"(g0[u]));
     }
     double U[CC], Ux[CC], Uy[CC], Uz[CC];
@@ -339,14 +389,14 @@ __device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, con
 #endif
 #pragma unroll
     for (int u = 0; u < CC; u++) {
-        if (l + SHF_GL * (U0 + u) < at.n) {
+        if (a0 + SHF_GL * u < at.n) {
             const double ed = fma(wx[u], Ux[u], fma(wy[u], Uy[u], z[u] * Uz[u]));
             const double t = fma(al[u], ed, fma(-be[u], U[u], g0[u]));
             const double f0 = fma(t, wx[u], -al[u] * Ux[u]);
             const double f1 = fma(t, wy[u], -al[u] * Uy[u]);
             const double f2 = fma(t, z[u], -al[u] * Uz[u]);
 #ifndef ANNP_SHF_SKIP_ADD
-            tab.add(nb.j[U0 + u], -f0, -f1, -f2);                    // F_a = -Fn_a to the neighbour, +Fn_a to the centre (fe:199-211)
+            tab.add(jn[u], -f0, -f1, -f2);                    // F_a = -Fn_a to the neighbour, +Fn_a to the centre (fe:199-211)
 #endif
             fi[0] += f0; fi[1] += f1; fi[2] += f2;
             if (VIRIAL) {   // ev_tally_xyz(i,j,...,fx=-Fj, del = xi-xj = r e)   (fe:201-209)
@@ -354,7 +404,7 @@ __device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, con
                 const double w0 = d0 * f0, w1 = d1 * f1, w2 = d2 * f2, w3 = d0 * f1, w4 = d0 * f2, w5 = d1 * f2;
                 vs[0] += w0; vs[1] += w1; vs[2] += w2; vs[3] += w3; vs[4] += w4; vs[5] += w5;
                 if (p.vatom) {
-                    double *vj = p.vatom + 6 * (size_t)nb.j[U0 + u];
+                    double *vj = p.vatom + 6 * (size_t)jn[u];
                     atomicAdd(vj + 0, 0.5 * w0); atomicAdd(vj + 1, 0.5 * w1); atomicAdd(vj + 2, 0.5 * w2);
                     atomicAdd(vj + 3, 0.5 * w3); atomicAdd(vj + 4, 0.5 * w4); atomicAdd(vj + 5, 0.5 * w5);
                 }
@@ -364,84 +414,73 @@ __device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, con
 }
 
 // developer timing builds (tools/shf_stamps.py): -DANNP_SHF_STAMPS writes s_memtime at a few points of a wave's life into the
-// descriptor row of its first atom (the descriptor buffer is dead by then); no stamp is compiled into the library
+// descriptor row of an atom of its own (the descriptor buffer is dead by then); no stamp is compiled into the library
 #ifdef ANNP_SHF_STAMPS
 #define SHF_STAMP(k) do { if (stamp_row && lane_id() == 0) stamp_row[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SHF_STAMP(k) do { } while (0)
 #endif
 
-// A wave's life is one stretch of waiting (the count and the candidates, then the positions; the moments arrive behind the
-// geometry), one stretch of arithmetic (the table, then both turns back to back) and the hand-over of the forces.  Two waves
-// share a SIMD: with the arithmetic in ONE stretch the partner's waiting falls beside it.  (With a stretch of waiting in front
-// of each turn -- positions and geometry of the turn's own neighbours -- the two waves of a SIMD settled half a life apart,
-// turn beside turn and wait beside wait: 5.8 ms per 1 M atoms for 4.1 ms of issue slots; tools/shf_stamps.py.)
 template <int NP, int NT, bool VIRIAL>
-__global__ __launch_bounds__(64 * SHF_WAVES, 2) void annp_fe_force_sh(FeArgs p)
+__global__ __launch_bounds__(64 * SHF_WAVES, 4) void annp_fe_force_sh(FeArgs p)
 {
     static_assert(NT == SH_LMAX + 1 && NP + 2 * NT + 1 <= ANNP_CPAD && NP + 1 <= SHF_GL, "coefficient row: c_m | p_k | W_l | P(1)");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
+    const int grp = wave / SHF_GW, wq = wave % SHF_GW;               // the wave's group in the workgroup, its place in the group
     ShfTable tab;
     tab.key = reinterpret_cast<int *>(lds_raw + (size_t)SHF_NBUCK * SHF_BATOMS * 24);
     tab.acc = reinterpret_cast<double *>(lds_raw);
     tab.f = p.f;
-#ifdef ANNP_SHF_STAMPS
-    unsigned long long *stamp_row = nullptr;
-    {
-        const int ii0 = (xcd_block() * SHF_WAVES + (int)(threadIdx.x >> 6)) * SHF_GA;
-        if (ii0 < p.inum) stamp_row = reinterpret_cast<unsigned long long *>(p.G + (size_t)ii0 * ANNP_GPAD);
-        if (stamp_row && lane_id() == 0) { stamp_row[15] = __builtin_amdgcn_s_getreg(0xF804); stamp_row[14] = blockIdx.x; stamp_row[13] = __builtin_amdgcn_s_getreg(0xF814); }
-    }
-#endif
-    SHF_STAMP(0);
-#ifdef ANNP_SHF_STAGGER         // developer experiment: the two workgroups of a CU's first generation start apart
-    if (p.dbg > 0 && blockIdx.x < 512 && ((blockIdx.x >> 8) & 1))
-        for (int k = 0; k < p.dbg; k++) __builtin_amdgcn_s_sleep(127);
-#endif
-    unsigned char *wbase = lds_raw + shf_lds_table() + (size_t)wave * shf_lds_per_wave();
+    unsigned char *gbase = lds_raw + shf_lds_table() + (size_t)grp * shf_lds_per_group();
     const int g = lane >> 4, l = lane & 15;
-    double2 *T = reinterpret_cast<double2 *>(wbase + (size_t)g * SHF_TBYTES);
-    double *Wl = reinterpret_cast<double *>(wbase + (size_t)SHF_GA * SHF_TBYTES + 32) + g * SHF_WPAD;      // W_l [19], P(1), c_m [9]
+    double2 *T = reinterpret_cast<double2 *>(gbase + (size_t)g * SHF_TBYTES);
+    double2 *dump = reinterpret_cast<double2 *>(gbase + (size_t)SHF_GA * SHF_TBYTES) + 1;      // (the slack behind the group's tables)
+    double *crl = reinterpret_cast<double *>(lds_raw + shf_lds_table() + SHF_GROUPS * shf_lds_per_group() + (size_t)wave * shf_lds_per_wave()) + g * SHF_WPAD;
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
     const double two_over_rcp = 2.0 / p.rc_par;
 
     // ---- this lane's atom.  Everything whose address follows from the list entry alone is requested at once: the count, the
-    //      eight candidate neighbours of the lane, the moments (entries l, l+16, .. of the 190 pairs), and from the coefficient
-    //      row W_l, c_m and P(1), which the network pass leaves there.
+    //      lane's two candidate neighbours, its moments of the wave's columns, and from the coefficient row the W_l of its table
+    //      positions, c_m and P(1), which the network pass leaves there.
     ShfAtom at;
-    at.ii = (xcd_block() * SHF_WAVES + wave) * SHF_GA + g;
+    at.ii = (xcd_block() * SHF_GROUPS + grp) * SHF_GA + g;
+#ifdef ANNP_SHF_STAMPS
+    unsigned long long *stamp_row = nullptr;
+    if (at.ii + wq < p.inum) stamp_row = reinterpret_cast<unsigned long long *>(p.G + (size_t)((at.ii & ~3) + wq) * ANNP_GPAD);
+    if (stamp_row && lane == 0) { stamp_row[15] = __builtin_amdgcn_s_getreg(0xF804); stamp_row[14] = blockIdx.x; stamp_row[13] = __builtin_amdgcn_s_getreg(0xF814); }
+#endif
+    SHF_STAMP(0);
     const bool exists = at.ii < p.inum;
     const size_t iic = (size_t)min(at.ii, p.inum - 1);
     at.i = p.ilist ? p.ilist[iic] : (int)iic;
     at.n = p.ncount[iic];
     const double *cf = p.coef + iic * ANNP_CPAD;
-    int jall[SHF_SLOTS];
+    const int a0 = l + SHF_GL * SHF_CC * wq;                           // this lane's first neighbour slot in this wave
+    int jn[SHF_CC];
 #pragma unroll
-    for (int u = 0; u < SHF_SLOTS; u++) jall[u] = p.nbrs[iic * SH_CAP_MAX + l + SHF_GL * u];
-    constexpr int NR = (SHF_NE + SHF_GL - 1) / SHF_GL;
-    double2 am[NR];
-    int lw[NR];
+    for (int u = 0; u < SHF_CC; u++) jn[u] = p.nbrs[iic * SH_CAP_MAX + a0 + SHF_GL * u];
+    double2 am[SHF_NSTAGE];
     {
-        const double2 *Am = reinterpret_cast<const double2 *>(p.A + iic * SH_MPAD);
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int e = min(l + SHF_GL * r, SHF_NE - 1);
-            am[r] = Am[e];
-            lw[r] = annp_shf_l[e];
+        const double2 *Am = reinterpret_cast<const double2 *>(p.A + iic * SH_MPAD) + l;
+        switch (wq) {           // (uniform)
+        case 0: ShfBuild<0, 0>::load(Am, l, am); break;
+        case 1: ShfBuild<1, 0>::load(Am, l, am); break;
+        case 2: ShfBuild<2, 0>::load(Am, l, am); break;
+        default: ShfBuild<3, 0>::load(Am, l, am); break;
         }
     }
-    const double w_lo = cf[NP + NT + l];                               // W_l, l = lane
-    const double w_hi = cf[NP + NT + min(l + SHF_GL, NT)];             // W_(16+l) for l < 3; lane 3: P(1)
-    const double c_l = cf[min(l, NP - 1)];                             // c_m, m = lane
+    double am_w[2];
+    am_w[0] = cf[NP + NT + (NT - 1) - l];                              // W_l of table position p = lane: l = 18 - p
+    am_w[1] = cf[NP + NT + max(2 - l, 0)];                             // ... of p = 16 + lane (lanes 0..2)
+    const double c_l = cf[l < NP ? l : NP + 2 * NT];                   // c_m, m = lane; lanes >= 9: P(1)
     at.xi = p.x[3 * (size_t)at.i]; at.yi = p.x[3 * (size_t)at.i + 1]; at.zi = p.x[3 * (size_t)at.i + 2];
-    tab.clear(threadIdx.x, 64 * SHF_WAVES);
-    __syncthreads();                                         // the force table is clear (the requests above are on their way)
+    tab.clear(threadIdx.x);
     if (!exists) at.n = 0;
     if (p.type && !type_mapped(p.active, p.type[at.i])) at.n = 0;
     if (at.n > p.n_cap) {            // no moments for this atom: the pair loop takes it (annp_fe_force_fixup)
-        if (l == 0) {
+        if (l == 0 && wq == 0) {
             const int k = p.ovf_list ? atomicAdd(p.ovf_count, 1) : p.ovf_cap;
             if (k < p.ovf_cap) p.ovf_list[k] = at.ii;
             else atomicMax(p.errflag, at.n);
@@ -450,54 +489,42 @@ __global__ __launch_bounds__(64 * SHF_WAVES, 2) void annp_fe_force_sh(FeArgs p)
     }
     const int nmax = max(max(__builtin_amdgcn_readlane(at.n, 0), __builtin_amdgcn_readlane(at.n, 16)),
                          max(__builtin_amdgcn_readlane(at.n, 32), __builtin_amdgcn_readlane(at.n, 48)));
-    const int C = (nmax + SHF_GL - 1) / SHF_GL;              // neighbours per lane (uniform), 0 .. 8
+    const int C = (nmax + SHF_GL - 1) / SHF_GL;                        // neighbours per lane (uniform), 0 .. 8
+    const int cc = min(SHF_CC, max(0, C - SHF_CC * wq));               // ... of which in this wave
     SHF_STAMP(1);
+    // ---- positions of the lane's neighbours (a slot without one reads the centre's own)
+    double dx[SHF_CC], dy[SHF_CC], dz[SHF_CC];
+#pragma unroll
+    for (int u = 0; u < SHF_CC; u++) {
+        if (!(a0 + SHF_GL * u < at.n)) jn[u] = at.i;
+        dx[u] = at.xi - p.x[3 * (size_t)jn[u]]; dy[u] = at.yi - p.x[3 * (size_t)jn[u] + 1]; dz[u] = at.zi - p.x[3 * (size_t)jn[u] + 2];
+    }
+    if (l <= NP) crl[l] = c_l;                                         // [0..8] c_m, [9] P(1)
+    // ---- the wave's columns of the table: B = W kappa A, then the change of basis in place
+    const unsigned tb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)T;
     if (nmax > 0) {
-        // ---- positions of all the lane's neighbours (a slot without one reads the centre's own)
-        ShfNbrs nb;
+        const unsigned dumpb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)dump;
+        const double *conv = annp_shf_conv;
+        asm volatile("" : "+s"(conv));          // (one base in scalar registers and immediate offsets, not a program-counter relative address per load)
+        if (at.n == 0) {
 #pragma unroll
-        for (int u = 0; u < SHF_SLOTS; u++) {
-            nb.j[u] = (l + SHF_GL * u < at.n) ? jall[u] : at.i;
-            if (u < C) {
-                nb.dx[u] = at.xi - p.x[3 * (size_t)nb.j[u]]; nb.dy[u] = at.yi - p.x[3 * (size_t)nb.j[u] + 1]; nb.dz[u] = at.zi - p.x[3 * (size_t)nb.j[u] + 2];
-            } else { nb.dx[u] = 0.0; nb.dy[u] = 0.0; nb.dz[u] = 0.0; }
+            for (int k = 0; k < SHF_NSTAGE; k++) am[k] = make_double2(0.0, 0.0);
         }
-        Wl[l] = w_lo;
-        if (l + SHF_GL <= NT) Wl[l + SHF_GL] = w_hi;         // [16..18] W, [19] P(1)
-        if (l < NP) Wl[20 + l] = c_l;
-        wave_lds_sync();
-        at.pone = Wl[NT];
-        SHF_STAMP(2);
-        // ---- B = W kappa A into the table, then its change of basis in place
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int e = l + SHF_GL * r;
-            const double w = at.n > 0 ? Wl[lw[r]] : 0.0;
-            if (e < SHF_NE) T[e] = at.n > 0 ? make_double2(w * am[r].x, w * am[r].y) : make_double2(0.0, 0.0);
+        switch (wq) {
+        case 0: ShfBuild<0, 0>::stage(T, dump, l, am_w, am); wave_lds_sync(); SHF_STAMP(2); ShfBuild<0, 0>::convert(tb, dumpb, conv, l); break;
+        case 1: ShfBuild<1, 0>::stage(T, dump, l, am_w, am); wave_lds_sync(); SHF_STAMP(2); ShfBuild<1, 0>::convert(tb, dumpb, conv, l); break;
+        case 2: ShfBuild<2, 0>::stage(T, dump, l, am_w, am); wave_lds_sync(); SHF_STAMP(2); ShfBuild<2, 0>::convert(tb, dumpb, conv, l); break;
+        default: ShfBuild<3, 0>::stage(T, dump, l, am_w, am); wave_lds_sync(); SHF_STAMP(2); ShfBuild<3, 0>::convert(tb, dumpb, conv, l); break;
         }
-        wave_lds_sync();
-        SHF_STAMP(3);
-#ifndef ANNP_SHF_SKIP_BUILD
-        ShfConvert<0>::run(T, reinterpret_cast<double2 *>(wbase + (size_t)SHF_GA * SHF_TBYTES) + 1, annp_shf_conv, l);
-#endif
-        wave_lds_sync();
-        SHF_STAMP(4);
-        // ---- the turns, back to back: 7 = 3 + 4 neighbours per lane
-        const unsigned tb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)T;
-        const double *crl = Wl + 20;
+    }
+    SHF_STAMP(3);
+    __syncthreads();                                         // the tables are complete, the force table is clear
+    SHF_STAMP(4);
+    if (cc > 0) {
+        at.pone = crl[NP];
         double fi[3] = {0.0, 0.0, 0.0}, vs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#define SHF_T(U0, CC) shf_turn<NP, U0, CC, VIRIAL>(p, at, l, nb, crl, pi_over_rc, two_over_rcp, tb, tab, fi, vs)
-        switch (C) {            // (uniform)
-        case 1: SHF_T(0, 1); break;
-        case 2: SHF_T(0, 2); break;
-        case 3: SHF_T(0, 3); break;
-        case 4: SHF_T(0, 4); break;
-        case 5: SHF_T(0, 2); SHF_T(2, 3); break;
-        case 6: SHF_T(0, 3); SHF_T(3, 3); break;
-        case 7: SHF_T(0, 3); SHF_T(3, 4); break;
-        default: SHF_T(0, 4); SHF_T(4, 4); break;
-        }
-#undef SHF_T
+        if (cc == 1) shf_turn<NP, 1, VIRIAL>(p, at, a0, jn, dx, dy, dz, crl, pi_over_rc, two_over_rcp, tb, tab, fi, vs);
+        else shf_turn<NP, 2, VIRIAL>(p, at, a0, jn, dx, dy, dz, crl, pi_over_rc, two_over_rcp, tb, tab, fi, vs);
         SHF_STAMP(5);
         // ---- the centre's share: sums over the atom's 16 lanes end up in the row's last lane
 #pragma unroll
@@ -524,7 +551,7 @@ __global__ __launch_bounds__(64 * SHF_WAVES, 2) void annp_fe_force_sh(FeArgs p)
     __syncthreads();
     SHF_STAMP(7);
 #ifndef ANNP_SHF_SKIP_FLUSH
-    tab.flush(threadIdx.x, 64 * SHF_WAVES);          // the workgroup's table, in memory order
+    tab.flush(threadIdx.x);          // the workgroup's table, in memory order
 #endif
     SHF_STAMP(8);
 }

@@ -39,11 +39,11 @@ def main():
         assert lib.annp_hip_compute_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value, dom.f.data_ptr(), None, eng.data_ptr(), None, None, st) == 0
     rows = np.zeros((dom.nlocal, 32))
     assert lib.annp_hip_last_descriptors(h, rows.ctypes.data_as(C.POINTER(C.c_double)), dom.nlocal) == 0
-    t = rows.view(np.uint64)[::4]            # one row per wave (4 atoms)
+    t = rows.view(np.uint64)                 # one row per wave (the four waves of a group use the rows of its four atoms)
     ok = t[:, 8] > t[:, 0]
     t = t[ok]
     d = (t[:, 1:9].astype(np.int64) - t[:, 0:8].astype(np.int64)).astype(np.float64)
-    names = ["start->count", "gather,stash", "stage", "convert", "turns", "tail", "barrier", "flush"]
+    names = ["start->count", "gather,stage", "convert", "barrier1", "turn", "tail", "barrier2", "flush"]
     print("waves %d; cycles per wave (mean / median / p90):" % len(t))
     for k, nm in enumerate(names):
         print("  %-14s %9.0f %9.0f %9.0f" % (nm, d[:, k].mean(), np.median(d[:, k]), np.percentile(d[:, k], 90)))
