@@ -41,15 +41,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# Per-unit algorithmic work (fp64, FMA = 2 flop), derived line by line in DESIGN.md 4.5.
-# (a) what the implemented formulation needs -- the roofline numerator:
-#     The Chebyshev passes work on the 361 moments of a neighbourhood (fe_sh_kernels.hpp), not on its pairs: per in-cutoff
-#     neighbour the 190 steps of the monic recurrences (mul + fma = 3 flop each) with 1-2 (descriptor) or 1-4 (force) FMAs
-#     behind each, the column ends, and what the pair-loop kernels also did per neighbour (geometry, cutoff function, radial
-#     functions, force assembly: 110 / 158); per atom the lane sums, power spectrum and 19 x 19 products of the descriptor pass
-#     and the coefficient table of the force pass.
-FLOP_PAIR_DESC, FLOP_NBR_DESC, FLOP_ATOM_DESC = 0.0, 19 * 5 + 171 * 7 + 18 * 6 + 110.0, 7000.0
-FLOP_PAIR_FORCE, FLOP_NBR_FORCE, FLOP_ATOM_FORCE = 0.0, 19 * 5 + 18 * 9 + 153 * 11 + 19 * 24 + 158.0, 1900.0
+# Per-unit algorithmic work (fp64, FMA = 2 flop, mul / add = 1), counted from the kernels as they execute (DESIGN.md 4.5:
+# "kernel-derived", not SURVEY.md 8d's budget for the reference formulation, which is printed beside it).
+# (a) what the implemented formulation needs -- the roofline numerator.  The Chebyshev passes work on the 361 moments of a
+#     neighbourhood (fe_sh_kernels.hpp, fe_shf_kernels.hpp), not on its pairs.
+#     Descriptor pass, per in-cutoff neighbour: the monic recurrences of the 19 columns (K - 2 steps of mul + fma = 3 flop in a
+#     column of K polynomials: the first two, 1 and z, cost nothing) 3 x 152 = 456; the accumulation behind every polynomial
+#     (1 FMA in column 0, 2 elsewhere) 2 x 19 + 4 x 171 = 722; advancing the power (x+iy)^m 18 x 6 = 108; geometry, cutoff
+#     function, 9 radial functions 110.  Per atom: lane sums 361 x 15, power spectrum, 19 x 19 product ~ 7 k.
+#     Force pass (round 4: Horner's rule on monomial coefficients), per in-cutoff neighbour: columns of K >= 3 entries start with
+#     6 FMAs for three entries and take 4 FMAs per entry after that (16 x 6 + 4 x 120 = 576 FMAs), the two-entry column 2, the
+#     cosine-only column m = 0 3 + 2 x 16 = 35, Horner's rule in w 12 FMAs per column and 8 at the end (224): 837 FMAs = 1 674 flop;
+#     geometry, radial T and T', force assembly 158.  Per atom: B = W kappa A 760, change of basis 1 430 FMAs = 2 860.
+FLOP_PAIR_DESC, FLOP_NBR_DESC, FLOP_ATOM_DESC = 0.0, 3 * 152 + (2 * 19 + 4 * 171) + 18 * 6 + 110.0, 7000.0
+FLOP_PAIR_FORCE, FLOP_NBR_FORCE, FLOP_ATOM_FORCE = 0.0, 2 * (16 * 6 + 4 * 120 + 2 + 35 + 12 * 18 + 8) + 158.0, 760.0 + 2860.0
 #     ... and the pair-loop kernels they replaced (ANNP_HIP_FE_DESC=pairs ANNP_HIP_FE_FORCE=pairs, or a system with more than
 #     128 neighbours per atom): pass 1: cos 5, weights 3, T_2..T_18 recurrence + accumulate 68; pass 3: cos 5, Horner P 36 +
 #     dP 34, dP fc_b 1, a-side 8, b-side 4
@@ -58,7 +63,7 @@ FLOP_MLP = 2500.0
 # (b) SURVEY.md 8d's budget for the reference formulation (T and T' recurrences for every function in both
 #     passes): 350 flop per pair + 175 per neighbour + 1.6 k = 2.20 MFLOP per atom-step at n = 112
 SURVEY_FLOP_PAIR, SURVEY_FLOP_NBR, SURVEY_FLOP_MLP = 350.0, 175.0, 1600.0
-BYTES_ATOM_STEP = 9960.0 + 2 * 368 * 8            # gathered bytes per atom-step + the moments written and read back
+BYTES_ATOM_STEP = 9960.0 + 2 * 384 * 8            # gathered bytes per atom-step + the moments written and read back
 PEAK_FP64_VECTOR = 78.6                           # TFLOP/s, MI355X (MI355X_MICROARCH.md: half of FP32 vector 157.3)
 PEAK_HBM = 8000.0                                 # GB/s spec
 # Ni (Behler G2/G4), counted from the kernels: per candidate (j,k) pair the distance pre-pass of the descriptor
@@ -195,6 +200,7 @@ class Leg:
         ftm2v = 1.0 / 1.0364269e-4          # LAMMPS metal units: (eV/A)/(g/mol) -> A/ps^2
         self.dtf = 0.5 * args.dt * ftm2v / self.mass
         self.reissued = 0
+        self.halo_marks = None              # when a list: (before, between, after) marks of the two exchanges of every step
         self.build_list()
 
     def stream(self):
@@ -237,15 +243,44 @@ class Leg:
         otherwise forward_comm; force_clear, pair compute, reverse_comm; final_integrate"""
         a, d = self.args, self.dom
         d.verlet_half(d.extra["v"], self.dtf, a.dt)         # FixNVE::initial_integrate
+        m0 = self.mark()
         if rebuild:
             d.replan()                      # Comm::exchange + Comm::borders (atoms, velocities and ids change rank here); f comes back zeroed
             self.build_list()               # Neighbor::build
             self.eng.zero_()
         else:
             d.forward(clear_forces=True, eng=self.eng)      # Comm::forward_comm + Verlet::force_clear
+        m1 = self.mark()
         self.force_eval()                   # Pair::compute
+        m2 = self.mark()
         d.reverse()                         # Comm::reverse_comm
+        m3 = self.mark()
+        if self.halo_marks is not None:
+            self.halo_marks.append((m0, m1, m2, m3))
         d.verlet_half(d.extra["v"], self.dtf, 0.0)          # FixNVE::final_integrate
+
+    def mark(self):
+        """a point in time on the step's stream (an event) -- or on the host clock in the CPU rehearsal"""
+        if self.halo_marks is None:
+            return None
+        if self.dry:
+            return time.perf_counter()
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record(self.torch.cuda.current_stream(self.dev))
+        return ev
+
+    def halo_ms(self):
+        """mean milliseconds per step in the forward and in the reverse exchange (device time between the marks)"""
+        if not self.halo_marks:
+            return 0.0, 0.0
+        fw = bw = 0.0
+        for m0, m1, m2, m3 in self.halo_marks:
+            if self.dry:
+                fw += (m1 - m0) * 1e3; bw += (m3 - m2) * 1e3
+            else:
+                fw += m0.elapsed_time(m1); bw += m2.elapsed_time(m3)
+        n = len(self.halo_marks)
+        return fw / n, bw / n
 
     def timed(self, steps, warmup):
         """(seconds, HIP-event means of the kernels) of `steps` steps; single rank, no thermo"""
@@ -305,6 +340,22 @@ def secondary_ni(args, dev, local_rank):
                         "flop_per_unit": {"candidate_pair": NI_FLOP_PAIR, "neighbour": NI_FLOP_NBR, "atom": NI_FLOP_MLP}},
            "neighbors_in_cutoff_mean": float(n.mean()), "list_neighbors_max": int(leg.mx.value), "energy_per_atom": e / leg.natoms,
            "evaluations_reissued": leg.reissued}
+    if args.cpu_sample > 0:
+        try:
+            from annp_testlib import FAST, KIND_NI_FIXED, NI_POT, oracle_compute, oracle_lib, read_pot
+            m = min(args.cpu_sample, leg.dom.nlocal)
+            s = _sample_system(leg.lib, leg.h, leg.dom.x.cpu().numpy(), leg.dom.nlocal, leg.dom.nall, m, leg.rc_list)
+            nthreads = min(oracle_lib().annp_oracle_max_threads(), _cpu_share())
+            pot = read_pot(NI_POT)
+            oracle_compute(pot, s, KIND_NI_FIXED, FAST, inum=min(m, 256), nthreads=nthreads)
+            t1 = time.perf_counter()
+            oracle_compute(pot, s, KIND_NI_FIXED, FAST, inum=m, nthreads=nthreads)
+            tc = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": m / tc, "unit": "atom-steps/s", "cores": int(nthreads), "kind": "port", "seconds": tc,
+                                   "sample": "1 force evaluation of the first %d of %d atoms of the same box (list at 8.5 A, as the reference "
+                                             "would be given), oracle FAST strategy with the GPU kernel's derivative (Ni-fixed), OpenMP" % (m, leg.natoms)}
+        except Exception as exc:
+            out["cpu_baseline"] = {"error": repr(exc)}
     leg.close()
     return out
 
@@ -324,7 +375,9 @@ def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` or under a launcher with "
+                         "--nproc-per-node N\n" % (args.gpus, world))
+        raise SystemExit(2)
     # ANNP_BENCH_DRYRUN=1: rehearsal of the control flow where there is no GPU at all (the launcher test): ranks on CPU over
     # gloo, every step of the loop except the force evaluation itself, no throughput reported.  There is no CPU force path.
     dry = os.environ.get("ANNP_BENCH_DRYRUN") == "1"
@@ -336,6 +389,10 @@ def run_rank(args):
             raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
         if os.environ.get("ANNP_BENCH_SHARE_GPU") == "1":      # rehearsal only: several ranks on one card
             local_rank = local_rank % torch.cuda.device_count()
+        elif torch.cuda.device_count() <= local_rank:
+            sys.stderr.write("bench.py: rank %d (local rank %d) sees %d HIP device(s): one GPU per rank is required "
+                             "(ANNP_BENCH_SHARE_GPU=1 is the rehearsal switch for ranks sharing a card)\n" % (rank, local_rank, torch.cuda.device_count()))
+            raise SystemExit(3)
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("ANNP_FORCE_DIST") == "1"      # the latter: rehearse RCCL with one rank
@@ -346,6 +403,9 @@ def run_rank(args):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus and not (world == 1 and args.gpus == 1):
+            sys.stderr.write("bench.py: the process group has %d ranks, --gpus says %d\n" % (dist.get_world_size(), args.gpus))
+            raise SystemExit(2)
     # ANNP_BENCH_WIRE_SELF=1 (with ANNP_FORCE_DIST=1, one rank): the x-periodic images travel through the transport to this same
     # rank instead of being local copies -- ncclSend / ncclRecv on device buffers, executed on a single GPU
     wire_self = world == 1 and use_dist and os.environ.get("ANNP_BENCH_WIRE_SELF") == "1"
@@ -389,11 +449,16 @@ def run_rank(args):
     barrier()
     if not dry:
         check(lib.annp_hip_set_timing(h, 1), "set_timing")
+    leg.halo_marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step_thermo()
+    sync()
+    dt_own = time.perf_counter() - t0       # this rank's own clock, before the barrier (per_rank.step_ms)
     barrier()
     dt_wall = time.perf_counter() - t0
+    halo_fw_ms, halo_bw_ms = leg.halo_ms()
+    leg.halo_marks = None
     ms4 = np.zeros(4)
     ns = C.c_int(0)
     if not dry:
@@ -439,6 +504,11 @@ def run_rank(args):
     # per-rank facts, gathered on every rank
     mine = torch.tensor([nlocal, nall - nlocal, halo_rank, md_migrated], dtype=torch.int64, device=dev)
     per_rank = tp.allgather(mine).numpy().reshape(world, 4)
+
+    # ... and what tells a slow rank from a slow wire when the curve over N is not what it should be
+    mine_f = torch.tensor([float(ms4[0]), float(ms4[1]), float(ms4[2]), float(ms4[3]), halo_fw_ms, halo_bw_ms, dt_own / args.steps * 1e3],
+                          dtype=torch.float64, device=dev)
+    per_rank_f = tp.allgather(mine_f).numpy().reshape(world, 7)
 
     n = counts.astype(np.float64)
     pairs = float((n * (n - 1) / 2).sum())
@@ -493,6 +563,12 @@ def run_rank(args):
             "parallelism": "spatial x%d, halo p2p" % world,
             "step": "verlet + forward halo + force evaluation + reverse halo; total energy all-reduced every %d steps" % args.thermo,
         },
+        "per_rank": {"kernel_ms": {"descriptor": [float(v) for v in per_rank_f[:, 0]], "network": [float(v) for v in per_rank_f[:, 1]],
+                                   "force": [float(v) for v in per_rank_f[:, 2]], "evaluation": [float(v) for v in per_rank_f[:, 3]]},
+                     "halo_ms": {"forward": [float(v) for v in per_rank_f[:, 4]], "reverse": [float(v) for v in per_rank_f[:, 5]],
+                                 "note": "device time per step between events around the exchange (pack / image fill + force clear and the "
+                                         "wire; fold of the returned ghost forces): includes waiting for the slower neighbour"},
+                     "step_ms": [float(v) for v in per_rank_f[:, 6]]},
         "energy_per_atom_eV": e_total / natoms,
         "mini_md": None if md_rate is None else {
             "value": None if dry else md_rate, "unit": "atom-steps/s", "atoms_that_changed_rank": int(per_rank[:, 3].sum()),
@@ -518,8 +594,11 @@ def run_rank(args):
             "frac": achieved / PEAK_FP64_VECTOR,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_flop_per_launch": flop_force,
+            "flop_model": "kernel-derived, DESIGN.md 4.5 (what the implemented formulation executes; SURVEY.md 8d's budget for the "
+                          "reference formulation is survey_budget below)",
             "flop_per_unit": {"pair": fpf, "neighbour": fnf, "atom": faf},
-            "descriptor_pass": {"achieved": flop_desc / (desc_ms * 1e-3) / 1e12, "frac": flop_desc / (desc_ms * 1e-3) / 1e12 / PEAK_FP64_VECTOR},
+            "descriptor_pass": {"achieved": flop_desc / (desc_ms * 1e-3) / 1e12, "frac": flop_desc / (desc_ms * 1e-3) / 1e12 / PEAK_FP64_VECTOR,
+                                "flop_per_unit": {"pair": fpd, "neighbour": fnd, "atom": fad}},
             "whole_evaluation": {"achieved": flop_eval / (float(ms4[3]) * 1e-3) / 1e12,
                                  "frac": flop_eval / (float(ms4[3]) * 1e-3) / 1e12 / PEAK_FP64_VECTOR,
                                  "flop_per_atom_step": flop_eval / nlocal},
@@ -531,6 +610,14 @@ def run_rank(args):
             "hbm": {"achieved_GBps": nlocal * BYTES_ATOM_STEP / (float(ms4[3]) * 1e-3) / 1e9, "peak_GBps": PEAK_HBM,
                     "note": "%.1f KB per atom-step over the whole evaluation; the path is FP64-VALU bound, not HBM bound" % (BYTES_ATOM_STEP / 1e3)},
     }
+    if wl == "fe" and not pair_loop:
+        ex = _pmc_extras(natoms if world == 1 else None, "annp_fe_force_sh")
+        for k in ("descriptor_pass", "network_pass"):
+            if k in ex:
+                out["roofline"].setdefault(k, {}).update(ex.pop(k))
+        out["roofline"].update(ex)
+        if "peak_at_sustained_clock" in out["roofline"]:
+            out["roofline"]["frac_of_peak_at_sustained_clock"] = achieved / out["roofline"]["peak_at_sustained_clock"]
     if world > 1:
         out["roofline"]["note"] = "rank 0's launches (its %d owned atoms)" % nlocal
     if wl == "ni":
@@ -579,6 +666,12 @@ def run_rank(args):
             "note": "the literal reference CPU pair_annp measured during the survey: 129 atom-steps/s on one core at "
                     "2 000 atoms (BASELINE.md 2); it cannot run at this size (O(N nall) allocations)",
         }
+        if wl == "fe":
+            try:
+                out["cpu_baseline"]["port_1024000"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample", "seconds")}
+                out["cpu_baseline"].update(_cpu_matrix(nthreads))
+            except Exception as exc:    # the metric's line must not be lost to a baseline
+                out["cpu_baseline"]["matrix_error"] = repr(exc)
     out["config"]["evaluations_reissued"] = leg.reissued
     # ---- BASELINE.json config 5 as a short second leg of the default run --------------------
     if world == 1 and wl == "fe" and args.secondary and not use_dist:
@@ -594,27 +687,67 @@ def run_rank(args):
         dist.destroy_process_group()
 
 
-def _pmc_traffic(kernel, natoms):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r*_pmc_counters.json: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950, i.e. the upper bound).  None when no matching profile exists:
-    the counters cannot be read from inside an un-profiled run.  Returns (bytes, where they came from)."""
+def _pmc_profile(natoms):
+    """the newest committed counter summary of this command at this size (profiles/r*_pmc_counters.json, written by
+    tools/summarise_profiles.py from tools/collect_profiles.sh's passes), or (None, None)"""
     import glob
     best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json"))):
         try:
             d = json.load(open(f))
-            if natoms is None or str(natoms) not in d.get("workload", ""):
-                continue
-            cand = [v["hbm_bytes_upper"] for k, v in d["per_launch_mean"].items()
-                    if kernel in k and "fixup" not in k and "hbm_bytes_upper" in v]
-            if cand:
-                best = max(cand)          # the steady-state instantiation (the first evaluation runs another one once)
-                src = "%s (builder's own rocprofv3 --pmc passes of this command on an MI355X, FETCH_SIZE and WRITE_SIZE in " \
-                      "separate passes, FETCH_SIZE doubled per the gfx950 note: an upper bound; NOT measured in this run)" % os.path.relpath(f, ROOT)
+            if natoms is not None and str(natoms) in d.get("workload", "") and "anna" not in d.get("workload", ""):
+                best, src = d["per_launch_mean"], os.path.relpath(f, ROOT)
         except Exception:
             pass
     return best, src
+
+
+def _pmc_kernel(prof, kernel):
+    """the steady-state instantiation of `kernel` in a counter summary (the one with the most HBM traffic: the first evaluation
+    may run another instantiation once)"""
+    cand = [v for k, v in (prof or {}).items() if kernel in k and "fixup" not in k and "hbm_bytes_upper" in v]
+    return max(cand, key=lambda v: v["hbm_bytes_upper"]) if cand else None
+
+
+def _pmc_traffic(kernel, natoms):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r*_pmc_counters.json: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, i.e. the upper bound).  None when no matching profile exists:
+    the counters cannot be read from inside an un-profiled run.  Returns (bytes, where they came from)."""
+    prof, f = _pmc_profile(natoms)
+    e = _pmc_kernel(prof, kernel)
+    if e is None:
+        return None, None
+    return e["hbm_bytes_upper"], "%s (builder's own rocprofv3 --pmc passes of this command on an MI355X, FETCH_SIZE and WRITE_SIZE in " \
+                                 "separate passes, FETCH_SIZE doubled per the gfx950 note: an upper bound; NOT measured in this run)" % f
+
+
+def _pmc_extras(natoms, force_kernel):
+    """What north_star asks rocprof to show, from the same committed passes: the shader clock the chip held under the force pass
+    (GRBM_GUI_ACTIVE / 8 XCDs / the kernel's mean duration in the kernel trace of the same command), the descriptor pass's HBM
+    bytes per second, the network pass's FP64-MFMA rate and matrix-pipe busy share.  Empty when no profile of this size exists."""
+    prof, f = _pmc_profile(natoms)
+    out = {}
+    e = _pmc_kernel(prof, force_kernel)
+    if e and e.get("clock_GHz"):
+        out["sustained_clock_GHz"] = e["clock_GHz"]
+        out["peak_at_sustained_clock"] = PEAK_FP64_VECTOR * e["clock_GHz"] / 2.4
+        if e.get("SQ_INSTS_VALU") and e.get("GRBM_GUI_ACTIVE"):
+            out["valu_instructions_per_atom"] = e["SQ_INSTS_VALU"] / natoms
+            out["valu_issue_share"] = e["SQ_INSTS_VALU"] * 4 / (1024 * e["GRBM_GUI_ACTIVE"] / 8)
+    d = _pmc_kernel(prof, "annp_fe_desc_sh")
+    if d and d.get("hbm_GBps_upper"):
+        out["descriptor_pass"] = {"hbm_GBps": d["hbm_GBps_upper"], "hbm_GBps_lower": d["hbm_GBps_lower"], "hbm_frac_of_8TBps": d["hbm_GBps_upper"] / PEAK_HBM,
+                                  "hbm_bytes_per_launch": d["hbm_bytes_upper"], "avg_ms": d.get("avg_ms"),
+                                  "valu_instructions_per_atom": d.get("SQ_INSTS_VALU", 0.0) / natoms,
+                                  "lds_bank_conflict_share": (d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"]) if d.get("SQ_LDS_IDX_ACTIVE") else None}
+    m = _pmc_kernel(prof, "annp_mlp_mfma")
+    if m and m.get("mfma_TFLOPs"):
+        out["network_pass"] = {"mfma_TFLOPs": m["mfma_TFLOPs"], "mfma_util": m["mfma_TFLOPs"] / PEAK_FP64_VECTOR,
+                               "mfma_busy_share": m.get("mfma_busy_share"), "hbm_GBps": m.get("hbm_GBps_upper"), "avg_ms": m.get("avg_ms")}
+    if out:
+        out["source"] = "%s: rocprofv3 --pmc passes + kernel trace of this command (tools/collect_profiles.sh), NOT measured in this run" % f
+    return out
 
 
 def _cpu_share():
@@ -650,6 +783,70 @@ def _sample_system(lib, h, x_all, nlocal, nall, m, rc_list):
     s.owner = np.zeros(s.nghost, dtype=np.int32)
     s.rc_list = rc_list
     return s
+
+
+def _host_sample(x_local, box, m, rc_list):
+    """A periodic box on the host, as the oracle wants it: ghosts from the test harness, neighbour-list rows of the first m atoms"""
+    from annp_testlib import System, _dp, _ip, _lp, oracle_lib
+    ol = oracle_lib()
+    x_local = np.ascontiguousarray(x_local, dtype=np.float64)
+    n = x_local.shape[0]
+    boxa = np.ascontiguousarray(box, dtype=np.float64)
+    per = np.ones(3, dtype=np.int32)
+    ng = ol.harness_ghosts(n, _dp(x_local), _dp(boxa), _ip(per), rc_list, 0, None, None)
+    xg = np.empty((ng, 3))
+    owner = np.empty(ng, dtype=np.int32)
+    ol.harness_ghosts(n, _dp(x_local), _dp(boxa), _ip(per), rc_list, ng, _dp(xg), _ip(owner))
+    s = System.__new__(System)
+    s.nlocal, s.nghost, s.nall = n, int(ng), n + int(ng)
+    s.x = np.ascontiguousarray(np.vstack([x_local, xg]))
+    s.type = np.ones(s.nall, dtype=np.int32)
+    s.numneigh = np.zeros(s.nall, dtype=np.int32)
+    tot = ol.harness_neigh(m, s.nall, _dp(s.x), rc_list, _ip(s.numneigh), None, None)
+    s.first = np.zeros(s.nall + 1, dtype=np.int64)
+    np.cumsum(s.numneigh, out=s.first[1:])
+    s.neigh = np.empty(max(int(tot), 1), dtype=np.int32)
+    ol.harness_neigh(m, s.nall, _dp(s.x), rc_list, _ip(s.numneigh), _lp(s.first), _ip(s.neigh))
+    s.ilist = np.arange(m, dtype=np.int32)
+    s.inum, s.owner, s.rc_list = m, owner, rc_list
+    return s
+
+
+def _cpu_matrix(nthreads):
+    """SURVEY.md 8d's CPU figures beside the GPU's, each a bounded sample (a few seconds in all): the oracle's LITERAL strategy
+    (one atom at a time, dG/dx materialised per list slot, forward-mode Jacobian, the reference's order of operations -- the closest
+    thing to fe_v2/src/pair_annp.cpp:74-218 that can be timed where the reference itself cannot be built) on ONE core at 2 000
+    atoms, and the allocation-free port (FAST, OpenMP) at 2 000 and 128 000 atoms."""
+    from annp_testlib import A_FE, FAST, FE_POT, KIND_FE, LITERAL, bcc, oracle_compute, perturb, read_pot
+    pot = read_pot(FE_POT)
+    out = {}
+    x, box = bcc(10, 10, 10, A_FE)
+    s = _host_sample(perturb(x, 12345, 0.05), box, 2000, 8.5)
+    oracle_compute(pot, s, KIND_FE, LITERAL, inum=16, nthreads=1)
+    t = time.perf_counter()
+    oracle_compute(pot, s, KIND_FE, LITERAL, inum=2000, nthreads=1)
+    dt = time.perf_counter() - t
+    out["literal_2000"] = {"value": 2000 / dt, "unit": "atom-steps/s", "cores": 1, "kind": "port (LITERAL strategy of the oracle)", "seconds": dt,
+                           "sample": "one evaluation of the whole 2 000-atom box (BASELINE.json config 0's system) on one core",
+                           "reference_carried_over": {"value": 129.0, "unit": "atom-steps/s per core",
+                                                      "note": "the unmodified reference translation unit measured during the survey (8 vCPU Xeon @ 2.1 GHz, "
+                                                              "BASELINE.md 2): several times slower than this restatement because it allocates and frees "
+                                                              "(nall+2) x nsf small arrays per atom (fe/src/pair_annp.cpp:122-130); it cannot be built here"}}
+    oracle_compute(pot, s, KIND_FE, FAST, inum=256, nthreads=nthreads)
+    t = time.perf_counter()
+    oracle_compute(pot, s, KIND_FE, FAST, inum=2000, nthreads=nthreads)
+    dt = time.perf_counter() - t
+    out["port_2000"] = {"value": 2000 / dt, "unit": "atom-steps/s", "cores": int(nthreads), "kind": "port", "seconds": dt,
+                        "sample": "one evaluation of the whole 2 000-atom box, oracle FAST strategy, OpenMP"}
+    x, box = bcc(40, 40, 40, A_FE)
+    m = 32768
+    s = _host_sample(perturb(x, 12345, 0.05), box, m, 8.5)
+    t = time.perf_counter()
+    oracle_compute(pot, s, KIND_FE, FAST, inum=m, nthreads=nthreads)
+    dt = time.perf_counter() - t
+    out["port_128000"] = {"value": m / dt, "unit": "atom-steps/s", "cores": int(nthreads), "kind": "port", "seconds": dt,
+                          "sample": "one evaluation of the first %d atoms of the 128 000-atom box (BASELINE.json config 1's system), oracle FAST strategy, OpenMP" % m}
+    return out
 
 
 def _main_one_json_line():

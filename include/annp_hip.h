@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define ANNP_HIP_ABI_VERSION 5
+#define ANNP_HIP_ABI_VERSION 6
 
 #define ANNP_HIP_OK 0
 #define ANNP_HIP_EARG (-1)
@@ -244,6 +244,17 @@ int annp_hip_sync(annp_hip_handle *handle);
  *   info4[2] neighbours per atom its force pass had room for (Chebyshev, moment kernels: the state the descriptor and force
  *            passes share, 64..128; pair-loop kernels and Behler: LDS records)   info4[3] what the next evaluation will use */
 int annp_hip_eval_info(annp_hip_handle *handle, int *info4);
+
+/* Which kernels the NEXT evaluation will run (after the most recent one's flag words, which this waits for):
+ *   0  Chebyshev passes on the moments of the neighbourhood (the fast path: up to 128 in-cutoff neighbours per atom)
+ *   1  Chebyshev passes pair by pair because the system is denser than that (about half the speed; back to 0 by itself when
+ *      the maximum falls under 128 again)
+ *   2  Chebyshev passes pair by pair because ANNP_HIP_FE_DESC / ANNP_HIP_FE_FORCE ask for it (developer A/B switches)
+ *   3  Behler G2/G4 kernels      4  pair_style anna_adp kernels
+ * The change 0 -> 1 is also announced once on the stream given to annp_hip_set_notice (annp_gpu_init passes LAMMPS' screen). */
+int annp_hip_eval_path(annp_hip_handle *handle);
+/* `file` is a FILE * (or NULL: silent, the default).  One line per event, prefixed "annp/hip:". */
+int annp_hip_set_notice(annp_hip_handle *handle, void *file);
 
 /* Kernel timing with HIP events recorded on the stream the kernels are launched on.
  * annp_hip_set_timing(h, 1) starts recording (and resets the sample count); every

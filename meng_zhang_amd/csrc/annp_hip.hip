@@ -125,12 +125,13 @@ struct annp_hip_handle {
     int sh_cap = SH_CAP_MAX;            // Chebyshev descriptor pass (annp_fe_desc_sh): state slots per atom for the next evaluation
     bool fe_desc_pairs = false;         // ANNP_HIP_FE_DESC=pairs: the pair-loop descriptor kernel (annp_fe_desc) for every atom
     bool fe_force_pairs = false;        // ANNP_HIP_FE_FORCE=pairs: the pair-loop force kernel (annp_fe_force) for every atom
-    bool fe_force_sh3 = false;          // ANNP_HIP_FE_FORCE=sh3: round 3's force pass on the moments (recurrences per neighbour), for A/B runs
+    FILE *notice = nullptr;             // annp_hip_set_notice: where a change of kernel path is announced (once per change)
+    bool fe_dense_said = false;
     int sh_cap_used = 0;                // state slots the last annp_fe_desc_sh launch had (= atoms with moments have at most that many neighbours)
     bool fe_dense = false;              // most atoms have more neighbours than the moment kernels take (128): the pair-loop kernels for all
     bool fe_last_sh = false;            // the last Chebyshev evaluation ran the moment kernels
+    bool flags_sh = false; int flags_inum = 0;      // ... and the evaluation the pending flag words belong to (several can be in flight)
     int fe_last_inum = 0;
-    int fe_dbg = 0;                     // ANNP_HIP_DBG (FeArgs::dbg)
     int sh_wpb = 0;                     // waves per workgroup of annp_fe_desc_sh (ANNP_HIP_SH_WPB; 0 = chosen per launch)
     int flagact[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // up to max(MLP_MAXL, ANNA_MAXL) weight layers
     static_assert(MLP_MAXL <= 8 && ANNA_MAXL <= 8, "flagact holds 8 layers");
@@ -345,8 +346,20 @@ void digest_flags(annp_hip_handle *h)
         // The moment kernels take atoms with up to SH_CAP_MAX neighbours and queue the others for the pair-loop fix-up launches, which
         // run one wave per workgroup: fine for a few atoms, slow for a dense system.  When a sixteenth of the atoms went through
         // the queue, the next evaluation uses the pair-loop kernels for all of them, until the maximum is back under the limit.
-        if (h->fe_last_sh) h->fe_dense = mx > SH_CAP_MAX && nfix > h->fe_last_inum / 16;
+        if (h->flags_sh) h->fe_dense = mx > SH_CAP_MAX && nfix > h->flags_inum / 16;
         else h->fe_dense = mx > SH_CAP_MAX;
+        if (h->fe_dense != h->fe_dense_said) {          // a 2x change of speed the caller would otherwise only see in its timings
+            h->fe_dense_said = h->fe_dense;
+            if (h->notice) {
+                if (h->fe_dense)
+                    std::fprintf(h->notice, "annp/hip: up to %d in-cutoff neighbours per atom, more than the %d the moment kernels keep per atom "
+                                 "(%d atoms went through the fix-up launch): the Chebyshev passes run pair by pair from the next evaluation on, "
+                                 "at about half the speed\n", mx, (int)SH_CAP_MAX, nfix);
+                else
+                    std::fprintf(h->notice, "annp/hip: at most %d in-cutoff neighbours per atom again: back to the moment kernels\n", mx);
+                std::fflush(h->notice);
+            }
+        }
         h->info[3] = (h->fe_dense || h->fe_desc_pairs || h->fe_force_pairs) ? h->fe_cap : h->sh_cap;     // capacity of the next force pass
         if (over > 0)
             h->sticky_rc = fail(h, ANNP_HIP_ENEIGHCAP, "an atom has %d in-cutoff neighbours, more than the list-row capacity the "
@@ -540,7 +553,6 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.type = types; a.active = h->active;
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = vtab; a.vatom = d_vatom; a.ncount = h->ncount.p;
         a.errflag = h->d_flags;
-        a.dbg = h->fe_dbg;
         // pass 1 (and, for the force pass on the moments, their buffer; that pass needs the fix-up launch behind it)
         const size_t lds_fix = fe_force_lds_per_wave(cap_list, false);      // the fix-up runs one wave per workgroup
         const bool fix_possible = lds_fix <= 160 * 1024;
@@ -570,11 +582,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             a.n_cap = cap;
             a.ovf_count = h->d_flags + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
             if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
-            if (h->fe_force_sh3) {
-                const int wpb = SH3_WAVES;
-                if (vir) hipLaunchKernelGGL((annp_fe_force_sh3<FE_NP, FE_NT, true>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), sh3_lds_per_block(), s, a);
-                else hipLaunchKernelGGL((annp_fe_force_sh3<FE_NP, FE_NT, false>), dim3((inum + wpb - 1) / wpb), dim3(64 * wpb), sh3_lds_per_block(), s, a);
-            } else {
+            {
                 const int apb = SHF_GROUPS * SHF_GA;        // atoms per workgroup
                 if (vir) hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, true>), dim3((inum + apb - 1) / apb), dim3(64 * SHF_WAVES), shf_lds_per_block(), s, a);
                 else hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, false>), dim3((inum + apb - 1) / apb), dim3(64 * SHF_WAVES), shf_lds_per_block(), s, a);
@@ -730,6 +738,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipEventRecord(h->ev_flags, s));
     h->flags_pending = true;
+    h->flags_sh = h->fe_last_sh; h->flags_inum = h->fe_last_inum;      // (what digest_flags judges the queue length by)
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[3], s)); h->ev_count++; }
     (void)nall; (void)d_type;
     return 0;
@@ -956,8 +965,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (const char *e = std::getenv("ANNP_HIP_NI_PAIRS")) h->ni_no_pairs = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_NI_FIXUP")) h->ni_no_fixup = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_FE_DESC")) h->fe_desc_pairs = std::strcmp(e, "pairs") == 0;
-    if (const char *e = std::getenv("ANNP_HIP_FE_FORCE")) { h->fe_force_pairs = std::strcmp(e, "pairs") == 0; h->fe_force_sh3 = std::strcmp(e, "sh3") == 0; }
-    if (const char *e = std::getenv("ANNP_HIP_DBG")) h->fe_dbg = std::atoi(e);
+    if (const char *e = std::getenv("ANNP_HIP_FE_FORCE")) h->fe_force_pairs = std::strcmp(e, "pairs") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SH_WPB")) h->sh_wpb = std::min(4, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("ANNP_HIP_SH_CAP")) h->sh_cap = std::min((int)SH_CAP_MAX, std::max((int)SH_CAP_MIN, round_up(std::atoi(e), 16)));
     h->cutsq = cutsq_all;
@@ -1175,8 +1183,6 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc_fixup<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh<FE_NP, FE_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh<FE_NP, FE_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
-        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh3<FE_NP, FE_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
-        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh3<FE_NP, FE_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
@@ -1277,6 +1283,32 @@ int annp_hip_sync(annp_hip_handle *h)
     DEVICE_GUARD(h);
     HIP_TRY(h, hipDeviceSynchronize());
     return poll_flags(h, true);
+}
+
+int annp_hip_eval_path(annp_hip_handle *h)
+{
+    if (!h) return ANNP_HIP_EARG;
+    DEVICE_GUARD(h);
+    if (h->flags_pending) {
+        HIP_TRY(h, hipEventSynchronize(h->ev_flags));
+        h->flags_pending = false;
+        digest_flags(h);
+    }
+    if (h->descriptor == ANNP_HIP_DESC_BEHLER) return 3;
+    if (h->descriptor == ANNP_HIP_DESC_ANNA_ADP) return 4;
+    if (h->fe_desc_pairs || h->fe_force_pairs) return 2;
+    return h->fe_dense ? 1 : 0;
+}
+
+int annp_hip_set_notice(annp_hip_handle *h, void *file)
+{
+    if (!h) return ANNP_HIP_EARG;
+    h->notice = static_cast<FILE *>(file);
+    if (h->notice && (h->fe_desc_pairs || h->fe_force_pairs) && h->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
+        std::fprintf(h->notice, "annp/hip: ANNP_HIP_FE_DESC / ANNP_HIP_FE_FORCE = pairs: the Chebyshev passes run pair by pair (developer switch, about half the speed)\n");
+        std::fflush(h->notice);
+    }
+    return 0;
 }
 
 int annp_hip_eval_info(annp_hip_handle *h, int *info4)

@@ -63,7 +63,6 @@ struct FeArgs {
     // annp_fe_desc_sh when given, read by annp_fe_force_sh
     double *A;
     int *nbrs;                 // nullable [inum][128]: the in-cutoff neighbours of every atom in list order, annp_fe_desc_sh -> annp_fe_force_sh
-    int dbg;                   // developer switches (ANNP_HIP_DBG): 1 = annp_fe_force_sh skips the neighbour atomics, 2 = skips the columns
 };
 
 // LDS layout of one wave.  A record is two 16-byte halves (e_x,e_y) and (e_z,fc), kept in two
@@ -468,15 +467,12 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
     wave_lds_sync();
 
     // ---- stage B: pairs
-    double ce[NT], cd[NT];
+    double ce[NT];
 #pragma unroll
     for (int m = 0; m < NT; m++) ce[m] = cf[NP + m];
-#pragma unroll
-    for (int m = 0; m < NT - 1; m++) cd[m] = (double)(m + 1) * ce[m + 1];        // P'(z): d_k = (k+1) p_(k+1)
-    cd[NT - 1] = 0.0;
-    // the two Horner chains start from a register, not from a second SGPR operand per step
-    double ce_top = ce[NT - 1], cd_top = cd[NT - 2];
-    asm volatile("" : "+v"(ce_top), "+v"(cd_top));
+    // the Horner chain starts from a register, not from a second SGPR operand per step
+    double ce_top = ce[NT - 1];
+    asm volatile("" : "+v"(ce_top));
 
     const int nitems = n * FE_Q;
     const bool even = (n & 1) == 0;
@@ -506,12 +502,14 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
         auto step = [&](const double2 B0, const double2 B1, double *q) {
             const double c = fma(A1.x, B1.x, fma(A0.y, B0.y, A0.x * B0.x));
             // P(z) and dP/dz by Horner, z = cos(theta)
-            double P = ce_top;
-            double Pd = cd_top;
+            // (the derivative rides on the same coefficients: d <- d z + p, p <- p z + c_k; rounds 1-3 took (k+1) p_(k+1) from the
+            // coefficient row, where the network pass now leaves W_l for the force pass on the moments)
+            double Pd = ce_top;
+            double P = fma(ce_top, c, ce[NT - 2]);
 #pragma unroll
-            for (int mm = NT - 2; mm >= 0; mm--) {
+            for (int mm = NT - 3; mm >= 0; mm--) {
+                Pd = fma(Pd, c, P);
                 P = fma(P, c, ce[mm]);
-                if (mm < NT - 2) Pd = fma(Pd, c, cd[mm]);
             }
             // alpha = dP/dz fc_a fc_b.  Every contribution to a target's V lacks exactly that target's own fc
             // (a-side: fc_a, b-side: fc_b), so the accumulators hold V' = sum dP/dz fc_partner e_partner and

@@ -505,355 +505,9 @@ __global__ __launch_bounds__(64) void annp_fe_desc_fixup(FeArgs p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Force pass on the moments.  With P(z) = sum_l W_l P_l(z) the atom's angular polynomial (the network pass hands it over in
-// powers of z: W_l = sum_k p_k ml[k][l]),
-//     E_ang = sum_{a<b} fc_a fc_b P(e_a.e_b) = 1/2 sum_a fc_a (U(e_a) - P(1) fc_a),
-//     U(e) = sum_b fc_b P(e.e_b) = sum_{l,m} W_l kappa_lm [ A^c_lm C_lm(e) + A^s_lm S_lm(e) ]
-//          = sum_m Re[ (beta^c_m(z) - i beta^s_m(z)) (x+iy)^m ],     beta_m(z) = sum_k B_{m+k,m} Pm_k(z),  B = W kappa A
-// is a polynomial of e = (x,y,z) whose value and gradient at e_a are what annp_fe_force accumulates pair by pair:
-// S_a = sum_{b != a} P fc_b = U(e_a) - P(1) fc_a,  V'_a = sum_b P' fc_b e_b = grad U(e_a)  (the self term of the gradient
-// is along e_a and drops out of the force, which only sees grad U's part across e_a).  Per neighbour:
-//     dU/dz = sum_m Re[(beta'^c_m - i beta'^s_m) w^m],  dU/dx = sum_m m Re[(beta^c_m - i beta^s_m) w^(m-1)],  dU/dy likewise with i w^(m-1)
-// and d/dz Pm^(m)_k = k Pm^(m+1)_(k-1): beta'_m is summed with column m+1's polynomials, so one pass over the 190 recurrence
-// steps (2 instructions each) carries four sums (beta^c_m, beta^s_m, beta'^c_(m-1), beta'^s_(m-1): 4 FMAs) -- 112 x 190 x 6
-// instructions instead of 6 216 pairs x 46.
-// One wave per atom, a lane owns neighbours lane and lane + 64 (registers); the atom's 190 x 4 coefficients sit in LDS (every lane
-// reads the same address: a broadcast) and serve both neighbours of a lane at once.  Atoms with more neighbours than the
-// descriptor pass had state for (no moments) or than 128 go to annp_fe_force_fixup, as before.
-__host__ __device__ constexpr size_t sh3_lds_per_wave() { return (size_t)SHF_NE * 32 + 108 * 8 + 128 * 4; }
-static_assert(SHF_NE * 32 >= 128 * 32, "the coefficient table takes the place of the staging records");
-__host__ __device__ constexpr int sh_col_off(int m) { return m == 0 ? 0 : 19 + 38 * (m - 1) - (m - 1) * m; }   // = SH_COL_OFF[m]
-static_assert(sh_col_off(1) == SH_COL_OFF[1] && sh_col_off(7) == SH_COL_OFF[7] && sh_col_off(18) == SH_COL_OFF[18], "moment order");
-
-struct ShfNbr {
-    double z, ex, ey, qc, qs;             // e = (ex, ey, z); (qc,qs) = (x+iy)^(m-1) at the start of column m
-    double U, Ux, Uy, Uz;
-};
-
+// The force pass on the moments (annp_fe_force_sh) is in fe_shf_kernels.hpp.  Round 3's version of it -- one wave per atom, the
+// three-term recurrences of Pm^(m)_k run again per neighbour and column, four sums behind each step (6 x 190 instructions per
+// neighbour) -- is in the history (profiles/r03_*: 7.9 ms per 1 M atoms against 5.7 now).
 typedef double shf_v2d __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(3))) shf_v2d *shf_lds_ptr;
-constexpr int SHF_AHEAD = 3;
-template <int M>
-__device__ __forceinline__ void shf_column(const unsigned T, ShfNbr (&nb)[2])      // T: the table's byte address in LDS
-{
-    constexpr int K = SH_LMAX + 1 - M;
-    // a column starts when the previous one is done: its recurrence depends on z alone and would otherwise be started early,
-    // all 19 columns' worth of it, and held in registers; and the sums at the end of a column would be put off to the end of the kernel
-    asm volatile("" : "+v"(nb[0].z), "+v"(nb[1].z), "+v"(nb[0].U), "+v"(nb[1].U), "+v"(nb[0].Ux), "+v"(nb[1].Ux), "+v"(nb[0].Uy), "+v"(nb[1].Uy),
-                      "+v"(nb[0].Uz), "+v"(nb[1].Uz), "+v"(nb[0].qc), "+v"(nb[1].qc), "+v"(nb[0].qs), "+v"(nb[1].qs));
-    double bc[2] = {0.0, 0.0}, bs[2] = {0.0, 0.0}, dc[2] = {0.0, 0.0}, ds[2] = {0.0, 0.0};
-    double P2[2] = {1.0, 1.0}, P1[2] = {nb[0].z, nb[1].z};
-    // The coefficients of step k are requested SHF_AHEAD steps before they are used.  All 190 x 2 loads have known addresses and
-    // nothing but data flow orders arithmetic: left alone the compiler issues every load at the top of the kernel, runs the
-    // recurrences of all columns ahead of the sums that consume them, and spills 5 KB per lane.  An empty asm that "modifies" the
-    // table address together with the sums pins each step between its neighbours: the requests that follow it cannot start
-    // before it, it cannot start before the previous step's sums are done.
-    shf_v2d c0[K], c1[K];
-    unsigned tb = T;
-    auto pin = [&]() {
-        asm volatile("" : "+v"(tb), "+v"(bc[0]), "+v"(bc[1]), "+v"(bs[0]), "+v"(bs[1]), "+v"(dc[0]), "+v"(dc[1]), "+v"(ds[0]), "+v"(ds[1]),
-                          "+v"(P1[0]), "+v"(P1[1]));
-    };
-    auto request = [&](int k) {
-        const shf_lds_ptr tp = (shf_lds_ptr)(uintptr_t)(tb + 32u * (unsigned)(SHF_OFF[M] + k));
-        c0[k] = tp[0]; c1[k] = tp[1];
-    };
-    pin();
-#pragma unroll
-    for (int k = 0; k < (K < SHF_AHEAD ? K : SHF_AHEAD); k++) request(k);
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        if (k + SHF_AHEAD < K) request(k + SHF_AHEAD);
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            double P;
-            if (k == 0) P = 1.0;
-            else if (k == 1) P = nb[u].z;
-            else { P = fma(nb[u].z, P1[u], -(sh_gamma(M, k) * P2[u])); P2[u] = P1[u]; P1[u] = P; }
-            bc[u] = fma(c0[k].x, P, bc[u]);
-            if (M > 0) bs[u] = fma(c0[k].y, P, bs[u]);
-            if (M > 0) dc[u] = fma(c1[k].x, P, dc[u]);
-            if (M > 1) ds[u] = fma(c1[k].y, P, ds[u]);
-        }
-        pin();
-    }
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        ShfNbr &q = nb[u];
-        // (qc,qs) = (x+iy)^(M-1) is what is kept; (x+iy)^M is made from it where it is needed
-        const double wc = M == 0 ? 1.0 : fma(q.qc, q.ex, -(q.qs * q.ey)), ws = M == 0 ? 0.0 : fma(q.qc, q.ey, q.qs * q.ex);
-        q.U = fma(bc[u], wc, q.U);
-        if (M > 0) {
-            q.U = fma(bs[u], ws, q.U);
-            q.Uz = fma(dc[u], q.qc, q.Uz);
-            if (M > 1) q.Uz = fma(ds[u], q.qs, q.Uz);
-            const double tx = fma(bc[u], q.qc, bs[u] * q.qs), ty = fma(bs[u], q.qc, -(bc[u] * q.qs));
-            q.Ux = fma((double)M, tx, q.Ux);
-            q.Uy = fma((double)M, ty, q.Uy);
-        }
-        q.qc = wc; q.qs = ws;
-    }
-}
-template <int M>
-struct ShfColumns {
-    static __device__ __forceinline__ void run(const unsigned T, ShfNbr (&nb)[2])
-    {
-        shf_column<M>(T, nb);
-        ShfColumns<M + 1>::run(T, nb);
-    }
-};
-template <>
-struct ShfColumns<SH_LMAX + 1> {
-    static __device__ __forceinline__ void run(const unsigned, ShfNbr (&)[2]) {}
-};
-
-// Forces leave through a table in LDS that the atoms of a workgroup share (8 waves = 8 consecutive atoms: neighbours in space,
-// whose ~900 (atom, neighbour) contributions fall on ~200 distinct atoms): open addressing on the atom index, LDS atomics, and one
-// global atomic per distinct atom and component when the workgroup is done.  The pass was bound by its 3 x 112 global
-// atomics per atom before: 12.0 ms per 1 M atoms with them, 7.4 without, 11.0 with them and without the arithmetic.
-constexpr int SH3_WAVES = 8;          // waves (atoms) per workgroup
-constexpr int SH3_TSLOTS = 512;       // slots of the workgroup's force table
-constexpr int SH3_TPROBE = 8;         // occupied slots tried before a contribution goes straight to global memory
-__host__ __device__ constexpr size_t sh3_lds_table() { return (size_t)SH3_TSLOTS * (4 + 24); }
-__host__ __device__ constexpr size_t sh3_lds_per_block();
-__host__ __device__ constexpr size_t sh3_lds_per_block() { return sh3_lds_table() + SH3_WAVES * sh3_lds_per_wave(); }
-struct Sh3Table {
-    int *key;          // [SH3_TSLOTS], -1 = free
-    double *acc;       // [SH3_TSLOTS][3]
-    double *f;
-    __device__ __forceinline__ void add(int j, double fx, double fy, double fz) const
-    {
-        unsigned sl = ((unsigned)j * 0x9E3779B1u) >> 23;
-#pragma unroll 1
-        for (int probe = 0; probe < SH3_TPROBE; probe++) {
-            const int old = atomicCAS(&key[sl], -1, j);
-            if (old == -1 || old == j) {
-                atomicAdd(&acc[3 * sl], fx); atomicAdd(&acc[3 * sl + 1], fy); atomicAdd(&acc[3 * sl + 2], fz);
-                return;
-            }
-            sl = (sl + 1) & (SH3_TSLOTS - 1);
-        }
-        atomicAdd(&f[3 * (size_t)j], fx); atomicAdd(&f[3 * (size_t)j + 1], fy); atomicAdd(&f[3 * (size_t)j + 2], fz);
-    }
-};
-
-template <int NP, int NT, bool VIRIAL>
-__device__ __forceinline__ void shf_atom(const FeArgs &p, const int ii, const int lane, unsigned char *wbase, const Sh3Table &tab)
-{
-    static_assert(NT == SH_LMAX + 1 && NP + 2 * NT - 1 <= 48, "coefficient row");
-    double2 *recA = reinterpret_cast<double2 *>(wbase);           // stage A: raw entries [128] (dx,dy), [128] (dz,r^2), [128] j
-    double2 *recB = recA + 128;
-    int *auxJ = reinterpret_cast<int *>(wbase + (size_t)SHF_NE * 32 + 108 * 8);     // (behind the table: read again at the end)
-    double2 *T = reinterpret_cast<double2 *>(wbase);              // then: the coefficient table [190][2]
-    double *cw = reinterpret_cast<double *>(wbase + (size_t)SHF_NE * 32);      // [0,48) coefficient row, [48,108) W_l in three partial sums
-    const int i = p.ilist ? p.ilist[ii] : ii;
-    const double pi_over_rc = ANNP_MY_PI / p.rc_list;
-    const double two_over_rcp = 2.0 / p.rc_par;
-    const double *cf = p.coef + (size_t)ii * ANNP_CPAD;
-
-    if (p.type && !type_mapped(p.active, p.type[i])) return;
-    // ---- everything that does not depend on the neighbour list is requested now and lands while the list is read: the
-    //      coefficient row, this lane's column of ml, and for its (up to) three table entries (m,k) the four scaled moments
-    //      kappa A of (l = m+k, m) and (l, m-1).  (Three dependent round trips through memory otherwise, behind the three the
-    //      list takes -- with half the arithmetic of the pair loop to hide them behind.)
-    const double cf_lane = cf[lane < 48 ? lane : 47];
-    // W_l: lane (l, part) = (lane % 19, lane / 19) sums every third k (57 lanes; three partial sums per l meet in LDS)
-    const int wl = lane % NT, wpart = lane / NT;
-    double mlv[(NT + 2) / 3];
-#pragma unroll
-    for (int t = 0; t < (NT + 2) / 3; t++) {
-        const int k = 3 * t + wpart;
-        mlv[t] = (wpart < 3 && k < NT) ? annp_sh_ml[k * NT + wl] : 0.0;
-    }
-    int te_l[3], te_k[3];
-    double te_a[3][4];
-    {
-        const double *Am = p.A + (size_t)ii * SH_MPAD;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            // entry e of the table = step k of column m: e = SHF_OFF[m] + k, SHF_OFF[m] = 19 m - m (m-1) / 2
-            const int e = min(lane + 64 * t, SHF_NE - 1);
-            int m = (int)((39.0f - __builtin_sqrtf(1521.0f - 8.0f * (float)e)) * 0.5f);
-            m = min(max(m, 0), SH_LMAX);
-            if (m < SH_LMAX && NT * (m + 1) - (m + 1) * m / 2 <= e) m++;
-            if (NT * m - m * (m - 1) / 2 > e) m--;
-            const int k = e - (NT * m - m * (m - 1) / 2), K = SH_LMAX + 1 - m;
-            te_l[t] = m + k; te_k[t] = k;
-            const int ic = sh_apos(m, k);
-            const int id = m > 0 ? sh_apos(m - 1, k + 1) : 0;
-            te_a[t][0] = Am[ic];
-            te_a[t][1] = m > 0 ? Am[ic + 1] : 0.0;
-            te_a[t][2] = m > 0 ? Am[id] : 0.0;
-            te_a[t][3] = m > 1 ? Am[id + 1] : 0.0;
-        }
-    }
-    // the in-cutoff neighbours: from the descriptor pass's list (count and indices, list order) or by filtering the row again
-    const bool listed = p.nbrs != nullptr;
-    const int n = listed ? uniform(p.ncount[ii]) : fe_compact<true>(p, i, lane, recA, recB, auxJ, 128);
-    if (n > p.n_cap) {            // no moments for this atom (or more neighbours than two per lane): the pair loop takes it
-        if (lane == 0) {
-            const int k = p.ovf_list ? atomicAdd(p.ovf_count, 1) : p.ovf_cap;
-            if (k < p.ovf_cap) p.ovf_list[k] = ii;
-            else atomicMax(p.errflag, n);
-        }
-        return;
-    }
-    if (lane < 48) cw[lane] = cf_lane;
-    wave_lds_sync();
-
-    // ---- this lane's two neighbours: geometry and the radial term (fe:648), kept in registers
-    ShfNbr nb[2];
-    double fc[2], dfc[2], rinv[2], rr[2];
-    {
-        double cr[NP];
-#pragma unroll
-        for (int m = 0; m < NP; m++) cr[m] = cf[m];
-        const int *myrow = p.nbrs + (size_t)ii * SH_CAP_MAX;
-        int jl[2] = {i, i};
-        if (listed && n > 0) {          // (an atom without neighbours has no row: nothing was written there)
-#pragma unroll
-            for (int u = 0; u < 2; u++) jl[u] = myrow[min(lane + 64 * u, n - 1)];
-        }
-        const double xi = p.x[3 * (size_t)i], yi = p.x[3 * (size_t)i + 1], zi = p.x[3 * (size_t)i + 2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int a = lane + 64 * u;
-            const bool has = a < n;
-            double2 R0, R1;
-            if (listed) {
-                const double dx = xi - p.x[3 * (size_t)jl[u]], dy = yi - p.x[3 * (size_t)jl[u] + 1], dz = zi - p.x[3 * (size_t)jl[u] + 2];
-                R0 = make_double2(dx, dy); R1 = make_double2(dz, dx * dx + dy * dy + dz * dz);
-                if (!has) { R0 = make_double2(0.0, 0.0); R1 = make_double2(1.0, 1.0); }
-            } else {
-                R0 = has ? recA[a] : make_double2(0.0, 0.0); R1 = has ? recB[a] : make_double2(1.0, 1.0);
-            }
-            const FeNbr g = fe_geometry(R0, R1, pi_over_rc);
-            const double xr = g.r * two_over_rcp - 1.0;
-            const double y2 = 2.0 * xr;
-            double tm2 = 1.0, tm1 = xr, dm2 = 0.0, dm1 = 1.0;
-            double st = cr[0], sd = 0.0;              // sum c T, sum c T'
-            if (NP > 1) { st = fma(cr[1], xr, st); sd = cr[1]; }
-#pragma unroll
-            for (int mm = 2; mm < NP; mm++) {
-                const double t = fma(y2, tm1, -tm2);
-                const double d = fma(y2, dm1, fma(2.0, tm1, -dm2));
-                st = fma(cr[mm], t, st);
-                sd = fma(cr[mm], d, sd);
-                tm2 = tm1; tm1 = t; dm2 = dm1; dm1 = d;
-            }
-            const double R = fma(sd * two_over_rcp, g.fc, st * g.dfc);
-            nb[u].z = g.ez; nb[u].ex = g.ex; nb[u].ey = g.ey;
-            nb[u].qc = 0.0; nb[u].qs = 0.0;
-            nb[u].U = 0.0; nb[u].Ux = 0.0; nb[u].Uy = 0.0; nb[u].Uz = 0.0;
-            fc[u] = has ? g.fc : 0.0; dfc[u] = g.dfc; rinv[u] = g.rinv; rr[u] = -R * g.r;
-        }
-    }
-    // ---- W_l = sum_k p_k ml[k][l], P(1) = sum_k p_k
-    {
-        double w = 0.0;
-#pragma unroll
-        for (int t = 0; t < (NT + 2) / 3; t++) {
-            const int k = 3 * t + wpart;
-            if (wpart < 3 && k < NT) w = fma(cw[NP + k], mlv[t], w);
-        }
-        if (wpart < 3) cw[48 + wpart * 20 + wl] = w;         // [48,67) [68,87) [88,107): the three partial sums
-    }
-    wave_lds_sync();            // the raw records are in registers, the W_l are there: the table may take the records' place
-
-    // ---- coefficient table: entry (m,k) = B^c, B^s of (l = m+k, m) and (k+1) B^c, (k+1) B^s of (l, m-1);  B = W_l kappa A
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-        const int e = lane + 64 * t;
-        if (e < SHF_NE) {
-            const double w = (cw[48 + te_l[t]] + cw[68 + te_l[t]]) + cw[88 + te_l[t]];
-            const double wk = w * (double)(te_k[t] + 1);
-            T[2 * e] = make_double2(w * te_a[t][0], w * te_a[t][1]);
-            T[2 * e + 1] = make_double2(wk * te_a[t][2], wk * te_a[t][3]);
-        }
-    }
-    wave_lds_sync();
-
-    // ---- value and gradient of U at the two neighbours
-    if (!(p.dbg & 2)) ShfColumns<0>::run((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)T, nb);
-
-    // ---- finalize: Fn_a = sum_n c_n dG_n/dx_a ; F_a = -Fn_a to neighbour, +Fn_a to centre (fe:190-213), as annp_fe_force
-    double fi0 = 0.0, fi1 = 0.0, fi2 = 0.0;
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
-    double pone = 0.0;          // P(1) = sum_k p_k (the coefficient row is still in LDS)
-#pragma unroll
-    for (int k = 0; k < NT; k++) pone += cw[NP + k];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        if (lane + 64 * u < n) {
-            const ShfNbr &q = nb[u];
-            const double V0 = fc[u] * q.Ux, V1 = fc[u] * q.Uy, V2 = fc[u] * q.Uz;           // V_a = fc_a grad U
-            const double S = fma(-pone, fc[u], q.U);                                        // sum_{b != a} P fc_b
-            const double cq = fma(q.ex, V0, fma(q.ey, V1, fma(q.z, V2, rr[u])));
-            const double t = fma(cq, rinv[u], -S * dfc[u]);
-            const double g0 = fma(t, q.ex, -V0 * rinv[u]);
-            const double g1 = fma(t, q.ey, -V1 * rinv[u]);
-            const double g2 = fma(t, q.z, -V2 * rinv[u]);
-            const int j = listed ? p.nbrs[(size_t)ii * SH_CAP_MAX + lane + 64 * u] : auxJ[lane + 64 * u];
-            if (!(p.dbg & 1)) tab.add(j, -g0, -g1, -g2);
-            fi0 += g0; fi1 += g1; fi2 += g2;
-            if (VIRIAL) {   // ev_tally_xyz(i,j,...,fx=-Fj, del = xi-xj = r e)   (fe:201-209)
-                const double r = 1.0 / rinv[u];
-                const double d0 = r * q.ex, d1 = r * q.ey, d2 = r * q.z;
-                const double w0 = d0 * g0, w1 = d1 * g1, w2 = d2 * g2, w3 = d0 * g1, w4 = d0 * g2, w5 = d1 * g2;
-                v0 += w0; v1 += w1; v2 += w2; v3 += w3; v4 += w4; v5 += w5;
-                if (p.vatom) {
-                    double *vj = p.vatom + 6 * (size_t)j;
-                    atomicAdd(vj + 0, 0.5 * w0); atomicAdd(vj + 1, 0.5 * w1); atomicAdd(vj + 2, 0.5 * w2);
-                    atomicAdd(vj + 3, 0.5 * w3); atomicAdd(vj + 4, 0.5 * w4); atomicAdd(vj + 5, 0.5 * w5);
-                }
-            }
-        }
-    }
-    fi0 = wave_sum(fi0); fi1 = wave_sum(fi1); fi2 = wave_sum(fi2);
-    if (lane == 0) tab.add(i, fi0, fi1, fi2);
-    if (VIRIAL) {
-        v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
-        v3 = wave_sum(v3); v4 = wave_sum(v4); v5 = wave_sum(v5);
-        if (lane == 0) {
-            if (p.virial) {
-                double *vr = virial_row(p.virial);          // (annp_common.hpp: the global virial)
-                atomicAdd(&vr[0], v0); atomicAdd(&vr[1], v1); atomicAdd(&vr[2], v2);
-                atomicAdd(&vr[3], v3); atomicAdd(&vr[4], v4); atomicAdd(&vr[5], v5);
-            }
-            if (p.vatom) {
-                double *vi = p.vatom + 6 * (size_t)i;
-                atomicAdd(vi + 0, 0.5 * v0); atomicAdd(vi + 1, 0.5 * v1); atomicAdd(vi + 2, 0.5 * v2);
-                atomicAdd(vi + 3, 0.5 * v3); atomicAdd(vi + 4, 0.5 * v4); atomicAdd(vi + 5, 0.5 * v5);
-            }
-        }
-    }
-}
-
-template <int NP, int NT, bool VIRIAL>
-__global__ __launch_bounds__(64 * SH3_WAVES, 4) void annp_fe_force_sh3(FeArgs p)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = lane_id();
-    const int wave = uniform(threadIdx.x >> 6);
-    const int ii = uniform(xcd_block() * SH3_WAVES + wave);
-    Sh3Table tab;
-    tab.key = reinterpret_cast<int *>(lds_raw + (size_t)SH3_TSLOTS * 24);
-    tab.acc = reinterpret_cast<double *>(lds_raw);
-    tab.f = p.f;
-    for (int sl = threadIdx.x; sl < SH3_TSLOTS; sl += 64 * SH3_WAVES) {
-        tab.key[sl] = -1; tab.acc[3 * sl] = 0.0; tab.acc[3 * sl + 1] = 0.0; tab.acc[3 * sl + 2] = 0.0;
-    }
-    __syncthreads();
-    if (ii < p.inum) shf_atom<NP, NT, VIRIAL>(p, ii, lane, lds_raw + sh3_lds_table() + (size_t)wave * sh3_lds_per_wave(), tab);
-    __syncthreads();
-    // the workgroup's table: one global atomic per distinct atom and component
-    for (int sl = threadIdx.x; sl < SH3_TSLOTS; sl += 64 * SH3_WAVES) {
-        const int j = tab.key[sl];
-        if (j >= 0) {
-            atomicAdd(&p.f[3 * (size_t)j], tab.acc[3 * sl]); atomicAdd(&p.f[3 * (size_t)j + 1], tab.acc[3 * sl + 1]);
-            atomicAdd(&p.f[3 * (size_t)j + 2], tab.acc[3 * sl + 2]);
-        }
-    }
-}
 
 }  // namespace annp

@@ -107,6 +107,7 @@ int init_common(const int ntypes, const int inum, const int nall, const int max_
     }
     S.ntypes = ntypes;
     S.cutneigh = cell_size;
+    annp_hip_set_notice(S.h, screen);           // a change of kernel path (a system denser than the moment kernels take) is said once
     const char *nm = std::getenv("ANNP_HIP_NEIGH");
     gpu_mode = (nm && std::strcmp(nm, "host") == 0) ? GPU_FORCE : GPU_NEIGH;
     if (screen)

@@ -8,7 +8,7 @@ _LIB = None
 # symbols include/annp_hip.h declares
 ABI_SYMBOLS = [
     "annp_hip_init", "annp_hip_compute", "annp_hip_compute_n", "annp_hip_compute_device",
-    "annp_hip_neigh_build_device", "annp_hip_list_cutoff", "annp_hip_list_layout", "annp_hip_neigh_to_host", "annp_hip_sync", "annp_hip_eval_info", "annp_hip_set_timing", "annp_hip_last_timing",
+    "annp_hip_neigh_build_device", "annp_hip_list_cutoff", "annp_hip_list_layout", "annp_hip_neigh_to_host", "annp_hip_sync", "annp_hip_eval_info", "annp_hip_eval_path", "annp_hip_set_notice", "annp_hip_set_timing", "annp_hip_last_timing",
     "annp_hip_timing_stats", "annp_hip_last_counts", "annp_hip_last_descriptors",
     "annp_hip_comm_unique_id", "annp_hip_comm_init", "annp_hip_comm_route", "annp_hip_comm_destroy",
     "annp_hip_halo_pack", "annp_hip_halo_unpack_images", "annp_hip_reverse_fold", "annp_hip_verlet_half",
@@ -62,6 +62,8 @@ def load_library():
     lib.annp_hip_list_cutoff.argtypes = [vp, C.c_double]
     lib.annp_hip_list_cutoff.restype = C.c_double
     lib.annp_hip_eval_info.argtypes = [vp, ip]
+    lib.annp_hip_eval_path.argtypes = [vp]
+    lib.annp_hip_set_notice.argtypes = [vp, vp]
     lib.annp_hip_set_timing.argtypes = [vp, C.c_int]
     lib.annp_hip_last_timing.argtypes = [vp, dp]
     lib.annp_hip_timing_stats.argtypes = [vp, dp, ip]

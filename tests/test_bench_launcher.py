@@ -44,3 +44,31 @@ def test_single_rank_needs_no_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip())
     assert out["n_gpus"] == 1 and out["config"]["atoms_rank"] == [432]
+
+
+def test_eight_ranks_the_driver_configuration():
+    """The driver's last configuration, N = 8, rehearsed here on CPU: eight ranks over gloo through
+    launch_ranks, slabs 3 cells = 8.57 A thick (the thinnest a one-neighbour halo allows), re-planning and thermo all-reduces
+    included; rank 0's line carries what tells a slow rank from a slow wire."""
+    r = run_bench("--gpus", "8", "--steps", "3", "--warmup", "1", "--cells", "24", "--rebuild-every", "2", "--thermo", "2", timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 8 and cfg["world_size"] == 8 and out["scaling"] == "strong"
+    assert len(cfg["atoms_rank"]) == 8 and sum(cfg["atoms_rank"]) == cfg["atoms"] == 2 * 24 ** 3
+    assert all(g > 0 for g in cfg["ghosts_rank"])
+    pr = out["per_rank"]
+    assert len(pr["step_ms"]) == 8 and all(v > 0 for v in pr["step_ms"])
+    assert len(pr["halo_ms"]["forward"]) == 8 and len(pr["halo_ms"]["reverse"]) == 8 and all(v >= 0 for v in pr["halo_ms"]["forward"])
+    assert all(len(v) == 8 for v in pr["kernel_ms"].values())
+    assert out["mini_md"] is not None
+
+
+def test_world_size_mismatch_fails_loudly():
+    """--gpus must be the size of the job: a rank started with another WORLD_SIZE exits non-zero with one line"""
+    env = dict(os.environ, ANNP_BENCH_DRYRUN="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--cells", "8"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()

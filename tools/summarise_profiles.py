@@ -38,8 +38,26 @@ out = {"command": "rocprofv3 --pmc <one counter group per pass> --output-format 
        "workload": {"fe": "1024000-atom bcc-Fe", "ni": "512000-atom fcc-Ni", "anna": "1024000-atom bcc-Fe, pair_style anna_adp"}[wl],
        "per_launch_mean": res}
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "profiles", tag + suffix + "_pmc_counters.json"), "w"), indent=1, sort_keys=True)
 ks = glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))
+# average launch duration of every kernel from the kernel trace of the same command, and what follows from it together with the
+# counters: the shader clock the chip held under that kernel (GRBM_GUI_ACTIVE is summed over the 8 XCDs), HBM bytes per second,
+# FP64-MFMA flop per second (SQ_INSTS_VALU_MFMA_MOPS_F64 counts 512 flop each: v_mfma_f64_16x16x4 = 2048 flop = 4 of them)
+if ks:
+    for r in csv.DictReader(open(ks[0])):
+        k = r["Name"].split("(")[0].replace("void ", "")
+        if k in res:
+            e = res[k]
+            e["avg_ms"] = float(r["AverageNs"]) / 1e6
+            e["trace_calls"] = int(r["Calls"])
+            if e.get("GRBM_GUI_ACTIVE"):
+                e["clock_GHz"] = e["GRBM_GUI_ACTIVE"] / 8 / float(r["AverageNs"])
+            if "hbm_bytes_upper" in e:
+                e["hbm_GBps_upper"] = e["hbm_bytes_upper"] / float(r["AverageNs"])
+                e["hbm_GBps_lower"] = e["hbm_bytes_lower"] / float(r["AverageNs"])
+            if e.get("SQ_INSTS_VALU_MFMA_MOPS_F64"):
+                e["mfma_TFLOPs"] = e["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512 / float(r["AverageNs"]) / 1e3
+                e["mfma_busy_share"] = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * e["GRBM_GUI_ACTIVE"] / 8) if e.get("GRBM_GUI_ACTIVE") else None
+json.dump(out, open(os.path.join(ROOT, "profiles", tag + suffix + "_pmc_counters.json"), "w"), indent=1, sort_keys=True)
 if ks:
     shutil.copy(ks[0], os.path.join(ROOT, "profiles", tag + suffix + "_bench_kernel_stats.csv"))
 bj = os.path.join(src, "bench_under_rocprof.json")
