@@ -135,9 +135,10 @@ __device__ __forceinline__ double sh_row_reduce(double (&v)[16], bool bit1, bool
 }
 __host__ __device__ constexpr int sh_pow2_at_least(int r) { return r <= 1 ? 1 : r <= 2 ? 2 : r <= 4 ? 4 : r <= 8 ? 8 : 16; }
 
+typedef double shf_v2d __attribute__((ext_vector_type(2)));
+
 struct ShLane {
-    double2 *SA, *SC;      // this lane's first LDS slot of (e_x,e_y) and of the running power
-    double *SZ;
+    unsigned a_sa, a_sc, a_sz;     // LDS byte addresses of this lane's first slot of (e_x,e_y), of the running power and of z
     double *pwg;           // pw of this lane's atom
     double *Aout;          // nullable: the atom's row of the moment buffer
     int iters;             // LDS-resident neighbours per lane to walk (uniform, may be 0)
@@ -219,20 +220,47 @@ __device__ __forceinline__ void sh_column(const ShLane &w, ShRegs &st)
     }
     int left = uniform(w.iters);
     if (left > 0) {
-        double2 *pa = w.SA, *pc = w.SC;
-        double *pz = w.SZ;
-        // the next neighbour's z and power are requested before the current one is worked on (one slot past the last is read and
-        // dropped: it exists); (e_x,e_y) is only needed when the power is advanced, at the end
-        double2 C = *pc;
-        double z = *pz;
-        do {
-            const double2 A = *pa, Cn = pc[SH_GL];
-            const double zn = pz[SH_GL];
-            neighbour(std::false_type{}, z, C.x, C.y);
-            if (M < SH_LMAX) *pc = make_double2(fma(C.x, A.x, -(C.y * A.y)), fma(C.x, A.y, C.y * A.x));
-            pa += SH_GL; pc += SH_GL; pz += SH_GL;
-            C = Cn; z = zn;
-        } while (--left > 0);
+        // The LDS-resident neighbours, two per trip (an odd one first).  A neighbour's z and power are requested while the one
+        // before it is worked on, into the registers that one has just given up (no moves), (e_x,e_y) only where the power is
+        // advanced; the three arrays are walked with one address each and immediate offsets (the compiler otherwise keeps a
+        // scalar base and a per-lane offset per array and adds them for every access: a dozen integer instructions per
+        // neighbour and column, a tenth of the kernel).  One slot past the last is read and dropped: it exists.
+        typedef __attribute__((address_space(3))) shf_v2d *l2p;
+        typedef __attribute__((address_space(3))) double *l1p;
+        unsigned qa = w.a_sa, qc = w.a_sc, qz = w.a_sz;
+        auto advance = [&](const shf_v2d C, const shf_v2d A, const unsigned at) {
+            if (M < SH_LMAX) {
+                shf_v2d r;
+                r.x = fma(C.x, A.x, -(C.y * A.y)); r.y = fma(C.x, A.y, C.y * A.x);
+                *(l2p)(uintptr_t)at = r;
+            }
+        };
+        shf_v2d C0 = *(l2p)(uintptr_t)qc;
+        double z0 = *(l1p)(uintptr_t)qz;
+        if (left & 1) {
+            const shf_v2d A0 = *(l2p)(uintptr_t)qa;
+            const shf_v2d Cn = *(l2p)(uintptr_t)(qc + 16u * SH_GL);
+            const double zn = *(l1p)(uintptr_t)(qz + 8u * SH_GL);
+            neighbour(std::false_type{}, z0, C0.x, C0.y);
+            advance(C0, A0, qc);
+            qa += 16u * SH_GL; qc += 16u * SH_GL; qz += 8u * SH_GL;
+            C0 = Cn; z0 = zn;
+            left--;
+        }
+        while (left > 0) {
+            const shf_v2d A0 = *(l2p)(uintptr_t)qa;
+            const shf_v2d C1 = *(l2p)(uintptr_t)(qc + 16u * SH_GL);
+            const double z1 = *(l1p)(uintptr_t)(qz + 8u * SH_GL);
+            neighbour(std::false_type{}, z0, C0.x, C0.y);
+            advance(C0, A0, qc);
+            const shf_v2d A1 = *(l2p)(uintptr_t)(qa + 16u * SH_GL);
+            C0 = *(l2p)(uintptr_t)(qc + 32u * SH_GL);
+            z0 = *(l1p)(uintptr_t)(qz + 16u * SH_GL);
+            neighbour(std::false_type{}, z1, C1.x, C1.y);
+            advance(C1, A1, qc + 16u * SH_GL);
+            qa += 32u * SH_GL; qc += 32u * SH_GL; qz += 16u * SH_GL;
+            left -= 2;
+        }
     }
     sh_batch<M, 0>(w, ac, as, kap0);
     if (NB > 1) sh_batch<M, (NB > 1 ? 1 : 0)>(w, ac, as, kap1);
@@ -454,7 +482,10 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
         }
     }
     ShLane w;
-    w.SA = SA + g * PL + l; w.SC = SC + g * PL + l; w.SZ = SZ + g * PL + l; w.pwg = pw + g * 20;
+    w.a_sa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(SA + g * PL + l);
+    w.a_sc = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(SC + g * PL + l);
+    w.a_sz = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(SZ + g * PL + l);
+    w.pwg = pw + g * 20;
     w.iters = iters;
     w.Aout = (p.A && !dead) ? p.A + (size_t)(ii0 + g) * SH_MPAD : nullptr;
     w.jrev = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 1) & 1) << 2) | ((lane & 1) << 3);
@@ -508,6 +539,4 @@ __global__ __launch_bounds__(64) void annp_fe_desc_fixup(FeArgs p)
 // The force pass on the moments (annp_fe_force_sh) is in fe_shf_kernels.hpp.  Round 3's version of it -- one wave per atom, the
 // three-term recurrences of Pm^(m)_k run again per neighbour and column, four sums behind each step (6 x 190 instructions per
 // neighbour) -- is in the history (profiles/r03_*: 7.9 ms per 1 M atoms against 5.7 now).
-typedef double shf_v2d __attribute__((ext_vector_type(2)));
-
 }  // namespace annp
