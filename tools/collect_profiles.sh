@@ -18,12 +18,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- p
     > $out/bench_under_rocprof.json 2> $out/trace.err
 echo "trace done"
 n=0
+failed=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_ATOMIC_sum" \
            "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \
            "SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64" \
            "SQ_WAIT_ANY SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS"; do
     n=$((n+1))
     rocprofv3 --pmc $grp --output-format csv -d $out/pmc$n -o pmc -- python3 bench.py $wlargs --steps 2 --warmup 1 --cpu-sample 0 --rebuild-every 0 --secondary 0 \
-        > $out/pmc$n.json 2> $out/pmc$n.err || echo "pmc pass $n FAILED (see $out/pmc$n.err)"
+        > $out/pmc$n.json 2> $out/pmc$n.err || { echo "pmc pass $n FAILED (see $out/pmc$n.err)"; tail -5 $out/pmc$n.err; failed=$((failed+1)); }
     echo "pmc pass $n done: $grp"
 done
+if [ $failed -ne 0 ]; then echo "$failed counter pass(es) failed: nothing of this run goes into profiles/ before that is understood"; exit 1; fi

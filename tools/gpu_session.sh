@@ -15,9 +15,9 @@ for step in "$@"; do
               timeout -k 10 300 python tools/kbench.py anna 80 > $out/kbench_anna.log 2>&1 || { tail -20 $out/kbench_anna.log; exit 1; }; tail -1 $out/kbench_anna.log ;;
     bench)    timeout -k 10 600 python bench.py > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }; cat $out/bench.json ;;
     hostpath) timeout -k 10 600 python tools/hostpath_bench.py 80 > $out/hostpath.log 2>&1 || { tail -20 $out/hostpath.log; exit 1; }; cat $out/hostpath.log ;;
-    selfwire) ANNP_FORCE_DIST=1 ANNP_BENCH_WIRE_SELF=1 timeout -k 10 300 python bench.py --cells 40 --steps 10 --secondary 0 --cpu-sample 0 > $out/selfwire.json 2> $out/selfwire.err; echo "selfwire rc=$?"; tail -5 $out/selfwire.err; cat $out/selfwire.json
-              ANNP_FORCE_DIST=1 ANNP_BENCH_WIRE_SELF=1 ANNP_BENCH_WIRE=lib timeout -k 10 300 python bench.py --cells 40 --steps 10 --secondary 0 --cpu-sample 0 > $out/selfwire_lib.json 2> $out/selfwire_lib.err; echo "selfwire_lib rc=$?"; tail -5 $out/selfwire_lib.err; cat $out/selfwire_lib.json
-              timeout -k 10 300 python bench.py --cells 40 --steps 10 --secondary 0 --cpu-sample 0 > $out/selfwire_ref.json 2> $out/selfwire_ref.err; cat $out/selfwire_ref.json ;;
+    selfwire) ANNP_FORCE_DIST=1 ANNP_BENCH_WIRE_SELF=1 timeout -k 10 300 python bench.py --cells 40 --steps 10 --secondary 0 --cpu-sample 0 > $out/selfwire.json 2> $out/selfwire.err || { tail -20 $out/selfwire.err; exit 1; }; cat $out/selfwire.json
+              ANNP_FORCE_DIST=1 ANNP_BENCH_WIRE_SELF=1 ANNP_BENCH_WIRE=lib timeout -k 10 300 python bench.py --cells 40 --steps 10 --secondary 0 --cpu-sample 0 > $out/selfwire_lib.json 2> $out/selfwire_lib.err || { tail -20 $out/selfwire_lib.err; exit 1; }; cat $out/selfwire_lib.json
+              timeout -k 10 300 python bench.py --cells 40 --steps 10 --secondary 0 --cpu-sample 0 > $out/selfwire_ref.json 2> $out/selfwire_ref.err || { tail -20 $out/selfwire_ref.err; exit 1; }; cat $out/selfwire_ref.json ;;
     trace128k) cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
               timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t128k -o t -- python3 bench.py --cells 40 --steps 20 --warmup 5 --cpu-sample 0 --rebuild-every 0 --secondary 0 > $out/b128k.json 2> $out/b128k.err || exit 1
               ANNP_BENCH_TORCH_STEP=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t128k_torch -o t -- python3 bench.py --cells 40 --steps 20 --warmup 5 --cpu-sample 0 --rebuild-every 0 --secondary 0 > $out/b128k_torch.json 2> $out/b128k_torch.err || exit 1 ;;
