@@ -245,9 +245,8 @@ class Leg:
         d.verlet_half(d.extra["v"], self.dtf, a.dt)         # FixNVE::initial_integrate
         m0 = self.mark()
         if rebuild:
-            d.replan()                      # Comm::exchange + Comm::borders (atoms, velocities and ids change rank here); f comes back zeroed
+            d.replan(eng=self.eng)          # Comm::exchange + Comm::borders (atoms, velocities and ids change rank here); f and the energy word come back zeroed
             self.build_list()               # Neighbor::build
-            self.eng.zero_()
         else:
             d.forward(clear_forces=True, eng=self.eng)      # Comm::forward_comm + Verlet::force_clear
         m1 = self.mark()

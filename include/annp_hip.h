@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define ANNP_HIP_ABI_VERSION 6
+#define ANNP_HIP_ABI_VERSION 7
 
 #define ANNP_HIP_OK 0
 #define ANNP_HIP_EARG (-1)
@@ -215,6 +215,33 @@ int annp_hip_halo_unpack_images(annp_hip_handle *handle, int nimg, const int *d_
                                 int first_image_row, double *d_f_clear, long long n_clear, double *d_eng_clear, void *stream);
 int annp_hip_reverse_fold(annp_hip_handle *handle, int nseg, const int *d_seg_dst, const int *d_seg_start, const int *d_perm,
                           const double *d_src, double *d_f, void *stream);
+/* Re-planning at a list rebuild, on the device -- what LAMMPS' Comm::exchange and Comm::borders do for the reference (the pair
+ * style only sees their result: owned atoms first, ghosts behind them).  Every selection keeps index order, so the arrays are
+ * those of meng_zhang_amd/domain.py's torch restatement bit for bit.  The wire stays with the caller.  Each call synchronises
+ * the stream once per selection (the counts size the caller's messages and buffers).
+ *   annp_hip_replan_exchange   wraps the n owned positions into the periodic box in place; with world > 1 also sorts the atoms
+ *                              into stay / to-left / to-right (slab of `rank` of `world` along x; has_left / has_right: whether
+ *                              that neighbour exists) and packs rows [x y z | id | e0 (w0 columns) | e1 (w1 columns)] of the
+ *                              stayers into d_keep and of the leavers into d_send ([to-left | to-right]); counts3 = stay, left, right
+ *   annp_hip_replan_unpack     m such rows (stayers + received) -> d_x, d_ids, d_e0, d_e1
+ *   annp_hip_replan_faces      indices (int32, ascending) of the owned atoms with x < lo_edge (if has_left), then of those with
+ *                              x >= hi_edge (if has_right); counts2 = their numbers
+ *   annp_hip_replan_images     periodic images in the dimensions of dims_mask (bit d) of rows [0, np0) of d_x and of the images made
+ *                              so far: positions appended behind row np0, d_root[k] / d_shift[k][3] = the row < np0 image k stems
+ *                              from and its total shift (what annp_hip_halo_unpack_images wants).  ANNP_HIP_ENEIGHCAP with an
+ *                              estimate in *nimg_out when capacity_rows is too small: come back with more
+ *   annp_hip_replan_fold_plan  items k < m with targets d_targets[k] in [0, nkeys) grouped by target, k ascending:
+ *                              d_start[nkeys + 1], d_perm[m] for annp_hip_reverse_fold with d_seg_dst = NULL (segment s = row s) */
+int annp_hip_replan_exchange(annp_hip_handle *handle, int n, double *d_x, const long long *d_ids, const double *d_e0, int w0,
+                             const double *d_e1, int w1, const double *box6, const int *periodic3, int world, int rank,
+                             int has_left, int has_right, double *d_keep, double *d_send, int *counts3, void *stream);
+int annp_hip_replan_unpack(annp_hip_handle *handle, int m, const double *d_rows, int w0, int w1, double *d_x, long long *d_ids,
+                           double *d_e0, double *d_e1, void *stream);
+int annp_hip_replan_faces(annp_hip_handle *handle, int n, const double *d_x, double lo_edge, double hi_edge, int has_left, int has_right,
+                          int *d_idx, int *counts2, void *stream);
+int annp_hip_replan_images(annp_hip_handle *handle, int np0, double *d_x, long long capacity_rows, const double *box6, const int *periodic3,
+                           double rc_halo, int dims_mask, int *d_root, double *d_shift, int *nimg_out, void *stream);
+int annp_hip_replan_fold_plan(annp_hip_handle *handle, int m, const int *d_targets, int nkeys, int *d_start, int *d_perm, void *stream);
 int annp_hip_verlet_half(annp_hip_handle *handle, int n, double *d_x, double *d_v, const double *d_f, double dtf, double dt,
                          void *stream);
 

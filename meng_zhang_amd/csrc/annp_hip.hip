@@ -35,6 +35,7 @@
 #include "ni_kernels.hpp"
 #include "anna_kernels.hpp"
 #include "step_kernels.hpp"
+#include "replan_kernels.hpp"
 
 using namespace annp;
 
@@ -153,6 +154,10 @@ struct annp_hip_handle {
     DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ni_npair, ni_fix_nbr, ovf, ovf_desc, fe_nbrs;
     DevBuf<unsigned short> ni_pairs;    // Behler: in-range (j,k) pairs per atom, descriptor pass -> force pass
     DevBuf<long long> first;
+    // re-planning (replan_kernels.hpp): flags / scan positions / block sums of its stream compactions, their totals
+    DevBuf<int> rp_flag, rp_cnt;
+    DevBuf<long long> rp_pos, rp_bs;
+    long long *rp_tot = nullptr, *rp_tot_h = nullptr;
     double *d_vslots = nullptr;         // [ANNP_VSLOTS][8]: where the kernels tally the global virial (annp_common.hpp), folded per evaluation
     double *d_scalars = nullptr;        // [0] energy, [1..6] virial
     int *d_flags = nullptr;             // [0] capacity error: max n of the atoms that were skipped (stays set until the host has
@@ -856,6 +861,9 @@ void annp_hip_clear(annp_hip_handle *h)
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom); release(h, h->vatom);
     release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr); release(h, h->ni_npair); release(h, h->ni_fix_nbr); release(h, h->ni_pairs); release(h, h->ovf);
     release(h, h->mom); release(h, h->fe_nbrs); release(h, h->ovf_desc);
+    release(h, h->rp_flag); release(h, h->rp_cnt); release(h, h->rp_pos); release(h, h->rp_bs);
+    if (h->rp_tot) (void)hipFree(h->rp_tot);
+    if (h->rp_tot_h) (void)hipHostFree(h->rp_tot_h);
     release(h, h->first);
     neigh_release(h->nb);
     if (h->d_scalars) (void)hipFree(h->d_scalars);
@@ -1519,11 +1527,187 @@ int annp_hip_halo_unpack_images(annp_hip_handle *h, int nimg, const int *d_root,
 int annp_hip_reverse_fold(annp_hip_handle *h, int nseg, const int *d_seg_dst, const int *d_seg_start, const int *d_perm,
                           const double *d_src, double *d_f, void *stream)
 {
-    if (!h || nseg < 0 || (nseg > 0 && (!d_seg_dst || !d_seg_start || !d_perm || !d_src || !d_f)))
+    if (!h || nseg < 0 || (nseg > 0 && (!d_seg_start || !d_perm || !d_src || !d_f)))
         return h ? fail(h, ANNP_HIP_EARG, "reverse_fold: bad argument") : ANNP_HIP_EARG;
     if (nseg == 0) return 0;
     DEVICE_GUARD(h);
     hipLaunchKernelGGL(annp_segment_add, dim3((3 * nseg + 255) / 256), dim3(256), 0, (hipStream_t)stream, nseg, d_seg_dst, d_seg_start, d_perm, d_src, d_f);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+
+// ---- re-planning on the device (Comm::exchange + Comm::borders; replan_kernels.hpp) ------------------------------------
+namespace {
+int rp_scratch(annp_hip_handle *h, size_t nflags, size_t npos)
+{
+    int rc;
+    if ((rc = ensure(h, h->rp_flag, nflags)) || (rc = ensure(h, h->rp_pos, npos)) || (rc = ensure(h, h->rp_bs, npos / 1024 + 8))) return rc;
+    if (!h->rp_tot) {
+        HIP_TRY(h, hipMalloc((void **)&h->rp_tot, 8 * sizeof(long long)));
+        HIP_TRY(h, hipHostMalloc((void **)&h->rp_tot_h, 8 * sizeof(long long)));
+    }
+    return 0;
+}
+// exclusive scan of flags[0..n) into pos, the total into tot[slot]
+void rp_scan(annp_hip_handle *h, const int *flags, int n, long long *pos, long long *bs, int slot, hipStream_t s)
+{
+    const int nblk = std::max(1, (n + 1023) / 1024);
+    hipLaunchKernelGGL(annp_scan_block_sums, dim3(nblk), dim3(1024), 0, s, flags, n, bs);
+    hipLaunchKernelGGL(annp_scan_block_offsets, dim3(1), dim3(64), 0, s, bs, nblk, h->rp_tot + slot);
+    hipLaunchKernelGGL(annp_scan_finish, dim3(nblk), dim3(1024), 0, s, flags, n, bs, pos);
+}
+int rp_totals(annp_hip_handle *h, int count, hipStream_t s)
+{
+    HIP_TRY(h, hipMemcpyAsync(h->rp_tot_h, h->rp_tot, sizeof(long long) * count, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return 0;
+}
+ReplanBox rp_box(const double *box6, const int *periodic3)
+{
+    ReplanBox b;
+    for (int d = 0; d < 3; d++) { b.lo[d] = box6[d]; b.hi[d] = box6[3 + d]; b.periodic[d] = periodic3[d]; }
+    return b;
+}
+}  // namespace
+
+int annp_hip_replan_exchange(annp_hip_handle *h, int n, double *d_x, const long long *d_ids, const double *d_e0, int w0, const double *d_e1, int w1,
+                             const double *box6, const int *periodic3, int world, int rank, int has_left, int has_right,
+                             double *d_keep, double *d_send, int *counts3, void *stream)
+{
+    if (!h || n < 0 || !box6 || !periodic3 || world < 1 || w0 < 0 || w1 < 0 || (n > 0 && !d_x) || (world > 1 && (!d_ids || !d_keep || !d_send || !counts3)))
+        return h ? fail(h, ANNP_HIP_EARG, "replan_exchange: bad argument") : ANNP_HIP_EARG;
+    if (counts3) { counts3[0] = n; counts3[1] = counts3[2] = 0; }
+    if (n == 0) return 0;
+    DEVICE_GUARD(h);
+    hipStream_t s = (hipStream_t)stream;
+    const ReplanBox b = rp_box(box6, periodic3);
+    const int blocks = (n + 255) / 256;
+    if (world == 1) {        // nothing to send: the wrap alone
+        hipLaunchKernelGGL(annp_replan_wrap_classify, dim3(blocks), dim3(256), 0, s, n, d_x, b, 1, 0, 0, 0, (int *)nullptr, (int *)nullptr, (int *)nullptr, (int *)nullptr);
+        HIP_TRY(h, hipGetLastError());
+        return 0;
+    }
+    int rc;
+    if ((rc = rp_scratch(h, 3 * (size_t)n + 8, 3 * (size_t)n + 8))) return rc;
+    int *fs = h->rp_flag.p, *fl = fs + n, *fr = fl + n;
+    long long *ps = h->rp_pos.p, *pl = ps + n, *pr = pl + n;
+    HIP_TRY(h, hipMemsetAsync(h->rp_tot, 0, 8 * sizeof(long long), s));
+    int *bad = reinterpret_cast<int *>(h->rp_tot + 3);
+    hipLaunchKernelGGL(annp_replan_wrap_classify, dim3(blocks), dim3(256), 0, s, n, d_x, b, world, rank, has_left, has_right, fs, fl, fr, bad);
+    rp_scan(h, fs, n, ps, h->rp_bs.p, 0, s);
+    rp_scan(h, fl, n, pl, h->rp_bs.p, 1, s);
+    rp_scan(h, fr, n, pr, h->rp_bs.p, 2, s);
+    HIP_TRY(h, hipGetLastError());
+    if ((rc = rp_totals(h, 4, s))) return rc;
+    const long long ns = h->rp_tot_h[0], nl = h->rp_tot_h[1], nr = h->rp_tot_h[2];
+    if ((h->rp_tot_h[3] & 0xffffffffll) != 0 || ns + nl + nr != n)
+        return fail(h, ANNP_HIP_EARG, "replan_exchange: an atom moved further than the neighbouring slab between two rebuilds");
+    counts3[0] = (int)ns; counts3[1] = (int)nl; counts3[2] = (int)nr;
+    hipLaunchKernelGGL(annp_replan_pack, dim3(blocks), dim3(256), 0, s, n, fs, ps, 0ll, d_x, d_ids, d_e0, w0, d_e1, w1, d_keep);
+    hipLaunchKernelGGL(annp_replan_pack, dim3(blocks), dim3(256), 0, s, n, fl, pl, 0ll, d_x, d_ids, d_e0, w0, d_e1, w1, d_send);
+    hipLaunchKernelGGL(annp_replan_pack, dim3(blocks), dim3(256), 0, s, n, fr, pr, nl, d_x, d_ids, d_e0, w0, d_e1, w1, d_send);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int annp_hip_replan_unpack(annp_hip_handle *h, int m, const double *d_rows, int w0, int w1, double *d_x, long long *d_ids, double *d_e0, double *d_e1, void *stream)
+{
+    if (!h || m < 0 || w0 < 0 || w1 < 0 || (m > 0 && (!d_rows || !d_x || !d_ids || (w0 > 0 && !d_e0) || (w1 > 0 && !d_e1))))
+        return h ? fail(h, ANNP_HIP_EARG, "replan_unpack: bad argument") : ANNP_HIP_EARG;
+    if (m == 0) return 0;
+    DEVICE_GUARD(h);
+    hipLaunchKernelGGL(annp_replan_unpack, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, m, w0, w1, d_rows, d_x, d_ids, d_e0, d_e1);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int annp_hip_replan_faces(annp_hip_handle *h, int n, const double *d_x, double lo_edge, double hi_edge, int has_left, int has_right,
+                          int *d_idx, int *counts2, void *stream)
+{
+    if (!h || n < 0 || !counts2 || (n > 0 && (!d_x || !d_idx))) return h ? fail(h, ANNP_HIP_EARG, "replan_faces: bad argument") : ANNP_HIP_EARG;
+    counts2[0] = counts2[1] = 0;
+    if (n == 0 || (!has_left && !has_right)) return 0;
+    DEVICE_GUARD(h);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = rp_scratch(h, 2 * (size_t)n + 8, 2 * (size_t)n + 8))) return rc;
+    int *fl = h->rp_flag.p, *fr = fl + n;
+    long long *pl = h->rp_pos.p, *pr = pl + n;
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(annp_replan_face_flags, dim3(blocks), dim3(256), 0, s, n, d_x, lo_edge, hi_edge, has_left, has_right, fl, fr);
+    rp_scan(h, fl, n, pl, h->rp_bs.p, 0, s);
+    rp_scan(h, fr, n, pr, h->rp_bs.p, 1, s);
+    HIP_TRY(h, hipGetLastError());
+    if ((rc = rp_totals(h, 2, s))) return rc;
+    const long long nl = h->rp_tot_h[0], nr = h->rp_tot_h[1];
+    counts2[0] = (int)nl; counts2[1] = (int)nr;
+    hipLaunchKernelGGL(annp_replan_scatter_idx, dim3(blocks), dim3(256), 0, s, n, fl, pl, 0ll, d_idx);
+    hipLaunchKernelGGL(annp_replan_scatter_idx, dim3(blocks), dim3(256), 0, s, n, fr, pr, nl, d_idx);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int annp_hip_replan_images(annp_hip_handle *h, int np0, double *d_x, long long capacity_rows, const double *box6, const int *periodic3, double rc_halo,
+                           int dims_mask, int *d_root, double *d_shift, int *nimg_out, void *stream)
+{
+    if (!h || np0 < 0 || !box6 || !periodic3 || !nimg_out || capacity_rows < np0 || (np0 > 0 && !d_x))
+        return h ? fail(h, ANNP_HIP_EARG, "replan_images: bad argument") : ANNP_HIP_EARG;
+    *nimg_out = 0;
+    if (np0 == 0) return 0;
+    DEVICE_GUARD(h);
+    hipStream_t s = (hipStream_t)stream;
+    long long cur = np0;
+    for (int d = 0; d < 3; d++) {
+        if (!((dims_mask >> d) & 1) || !periodic3[d]) continue;
+        int rc;
+        if (cur > 0x7fffffffll / 3) return fail(h, ANNP_HIP_EARG, "replan_images: too many rows");
+        if ((rc = rp_scratch(h, 2 * (size_t)cur + 8, 2 * (size_t)cur + 8))) return rc;
+        int *flo = h->rp_flag.p, *fhi = flo + cur;
+        long long *plo = h->rp_pos.p, *phi = plo + cur;
+        const int blocks = (int)((cur + 255) / 256);
+        hipLaunchKernelGGL(annp_replan_image_flags, dim3(blocks), dim3(256), 0, s, (int)cur, d_x, d, box6[d] + rc_halo, box6[3 + d] - rc_halo, flo, fhi);
+        rp_scan(h, flo, (int)cur, plo, h->rp_bs.p, 0, s);
+        rp_scan(h, fhi, (int)cur, phi, h->rp_bs.p, 1, s);
+        HIP_TRY(h, hipGetLastError());
+        if ((rc = rp_totals(h, 2, s))) return rc;
+        const long long add = h->rp_tot_h[0] + h->rp_tot_h[1];
+        if (cur + add > capacity_rows || !d_root || !d_shift) {
+            // not enough room (or a sizing call): count the remaining dimensions as if every row so far had images on both sides is
+            // not knowable without making them, so the caller is told what this dimension needs and asked to come back with more
+            *nimg_out = (int)std::min<long long>(0x7fffffffll, (cur + add - np0) * ((d == 0) ? 9 : (d == 1 ? 3 : 1)));
+            return ANNP_HIP_ENEIGHCAP;
+        }
+        if (add > 0) {
+            hipLaunchKernelGGL(annp_replan_image_make, dim3(blocks), dim3(256), 0, s, (int)cur, np0, d, box6[3 + d] - box6[d], flo, plo, fhi, phi,
+                               h->rp_tot + 0, d_x, d_root, d_shift);
+            HIP_TRY(h, hipGetLastError());
+        }
+        cur += add;
+    }
+    *nimg_out = (int)(cur - np0);
+    return 0;
+}
+
+int annp_hip_replan_fold_plan(annp_hip_handle *h, int m, const int *d_targets, int nkeys, int *d_start, int *d_perm, void *stream)
+{
+    if (!h || m < 0 || nkeys < 0 || (nkeys > 0 && !d_start) || (m > 0 && (!d_targets || !d_perm)))
+        return h ? fail(h, ANNP_HIP_EARG, "replan_fold_plan: bad argument") : ANNP_HIP_EARG;
+    if (nkeys == 0) return 0;
+    DEVICE_GUARD(h);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = ensure(h, h->rp_cnt, 2 * (size_t)nkeys + 8)) || (rc = rp_scratch(h, 8, (size_t)nkeys + 8))) return rc;
+    int *cnt = h->rp_cnt.p, *cursor = cnt + nkeys + 4;
+    HIP_TRY(h, hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)nkeys, s));
+    if (m > 0) hipLaunchKernelGGL(annp_replan_count, dim3((m + 255) / 256), dim3(256), 0, s, m, d_targets, cnt);
+    rp_scan(h, cnt, nkeys, h->rp_pos.p, h->rp_bs.p, 0, s);
+    HIP_TRY(h, hipMemcpyAsync(h->rp_pos.p + nkeys, h->rp_tot, sizeof(long long), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(annp_replan_start32, dim3((nkeys + 256) / 256), dim3(256), 0, s, nkeys, h->rp_pos.p, d_start, cursor);
+    if (m > 0) {
+        hipLaunchKernelGGL(annp_replan_fill, dim3((m + 255) / 256), dim3(256), 0, s, m, d_targets, cursor, d_perm);
+        hipLaunchKernelGGL(annp_replan_sort_segments, dim3((nkeys + 255) / 256), dim3(256), 0, s, nkeys, d_start, d_perm);
+    }
     HIP_TRY(h, hipGetLastError());
     return 0;
 }

@@ -47,9 +47,12 @@ __global__ __launch_bounds__(256) void annp_segment_add(int nseg, const int *__r
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= 3 * nseg) return;
     const int s = t / 3, c = t - 3 * s;
-    double acc = f[3 * (size_t)dst[s] + c];
-    for (int k = start[s]; k < start[s + 1]; k++) acc += src[3 * (size_t)perm[k] + c];
-    f[3 * (size_t)dst[s] + c] = acc;
+    const int k0 = start[s], k1 = start[s + 1];
+    if (k0 == k1) return;                        // (dst == nullptr: segment s belongs to row s, most of them empty)
+    const size_t row = dst ? (size_t)dst[s] : (size_t)s;
+    double acc = f[3 * row + c];
+    for (int k = k0; k < k1; k++) acc += src[3 * (size_t)perm[k] + c];
+    f[3 * row + c] = acc;
 }
 
 // velocity-Verlet half step: v += dtf f; then x += dt v when dt != 0 (FixNVE::initial_integrate), v only otherwise

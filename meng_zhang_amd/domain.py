@@ -369,8 +369,10 @@ class SlabDomain:
         t = self.torch
         self.send_idx32 = self.send_idx.to(t.int32).contiguous()
         self.img_root32 = self.img_root.to(t.int32).contiguous()
-        self._img_seg = self._segments(self.img_root)
-        self._back_seg = self._segments(self.send_idx)
+        d, st, pm = self._segments(self.img_root)
+        self._img_seg = (int(d.numel()), d, st, pm)
+        d, st, pm = self._segments(self.send_idx)
+        self._back_seg = (int(d.numel()), d, st, pm)
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
@@ -380,11 +382,163 @@ class SlabDomain:
             lib, h = self.hip
             raise RuntimeError("%s failed (%d): %s" % (what, rc, lib.annp_hip_last_error(h).decode()))
 
-    def replan(self):
-        """Comm::exchange + Comm::borders: call whenever the neighbour list is rebuilt."""
-        self._exchange()
-        self._borders()
+    def replan(self, eng=None):
+        """Comm::exchange + Comm::borders: call whenever the neighbour list is rebuilt; f comes back zeroed, and so does the energy
+        word `eng` when given (Verlet::force_clear of the reneighbouring step).  With the library at hand (hip=(lib, handle),
+        atoms on the GPU) both run as its kernels (annp_hip_replan_*: stable stream compactions, the same arrays as the torch
+        restatement below bit for bit); the wire and the exchange of message sizes stay here."""
+        if self.hip is not None and self.device.type == "cuda" and len(self.extra) <= 2:
+            self._exchange_hip()
+            self._borders_hip(eng)
+        else:
+            self._exchange()
+            self._borders()
+            if eng is not None:
+                eng.zero_()
         self.n_replans += 1
+
+    # ------------------------------------------------------------------ the same two jobs as library kernels
+    def _box_args(self):
+        import ctypes as C
+        return (C.c_double * 6)(*[float(v) for v in self.box]), (C.c_int * 3)(*[1 if q else 0 for q in self.periodic])
+
+    def _exchange_hip(self):
+        import ctypes as C
+        t = self.torch
+        lib, h = self.hip
+        n = self.nlocal
+        keys = sorted(self.extra)
+        ex = [self.extra[k] for k in keys] + [None, None]
+        w = [int(e.shape[1]) if e is not None else 0 for e in ex[:2]]
+        box6, per3 = self._box_args()
+        self.migrated_last = 0
+        ptr = lambda a: a.data_ptr() if a is not None else None
+        if self.world == 1:
+            self._hip_check(lib.annp_hip_replan_exchange(h, n, self.x.data_ptr(), None, None, 0, None, 0, box6, per3, 1, 0, 0, 0, None, None, None,
+                                                         self._stream()), "replan_exchange")
+            return
+        width = 4 + w[0] + w[1]
+        cap = n + max(1024, n // 8)
+        keep = t.empty((cap, width), dtype=t.float64, device=self.device)
+        send = t.empty((max(n, 1), width), dtype=t.float64, device=self.device)
+        counts = (C.c_int * 3)()
+        self._hip_check(lib.annp_hip_replan_exchange(h, n, self.x.data_ptr(), self.ids.data_ptr(), ptr(ex[0]), w[0], ptr(ex[1]), w[1], box6, per3,
+                                                     self.world, self.rank, int(self.left is not None), int(self.right is not None),
+                                                     keep.data_ptr(), send.data_ptr(), counts, self._stream()), "replan_exchange")
+        ns, n_l, n_r = int(counts[0]), int(counts[1]), int(counts[2])
+        m_r, m_l = self._peer_counts(n_l, n_r)
+        m = ns + m_r + m_l
+        if m > cap:
+            big = t.empty((m, width), dtype=t.float64, device=self.device)
+            big[:ns] = keep[:ns]
+            keep = big
+        self.tp.route(self._route(send, n_l, n_r, keep[ns:m], m_r, m_l))
+        self.migrated_last = n_l + n_r
+        self.nlocal = m
+        self._xcap = m + max(4096, m // 2)
+        xb = t.empty((self._xcap, 3), dtype=t.float64, device=self.device)
+        self.ids = t.empty(m, dtype=t.int64, device=self.device)
+        new_ex = [t.empty((m, wk), dtype=t.float64, device=self.device) if wk else None for wk in w]
+        self._hip_check(lib.annp_hip_replan_unpack(h, m, keep.data_ptr(), w[0], w[1], xb.data_ptr(), self.ids.data_ptr(), ptr(new_ex[0]), ptr(new_ex[1]),
+                                                   self._stream()), "replan_unpack")
+        for k, e in zip(keys, new_ex):
+            self.extra[k] = e
+        self._xbuf = xb
+        self.x = xb[:m]
+
+    def _borders_hip(self, eng=None):
+        import ctypes as C
+        t = self.torch
+        lib, h = self.hip
+        dev = self.device
+        n = self.nlocal
+        L = self.box[3:] - self.box[:3]
+        box6, per3 = self._box_args()
+        i32 = dict(dtype=t.int32, device=dev)
+        f64 = dict(dtype=t.float64, device=dev)
+        # the position buffer has room behind the owned atoms for the ghosts: [owned | wire ghosts | images]
+        xb = getattr(self, "_xbuf", None)
+        if xb is None or xb.data_ptr() != self.x.data_ptr() or xb.shape[0] < n:
+            self._xcap = n + max(4096, n // 2)
+            xb = t.empty((self._xcap, 3), **f64)
+            xb[:n] = self.x[:n]
+            self._xbuf = xb
+        # (1) across the slab faces
+        n_l = n_r = m_r = m_l = 0
+        if self.wired:
+            idx = t.empty(2 * max(n, 1), **i32)
+            c2 = (C.c_int * 2)()
+            self._hip_check(lib.annp_hip_replan_faces(h, n, xb.data_ptr(), float(self.lo + self.rc), float(self.hi - self.rc), int(self.left is not None),
+                                                      int(self.right is not None), idx.data_ptr(), c2, self._stream()), "replan_faces")
+            n_l, n_r = int(c2[0]), int(c2[1])
+            m_r, m_l = self._peer_counts(n_l, n_r)
+            self.send_idx32 = idx[: n_l + n_r]
+            sh = t.zeros((n_l + n_r, 3), **f64)
+            if self.rank == 0:                       # my left neighbour sits at the far end of the box
+                sh[:n_l, 0] = L[0]
+            if self.rank == self.world - 1:
+                sh[n_l:, 0] = -L[0]
+            self.send_shift = sh
+        else:
+            self.send_idx32 = t.empty(0, **i32)
+            self.send_shift = t.empty((0, 3), **f64)
+        self.send_idx = None                         # (the torch path's int64 copy: not needed here)
+        self.n_l, self.n_r, self.m_r, self.m_l = n_l, n_r, m_r, m_l
+        nxg = m_r + m_l
+        np0 = n + nxg
+        need = np0 + max(getattr(self, "nimg", 0) * 9 // 8, 1024)
+        if xb.shape[0] < need:
+            nb_ = t.empty((need + need // 4, 3), **f64)
+            nb_[:n] = xb[:n]
+            xb = self._xbuf = nb_
+        self.sendbuf = t.empty((n_l + n_r, 3), **f64)
+        if self.wired:
+            if n_l + n_r:
+                self._hip_check(lib.annp_hip_halo_pack(h, n_l + n_r, self.send_idx32.data_ptr(), self.send_shift.data_ptr(), xb.data_ptr(),
+                                                       self.sendbuf.data_ptr(), self._stream()), "halo_pack")
+            self.tp.route(self._route(self.sendbuf, n_l, n_r, xb[n:np0], m_r, m_l))
+        # (2) periodic images of everything held so far (y and z; x too when nothing travels over the wire)
+        dims_mask = 0b110 if self.wired else 0b111
+        nimg = C.c_int(0)
+        while True:
+            cap = int(xb.shape[0])
+            root = t.empty(max(cap - np0, 1), **i32)
+            shift = t.empty((max(cap - np0, 1), 3), **f64)
+            rc = lib.annp_hip_replan_images(h, np0, xb.data_ptr(), cap, box6, per3, float(self.rc), dims_mask, root.data_ptr(), shift.data_ptr(),
+                                            C.byref(nimg), self._stream())
+            if rc != -7:
+                self._hip_check(rc, "replan_images")
+                break
+            nb_ = t.empty((np0 + int(nimg.value) + 4096, 3), **f64)      # not enough room: come back with more (rows < np0 are intact)
+            nb_[:np0] = xb[:np0]
+            xb = self._xbuf = nb_
+        self.nxg, self.nimg = nxg, int(nimg.value)
+        self.img_root32 = root[: self.nimg]
+        self.img_shift = shift[: self.nimg]
+        self.img_root = None
+        self.nghost = nxg + self.nimg
+        self.nall = n + self.nghost
+        self.x = xb[: self.nall]
+        if getattr(self, "_fbuf", None) is None or self._fbuf.shape[0] < self.nall:
+            self._fbuf = t.empty((int(xb.shape[0]), 3), **f64)
+        self.f = self._fbuf[: self.nall]
+        self._hip_check(lib.annp_hip_halo_unpack_images(h, 0, None, None, None, 0, self.f.data_ptr(), 3 * self.nall,
+                                                        eng.data_ptr() if eng is not None else None, self._stream()), "force clear")
+        self.backbuf = t.empty((n_l + n_r, 3), **f64)
+        self.x_plan = t.empty((n, 3), **f64)
+        self.x_plan.copy_(self.x[:n])
+        self._fwd = self._route(self.sendbuf, n_l, n_r, self.x[n:np0], m_r, m_l)
+        self._rev = self._route_back(self.f[n:np0], m_r, m_l, self.backbuf, n_l, n_r)
+        self.bytes_per_exchange = (n_l + n_r) * 24
+        # the plans of the two folds: image forces onto their roots, returned rows onto the boundary atoms
+        st_i, pm_i = t.empty(np0 + 1, **i32), t.empty(max(self.nimg, 1), **i32)
+        self._hip_check(lib.annp_hip_replan_fold_plan(h, self.nimg, self.img_root32.data_ptr() if self.nimg else None, np0, st_i.data_ptr(),
+                                                      pm_i.data_ptr(), self._stream()), "replan_fold_plan")
+        self._img_seg = (np0, None, st_i, pm_i)
+        st_b, pm_b = t.empty(n + 1, **i32), t.empty(max(n_l + n_r, 1), **i32)
+        self._hip_check(lib.annp_hip_replan_fold_plan(h, n_l + n_r, self.send_idx32.data_ptr() if n_l + n_r else None, n, st_b.data_ptr(),
+                                                      pm_b.data_ptr(), self._stream()), "replan_fold_plan")
+        self._back_seg = (n, None, st_b, pm_b)
 
     # ------------------------------------------------------------------ per step
     def forward(self, clear_forces=False, eng=None):
@@ -425,13 +579,13 @@ class SlabDomain:
         if self.hip is not None:
             lib, h = self.hip
             if self.nimg:       # images first: their roots may be wire ghosts, whose total then travels
-                dst, start, perm = self._img_seg
-                self._hip_check(lib.annp_hip_reverse_fold(h, int(dst.numel()), dst.data_ptr(), start.data_ptr(), perm.data_ptr(),
+                nseg, dst, start, perm = self._img_seg
+                self._hip_check(lib.annp_hip_reverse_fold(h, nseg, dst.data_ptr() if dst is not None else None, start.data_ptr(), perm.data_ptr(),
                                                           self.f.data_ptr() + 24 * np0, self.f.data_ptr(), self._stream()), "reverse_fold")
             if self._rev:
                 self.tp.route(self._rev)
-                dst, start, perm = self._back_seg
-                self._hip_check(lib.annp_hip_reverse_fold(h, int(dst.numel()), dst.data_ptr(), start.data_ptr(), perm.data_ptr(),
+                nseg, dst, start, perm = self._back_seg
+                self._hip_check(lib.annp_hip_reverse_fold(h, nseg, dst.data_ptr() if dst is not None else None, start.data_ptr(), perm.data_ptr(),
                                                           self.backbuf.data_ptr(), self.f.data_ptr(), self._stream()), "reverse_fold")
             return
         if self.nimg:

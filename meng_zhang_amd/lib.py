@@ -11,6 +11,7 @@ ABI_SYMBOLS = [
     "annp_hip_neigh_build_device", "annp_hip_list_cutoff", "annp_hip_list_layout", "annp_hip_neigh_to_host", "annp_hip_sync", "annp_hip_eval_info", "annp_hip_eval_path", "annp_hip_set_notice", "annp_hip_set_timing", "annp_hip_last_timing",
     "annp_hip_timing_stats", "annp_hip_last_counts", "annp_hip_last_descriptors",
     "annp_hip_comm_unique_id", "annp_hip_comm_init", "annp_hip_comm_route", "annp_hip_comm_destroy",
+    "annp_hip_replan_exchange", "annp_hip_replan_unpack", "annp_hip_replan_faces", "annp_hip_replan_images", "annp_hip_replan_fold_plan",
     "annp_hip_halo_pack", "annp_hip_halo_unpack_images", "annp_hip_reverse_fold", "annp_hip_verlet_half",
     "annp_hip_clear", "annp_hip_bytes", "annp_hip_last_error", "annp_hip_abi_version", "annp_hip_device_count",
 ]
@@ -57,6 +58,11 @@ def load_library():
     lib.annp_hip_halo_pack.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     lib.annp_hip_halo_unpack_images.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_longlong, vp, vp]
     lib.annp_hip_reverse_fold.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.annp_hip_replan_exchange.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, dp, ip, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, ip, vp]
+    lib.annp_hip_replan_unpack.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    lib.annp_hip_replan_faces.argtypes = [vp, C.c_int, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, ip, vp]
+    lib.annp_hip_replan_images.argtypes = [vp, C.c_int, vp, C.c_longlong, dp, ip, C.c_double, C.c_int, vp, vp, ip, vp]
+    lib.annp_hip_replan_fold_plan.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
     lib.annp_hip_verlet_half.argtypes = [vp, C.c_int, vp, vp, vp, C.c_double, C.c_double, vp]
     lib.annp_hip_list_layout.argtypes = [vp, ip]
     lib.annp_hip_list_cutoff.argtypes = [vp, C.c_double]

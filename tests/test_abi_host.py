@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported(lib):
         assert getattr(lib, name) is not None, name
     from meng_zhang_amd.lib import ABI_SYMBOLS
     assert sorted(ABI_SYMBOLS) == declared
-    assert lib.annp_hip_abi_version() == 6      # 6: annp_hip_eval_path, annp_hip_set_notice
+    assert lib.annp_hip_abi_version() == 7      # 7: annp_hip_replan_*
 
 
 def test_pair_symbols_exported(lib):

@@ -19,7 +19,7 @@ for step in "$@"; do
               ANNP_FORCE_DIST=1 ANNP_BENCH_WIRE_SELF=1 ANNP_BENCH_WIRE=lib timeout -k 10 300 python bench.py --cells 40 --steps 10 --secondary 0 --cpu-sample 0 > $out/selfwire_lib.json 2> $out/selfwire_lib.err || { tail -20 $out/selfwire_lib.err; exit 1; }; cat $out/selfwire_lib.json
               timeout -k 10 300 python bench.py --cells 40 --steps 10 --secondary 0 --cpu-sample 0 > $out/selfwire_ref.json 2> $out/selfwire_ref.err || { tail -20 $out/selfwire_ref.err; exit 1; }; cat $out/selfwire_ref.json ;;
     trace128k) cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-              timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t128k -o t -- python3 bench.py --cells 40 --steps 20 --warmup 5 --cpu-sample 0 --rebuild-every 0 --secondary 0 > $out/b128k.json 2> $out/b128k.err || exit 1
+              timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t128k -o t -- python3 bench.py --cells 40 --steps 20 --warmup 5 --cpu-sample 0 --rebuild-every 10 --secondary 0 > $out/b128k.json 2> $out/b128k.err || exit 1
               ANNP_BENCH_TORCH_STEP=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t128k_torch -o t -- python3 bench.py --cells 40 --steps 20 --warmup 5 --cpu-sample 0 --rebuild-every 0 --secondary 0 > $out/b128k_torch.json 2> $out/b128k_torch.err || exit 1 ;;
     rehearse) for n in 2 4; do ANNP_BENCH_SHARE_GPU=1 ANNP_BENCH_BACKEND=gloo timeout -k 10 400 python bench.py --gpus $n --cells 40 --steps 10 --warmup 2 --cpu-sample 0 --secondary 0 > $out/share$n.json 2> $out/share$n.err || { tail -20 $out/share$n.err; exit 1; }; done
               timeout -k 10 300 python bench.py --cells 40 --steps 10 --warmup 2 --cpu-sample 0 --secondary 0 > $out/share1.json 2> $out/share1.err || exit 1 ;;

@@ -57,10 +57,14 @@ def main():
     build()
     evaluate()
     print("atoms %d ghosts %d" % (dom.nlocal, dom.nghost))
-    for name, fn in (("replan (exchange + borders)", dom.replan), ("  of which exchange", dom._exchange), ("list build", build), ("evaluation", evaluate),
+    for name, fn in (("replan (exchange + borders)", dom.replan), ("list build", build), ("evaluation", evaluate),
                      ("forward + reverse", lambda: (dom.forward(clear_forces=True, eng=eng), dom.reverse()))):
         lo, med = timed(fn)
         print("%-30s min %7.3f  median %7.3f ms" % (name, lo, med))
+    # the torch restatement of the same re-planning, for comparison (the library's kernels are the default on the GPU)
+    dom2 = SlabDomain.from_global(xg, box, (1, 1, 1), 8.5, dev, extra={"v": np.zeros_like(xg)}, hip=None)
+    lo, med = timed(dom2.replan)
+    print("%-30s min %7.3f  median %7.3f ms" % ("replan as torch ops", lo, med))
     pair.close()
 
 
