@@ -132,14 +132,15 @@ __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
     };
     auto table_flush = [&]() {
         wave_lds_sync();
-        for (int sl = lane; sl < ANNA_TSLOTS; sl += 64) {
+        // (the three components of an atom leave from three neighbouring lanes of one instruction: one memory-side request per
+        // line instead of three, fe_shf_kernels.hpp)
+        for (int k = lane; k < 3 * ANNA_TSLOTS; k += 64) {
+            const int sl = k / 3, c = k - 3 * sl;
             const int j = Tkey[sl];
-            if (j >= 0) {
-                atomicAdd(&p.f[3 * (size_t)j], Tacc[3 * sl]); atomicAdd(&p.f[3 * (size_t)j + 1], Tacc[3 * sl + 1]);
-                atomicAdd(&p.f[3 * (size_t)j + 2], Tacc[3 * sl + 2]);
-                Tkey[sl] = -1; Tacc[3 * sl] = 0.0; Tacc[3 * sl + 1] = 0.0; Tacc[3 * sl + 2] = 0.0;
-            }
+            if (j >= 0) { atomicAdd(&p.f[3 * (size_t)j + c], Tacc[k]); Tacc[k] = 0.0; }
         }
+        wave_lds_sync();
+        for (int sl = lane; sl < ANNA_TSLOTS; sl += 64) Tkey[sl] = -1;
         wave_lds_sync();
     };
     // a wave walks over many atoms and adds its energies once at the end: one atomic per atom on the single

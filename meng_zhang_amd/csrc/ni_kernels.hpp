@@ -1098,14 +1098,14 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     }
     wave_lds_sync();            // the next group of the run reuses the records
     }
-    // flush the run's table: one global atomic per distinct atom and component
+    // flush the run's table: one global atomic per distinct atom and component, the three components of an atom from three
+    // neighbouring lanes of one instruction -- float atomics are executed at the memory side, one request per 64-byte line an
+    // instruction touches, and a lane per atom issuing x, then y, then z made three requests of what is one (or two) lines
     wave_lds_sync();
-    for (int sl = lane; sl < NI_TSLOTS; sl += 64) {
+    for (int k = lane; k < 3 * NI_TSLOTS; k += 64) {
+        const int sl = k / 3, c = k - 3 * sl;
         const int j = L.tkey[sl];
-        if (j >= 0) {
-            atomicAdd(&p.f[3 * (size_t)j], L.tacc[3 * sl]); atomicAdd(&p.f[3 * (size_t)j + 1], L.tacc[3 * sl + 1]);
-            atomicAdd(&p.f[3 * (size_t)j + 2], L.tacc[3 * sl + 2]);
-        }
+        if (j >= 0) atomicAdd(&p.f[3 * (size_t)j + c], L.tacc[k]);
     }
 }
 
