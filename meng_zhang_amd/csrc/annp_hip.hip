@@ -1554,7 +1554,7 @@ void rp_scan(annp_hip_handle *h, const int *flags, int n, long long *pos, long l
 {
     const int nblk = std::max(1, (n + 1023) / 1024);
     hipLaunchKernelGGL(annp_scan_block_sums, dim3(nblk), dim3(1024), 0, s, flags, n, bs);
-    hipLaunchKernelGGL(annp_scan_block_offsets, dim3(1), dim3(64), 0, s, bs, nblk, h->rp_tot + slot);
+    hipLaunchKernelGGL(annp_scan_block_offsets, dim3(1), dim3(1024), 0, s, bs, nblk, h->rp_tot + slot);
     hipLaunchKernelGGL(annp_scan_finish, dim3(nblk), dim3(1024), 0, s, flags, n, bs, pos);
 }
 int rp_totals(annp_hip_handle *h, int count, hipStream_t s)

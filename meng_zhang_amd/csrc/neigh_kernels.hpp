@@ -287,13 +287,29 @@ __global__ __launch_bounds__(1024) void annp_scan_block_sums(const int *v, int n
     __syncthreads();
     if (threadIdx.x == 0) { long long t = 0; for (int w = 0; w < 16; w++) t += sh[w]; bs[blockIdx.x] = t; }
 }
-__global__ void annp_scan_block_offsets(long long *bs, int nblocks, long long *total)
+// exclusive scan of the block sums in place, the grand total to *total.  One workgroup of 1024 threads (launch it as <<<1, 1024>>>;
+// any smaller workgroup works too): a thread sums a contiguous chunk, the chunk sums are scanned through LDS, the chunk is
+// rewritten.  (Rounds 1-3 did this with one thread: 0.1 us per block sum, 120 us for the 1 221 block sums of a 1.25 M-row scan --
+// most of a re-planning's device time once that was kernels, and a fifteenth of the list build.)
+__global__ __launch_bounds__(1024) void annp_scan_block_offsets(long long *bs, int nblocks, long long *total)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        long long run = 0;
-        for (int k = 0; k < nblocks; k++) { const long long t = bs[k]; bs[k] = run; run += t; }
-        *total = run;
+    __shared__ long long sh[1024];
+    const int nt = blockDim.x, t = threadIdx.x;
+    const int chunk = (nblocks + nt - 1) / nt;
+    const int a = min(nblocks, t * chunk), b = min(nblocks, a + chunk);
+    long long sum = 0;
+    for (int k = a; k < b; k++) sum += bs[k];
+    sh[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {        // Hillis-Steele inclusive scan of the chunk sums
+        const long long v = (t >= off) ? sh[t - off] : 0;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
     }
+    long long run = sh[t] - sum;
+    for (int k = a; k < b; k++) { const long long v = bs[k]; bs[k] = run; run += v; }
+    if (t == nt - 1) *total = sh[t];
 }
 __global__ __launch_bounds__(1024) void annp_scan_finish(const int *v, int n, const long long *bs, long long *first)
 {
@@ -414,7 +430,7 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     long long *dtot = reinterpret_cast<long long *>(nb.dmax) + 1;
     NB_TRY(hipMemsetAsync(nb.dmax, 0, 4 * sizeof(long long), s));
     hipLaunchKernelGGL(annp_scan_block_sums, dim3(nblk), dim3(1024), 0, s, nb.numneigh, nlocal, nb.blocksum);
-    hipLaunchKernelGGL(annp_scan_block_offsets, dim3(1), dim3(64), 0, s, nb.blocksum, nblk, dtot);
+    hipLaunchKernelGGL(annp_scan_block_offsets, dim3(1), dim3(1024), 0, s, nb.blocksum, nblk, dtot);
     hipLaunchKernelGGL(annp_scan_finish, dim3(nblk), dim3(1024), 0, s, nb.numneigh, nlocal, nb.blocksum, nb.first);
     hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(nlocal)), dim3(256), 0, s, nb.numneigh, nlocal, nb.dmax);
     long long hres[2];

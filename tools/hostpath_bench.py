@@ -41,16 +41,18 @@ def main():
     # device-built list (annp_hip_compute_n): only x and f cross PCIe
     p.ago = 0
     p.compute_n(cutneigh=8.5, eflag=1, vflag=0, eflag_atom=False)
-    for label, k, rebuild in (("compute_n ago=0", 3, True), ("compute_n ago>0", 5, False)):
-        dt = 0.0
+    for label, k, rebuild in (("compute_n ago=0", 8, True), ("compute_n ago>0", 8, False)):
+        dt, each = 0.0, []
         for _ in range(k):
             p.atom.f[:] = 0.0
             if rebuild:
                 p.ago = 0
             t = time.perf_counter()
             e = p.compute_n(cutneigh=8.5, eflag=1, vflag=0, eflag_atom=False)
-            dt += (time.perf_counter() - t) / k
-        print("%-20s %.1f ms per call -> %.2f M atom-steps/s   E/atom %.6f" % (label, dt * 1e3, s.nlocal / dt / 1e6, e / s.nlocal))
+            each.append((time.perf_counter() - t) * 1e3)
+            dt += each[-1] * 1e-3 / k
+        print("%-20s %.1f ms per call -> %.2f M atom-steps/s   E/atom %.6f   (calls: %s)" % (
+            label, dt * 1e3, s.nlocal / dt / 1e6, e / s.nlocal, " ".join("%.1f" % v for v in each)))
     # what an NPT step asks for (global virial) and what a step with per-atom energies asks for
     for label, kw in (("compute_n ago>0 vflag", dict(vflag=1, eflag_atom=False)), ("compute_n ago>0 eatom", dict(vflag=0, eflag_atom=True))):
         dt = 0.0
