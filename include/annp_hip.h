@@ -278,7 +278,11 @@ int annp_hip_eval_info(annp_hip_handle *handle, int *info4);
  *      the maximum falls under 128 again)
  *   2  Chebyshev passes pair by pair because ANNP_HIP_FE_DESC / ANNP_HIP_FE_FORCE ask for it (developer A/B switches)
  *   3  Behler G2/G4 kernels      4  pair_style anna_adp kernels
- * The change 0 -> 1 is also announced once on the stream given to annp_hip_set_notice (annp_gpu_init passes LAMMPS' screen). */
+ * The change 0 -> 1 is also announced once on the stream given to annp_hip_set_notice (annp_gpu_init passes LAMMPS' screen).
+ * So is one more thing a caller would otherwise only see in its timings: atoms in no spatial order.  The force pass collects
+ * forces in a table whose buckets hold eight atoms with consecutive indices; a caller that sorts its atoms in space (LAMMPS:
+ * atom_modify sort, the default) needs ~18 memory requests per atom for them, atoms in random order 113 and up to 2.3 times
+ * the time of that pass (results are the same).  The notice appears when more than eight contributions per atom found no bucket. */
 int annp_hip_eval_path(annp_hip_handle *handle);
 /* `file` is a FILE * (or NULL: silent, the default).  One line per event, prefixed "annp/hip:". */
 int annp_hip_set_notice(annp_hip_handle *handle, void *file);

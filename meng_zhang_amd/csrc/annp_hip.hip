@@ -103,6 +103,8 @@ class CopyPool {
     bool stop_ = false;
 };
 
+constexpr int ANNP_NFLAGS = 8;          // device flag words of an evaluation (annp_hip_handle::d_flags)
+
 struct annp_hip_handle {
     int device = 0;
     hipStream_t stream = nullptr;       // used by the host-pointer entry points
@@ -132,6 +134,7 @@ struct annp_hip_handle {
     bool fe_dense = false;              // most atoms have more neighbours than the moment kernels take (128): the pair-loop kernels for all
     bool fe_last_sh = false;            // the last Chebyshev evaluation ran the moment kernels
     bool flags_sh = false; int flags_inum = 0;      // ... and the evaluation the pending flag words belong to (several can be in flight)
+    bool shf_scattered = false, shf_scattered_said = false;       // the caller's atoms are in no spatial order (annp_fe_force_sh's force table)
     int fe_last_inum = 0;
     int sh_wpb = 0;                     // waves per workgroup of annp_fe_desc_sh (ANNP_HIP_SH_WPB; 0 = chosen per launch)
     int flagact[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // up to max(MLP_MAXL, ANNA_MAXL) weight layers
@@ -161,7 +164,8 @@ struct annp_hip_handle {
     double *d_vslots = nullptr;         // [ANNP_VSLOTS][8]: where the kernels tally the global virial (annp_common.hpp), folded per evaluation
     double *d_scalars = nullptr;        // [0] energy, [1..6] virial
     int *d_flags = nullptr;             // [0] capacity error: max n of the atoms that were skipped (stays set until the host has
-                                        //     seen it), [1] max in-cutoff n, [2] length of the force fix-up queue, [3] of the descriptor fix-up queue; [1..3] per evaluation
+                                        //     seen it), [1] max in-cutoff n, [2] length of the force fix-up queue, [3] of the descriptor fix-up queue,
+                                        //     [4] contributions annp_fe_force_sh's force tables had no bucket for; [1..] per evaluation
     int *h_flags = nullptr;             // pinned mirror, copied back behind every evaluation
     hipEvent_t ev_flags = nullptr;      // ... that copy has landed
     int sticky_rc = 0;                  // error found in a landed copy, returned by the next call on the handle
@@ -366,6 +370,25 @@ void digest_flags(annp_hip_handle *h)
             }
         }
         h->info[3] = (h->fe_dense || h->fe_desc_pairs || h->fe_force_pairs) ? h->fe_cap : h->sh_cap;     // capacity of the next force pass
+        // The force table of annp_fe_force_sh keeps eight atoms with consecutive indices per bucket, and counts the contributions that
+        // found none (each is three memory requests, where a bucket leaves with three for all its contributions).  Eight per atom --
+        // 7 % of a bcc-Fe neighbourhood -- is where the pass starts to take visibly longer: the caller should know that sorting
+        // its atoms in space buys up to a factor 2.3 in that pass.
+        if (h->flags_sh) {
+            h->shf_scattered = h->h_flags[4] > 8 * (long long)h->flags_inum;
+            if (h->shf_scattered != h->shf_scattered_said) {
+                h->shf_scattered_said = h->shf_scattered;
+                if (h->notice) {
+                    if (h->shf_scattered)
+                        std::fprintf(h->notice, "annp/hip: atoms are not ordered in space (%.1f force contributions per atom found no room in the force pass's "
+                                     "table of eight-atom buckets): the force pass takes up to 2.3 times as long as with sorted atoms (atom_modify sort)\n",
+                                     (double)h->h_flags[4] / std::max(1, h->flags_inum));
+                    else
+                        std::fprintf(h->notice, "annp/hip: atoms are ordered in space again\n");
+                    std::fflush(h->notice);
+                }
+            }
+        }
         if (over > 0)
             h->sticky_rc = fail(h, ANNP_HIP_ENEIGHCAP, "an atom has %d in-cutoff neighbours, more than the list-row capacity the "
                                 "evaluation was given (max_numneigh) or than LDS holds; it was skipped", over);
@@ -522,10 +545,10 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     if ((rc = ensure(h, h->coef, (size_t)inum * ANNP_CPAD))) return rc;
     if ((rc = ensure(h, h->ncount, (size_t)inum))) return rc;
     if (h->reset_err) {
-        HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, 4 * sizeof(int), s));
+        HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, ANNP_NFLAGS * sizeof(int), s));
         h->reset_err = false;
     } else {
-        HIP_TRY(h, hipMemsetAsync(h->d_flags + 1, 0, 3 * sizeof(int), s));
+        HIP_TRY(h, hipMemsetAsync(h->d_flags + 1, 0, (ANNP_NFLAGS - 1) * sizeof(int), s));
     }
     if (h->timing) {
         h->ev = h->evring.data() + 4 * (size_t)(h->ev_count % annp_hip_handle::kRing);
@@ -589,6 +612,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
             {
                 const int apb = SHF_GROUPS * SHF_GA;        // atoms per workgroup
+                a.tab_spills = h->d_flags + 4;
                 if (vir) hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, true>), dim3((inum + apb - 1) / apb), dim3(64 * SHF_WAVES), shf_lds_per_block(), s, a);
                 else hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, false>), dim3((inum + apb - 1) / apb), dim3(64 * SHF_WAVES), shf_lds_per_block(), s, a);
             }
@@ -607,7 +631,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             // first evaluation on this handle: read the maximum just measured, once.  Also whenever a whole list row would not
             // fit the fix-up launch's LDS (very long rows): nothing would stand behind a stale capacity then
             if (h->fe_cap == 0 || (!fix_possible && h->fe_cap < cap_list)) {
-                HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+                HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, ANNP_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, s));
                 HIP_TRY(h, hipStreamSynchronize(s));
                 if (h->h_flags[0] > 0) {
                     h->reset_err = true;
@@ -712,7 +736,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         HIP_TRY(h, hipGetLastError());
         cap_force = a.n_cap;
         if (!h->ni_primed) {    // first evaluation on the handle (or the one after an error): look at the counts once
-            HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, ANNP_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
             if (h->h_flags[0] > 0) {
                 h->reset_err = true;
@@ -740,10 +764,11 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         HIP_TRY(h, hipGetLastError());
     }
     // flag words of this evaluation, for whoever looks next (poll_flags)
-    HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, ANNP_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipEventRecord(h->ev_flags, s));
     h->flags_pending = true;
     h->flags_sh = h->fe_last_sh; h->flags_inum = h->fe_last_inum;      // (what digest_flags judges the queue length by)
+
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[3], s)); h->ev_count++; }
     (void)nall; (void)d_type;
     return 0;
@@ -1178,11 +1203,11 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     }
     INIT_TRY(hipMalloc((void **)&h->d_scalars, 8 * sizeof(double)));
     INIT_TRY(hipMalloc((void **)&h->d_vslots, sizeof(double) * 8 * ANNP_VSLOTS));
-    INIT_TRY(hipMalloc((void **)&h->d_flags, 4 * sizeof(int)));
-    INIT_TRY(hipMemset(h->d_flags, 0, 4 * sizeof(int)));
-    INIT_TRY(hipHostMalloc((void **)&h->h_flags, 4 * sizeof(int)));
+    INIT_TRY(hipMalloc((void **)&h->d_flags, ANNP_NFLAGS * sizeof(int)));
+    INIT_TRY(hipMemset(h->d_flags, 0, ANNP_NFLAGS * sizeof(int)));
+    INIT_TRY(hipHostMalloc((void **)&h->h_flags, ANNP_NFLAGS * sizeof(int)));
     INIT_TRY(hipHostMalloc((void **)&h->h_scalars, 8 * sizeof(double)));
-    h->bytes += 8 * sizeof(double) + 4 * sizeof(int) + sizeof(double) * 8 * ANNP_VSLOTS;
+    h->bytes += 8 * sizeof(double) + ANNP_NFLAGS * sizeof(int) + sizeof(double) * 8 * ANNP_VSLOTS;
     // kernels may ask for the whole LDS
     {
         const int full = 160 * 1024;

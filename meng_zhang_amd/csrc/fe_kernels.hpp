@@ -63,6 +63,7 @@ struct FeArgs {
     // annp_fe_desc_sh when given, read by annp_fe_force_sh
     double *A;
     int *nbrs;                 // nullable [inum][128]: the in-cutoff neighbours of every atom in list order, annp_fe_desc_sh -> annp_fe_force_sh
+    int *tab_spills;           // nullable device int: contributions annp_fe_force_sh's force tables had no bucket for
 };
 
 // LDS layout of one wave.  A record is two 16-byte halves (e_x,e_y) and (e_z,fc), kept in two

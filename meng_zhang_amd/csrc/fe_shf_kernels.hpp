@@ -66,9 +66,14 @@ static_assert(shf_lds_per_group() % 16 == 0 && shf_lds_table() % 16 == 0, "b128 
 // and the flush walks the table in memory order: a wave-instruction writes 64 consecutive doubles of the table = 2.7 buckets
 // = 8-9 lines.  Atoms that are neighbours in space are neighbours in index wherever the caller sorts its atoms (LAMMPS:
 // atom_modify sort, on by default); where they are not, a bucket holds one atom, the table fills up (SHF_NBUCK buckets) and the
-// contributions beyond it go to memory one by one -- slower, never wrong.  Untouched slots hold +0.0 and are skipped.
+// contributions beyond it go to memory one by one -- never wrong (tests/test_gpu_parity.py::test_fe_atoms_in_random_order), and
+// 2.3 times the time of the pass when the order is random (tools/kbench.py, KBENCH_SHUFFLE: 0.83 -> 1.90 ms per 128 000 atoms).
+// No table changes that: eight atoms picked at random share no neighbours, their 900 force targets are 900 lines of f, against
+// 18 requests per atom in a sorted box (a table with a bucket per atom and eight times the buckets was tried: 1.90 ms as well).
+// The contributions that found no bucket are counted (FeArgs::tab_spills) and the host says so once (annp_hip_set_notice).
+// Untouched slots hold +0.0 and are skipped.
 struct ShfTable {
-    int *key;          // [SHF_NBUCK]: index >> 3 of the bucket's atoms, -1 = free
+    int *key;          // [SHF_NBUCK]: index >> 3 of the bucket's atoms, -1 = free; key[SHF_NBUCK]: contributions that found no bucket
     double *acc;       // [SHF_NBUCK][8][3]
     double *f;
     __device__ __forceinline__ void add(int j, double fx, double fy, double fz) const
@@ -88,6 +93,7 @@ struct ShfTable {
             }
             h = (h + 1) & (SHF_NBUCK - 1);
         }
+        atomicAdd(&key[SHF_NBUCK], 1);
         atomicAdd(&f[3 * (size_t)j], fx); atomicAdd(&f[3 * (size_t)j + 1], fy); atomicAdd(&f[3 * (size_t)j + 2], fz);
     }
     // (both walk the table with compile-time strides: a handful of instructions per pass instead of an index computation per
@@ -99,11 +105,11 @@ struct ShfTable {
 #pragma unroll
         for (int k = 0; k < (NT2 + TH - 1) / TH; k++)
             if (k * TH + TH <= NT2 || tid + k * TH < NT2) a2[tid + k * TH] = make_double2(0.0, 0.0);
-        if (tid < SHF_NBUCK) key[tid] = -1;
+        if (tid <= SHF_NBUCK) key[tid] = tid < SHF_NBUCK ? -1 : 0;
     }
     // thread t < 384 takes double t % 24 of buckets t / 24, t / 24 + 16, ..: a wave-instruction still writes 64 consecutive doubles of
     // the table (2.7 buckets = 8-9 lines of f)
-    __device__ __forceinline__ void flush(int tid) const
+    __device__ __forceinline__ void flush(int tid, int *spills) const
     {
         constexpr int PB = 64 * SHF_WAVES >= 16 * SHF_BATOMS * 3 ? 16 : 8;         // buckets per pass
         static_assert(64 * SHF_WAVES >= PB * SHF_BATOMS * 3 && SHF_NBUCK % PB == 0, "whole buckets per pass");
@@ -116,6 +122,7 @@ struct ShfTable {
                 if (b >= 0 && v != 0.0) atomicAdd(&f[(size_t)b * (SHF_BATOMS * 3) + r], v);
             }
         }
+        if (tid == 64 * SHF_WAVES - 1 && spills && key[SHF_NBUCK]) atomicAdd(spills, key[SHF_NBUCK]);
     }
 };
 
@@ -551,7 +558,7 @@ __global__ __launch_bounds__(64 * SHF_WAVES, 4) void annp_fe_force_sh(FeArgs p)
     __syncthreads();
     SHF_STAMP(7);
 #ifndef ANNP_SHF_SKIP_FLUSH
-    tab.flush(threadIdx.x);          // the workgroup's table, in memory order
+    tab.flush(threadIdx.x, p.tab_spills);          // the workgroup's table, in memory order
 #endif
     SHF_STAMP(8);
 }

@@ -3,7 +3,8 @@
    python tools/kbench.py fe 80      # bcc Fe, 80^3 cells
    python tools/kbench.py ni 40 40 80  # fcc Ni 40x40x80 cells (512 000 atoms)
    python tools/kbench.py anna 80      # bcc Fe, pair_style anna_adp (list cutoff 5.055 + 2 A)
-   KBENCH_VIRIAL=1 python tools/kbench.py fe 80     # with the global virial tallied (vflag_global of an NPT step)"""
+   KBENCH_VIRIAL=1 python tools/kbench.py fe 80     # with the global virial tallied (vflag_global of an NPT step)
+   KBENCH_SHUFFLE=1 python tools/kbench.py fe 40    # atoms in random order (no locality of index: the slow path of the force tables)"""
 import ctypes as C
 import os
 import sys
@@ -38,6 +39,8 @@ def main():
         x0, box = fcc(*dims, A_NI)
         pot, el = NI_POT, "Ni"
     xg = perturb(x0, 12345, 0.05)
+    if os.environ.get("KBENCH_SHUFFLE"):          # atoms in random order: what the force tables do for a caller that does not sort its atoms
+        xg = xg[np.random.default_rng(1).permutation(xg.shape[0])]
     lib = load_library()
     dev = torch.device("cuda", 0)
     dom = plan = SlabDomain.from_global(xg, box, (1, 1, 1), rc_list, dev)
@@ -60,8 +63,9 @@ def main():
     print("list builds (host clock, ms): first %.2f, rebuilds %s" % (tb[0], " ".join("%.2f" % v for v in tb[1:])))
     eng = torch.zeros(1, dtype=torch.float64, device=dev)
     vir = torch.zeros(6, dtype=torch.float64, device=dev) if os.environ.get("KBENCH_VIRIAL") else None
-    lib.annp_hip_set_timing(h, 1)
-    for _ in range(reps + 1):
+    for k in range(reps + 2):
+        if k == 1:
+            lib.annp_hip_set_timing(h, 1)          # (the first evaluation sizes the state the later ones run with)
         dom.f.zero_()
         eng.zero_()
         rc = lib.annp_hip_compute_device(h, plan.nlocal, plan.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value, dom.f.data_ptr(), None, eng.data_ptr(), vir.data_ptr() if vir is not None else None, None, st)
@@ -71,6 +75,7 @@ def main():
     lib.annp_hip_timing_stats(h, ms.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ns))
     print("%s atoms=%d ghosts=%d maxnbr=%d  desc %.3f  net %.3f  force %.3f  total %.3f ms  -> %.2f M atom-evals/s  E/atom %.6f" % (
         kind, plan.nlocal, plan.nghost, mx.value, ms[0], ms[1], ms[2], ms[3], plan.nlocal / ms[3] / 1e3, float(eng.item()) / plan.nlocal))
+    print("eval_path %d" % lib.annp_hip_eval_path(h))
 
 
 if __name__ == "__main__":
