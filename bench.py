@@ -45,15 +45,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # "kernel-derived", not SURVEY.md 8d's budget for the reference formulation, which is printed beside it).
 # (a) what the implemented formulation needs -- the roofline numerator.  The Chebyshev passes work on the 361 moments of a
 #     neighbourhood (fe_sh_kernels.hpp, fe_shf_kernels.hpp), not on its pairs.
-#     Descriptor pass, per in-cutoff neighbour: the monic recurrences of the 19 columns (K - 2 steps of mul + fma = 3 flop in a
-#     column of K polynomials: the first two, 1 and z, cost nothing) 3 x 152 = 456; the accumulation behind every polynomial
-#     (1 FMA in column 0, 2 elsewhere) 2 x 19 + 4 x 171 = 722; advancing the power (x+iy)^m 18 x 6 = 108; geometry, cutoff
-#     function, 9 radial functions 110.  Per atom: lane sums 361 x 15, power spectrum, 19 x 19 product ~ 7 k.
+#     Descriptor pass (round 4b: monomial moments), per in-cutoff neighbour: the powers of z of the 19 columns (K - 2 multiplies in
+#     a column of K powers: 1 and z cost nothing) 153; the accumulation behind every power (1 FMA in column 0, 2 elsewhere)
+#     2 x 19 + 4 x 171 = 722; advancing the power (x+iy)^m 18 x 6 = 108; geometry, cutoff function, 9 radial functions 110.
+#     Per atom: lane sums 361 x 15, 19 x 19 product ~ 7 k; the change of basis to the moments of the Pm^(m)_k 1 430 FMAs, power
+#     spectrum 3 x 190.
 #     Force pass (round 4: Horner's rule on monomial coefficients), per in-cutoff neighbour: columns of K >= 3 entries start with
 #     6 FMAs for three entries and take 4 FMAs per entry after that (16 x 6 + 4 x 120 = 576 FMAs), the two-entry column 2, the
 #     cosine-only column m = 0 3 + 2 x 16 = 35, Horner's rule in w 12 FMAs per column and 8 at the end (224): 837 FMAs = 1 674 flop;
 #     geometry, radial T and T', force assembly 158.  Per atom: B = W kappa A 760, change of basis 1 430 FMAs = 2 860.
-FLOP_PAIR_DESC, FLOP_NBR_DESC, FLOP_ATOM_DESC = 0.0, 3 * 152 + (2 * 19 + 4 * 171) + 18 * 6 + 110.0, 7000.0
+FLOP_PAIR_DESC, FLOP_NBR_DESC, FLOP_ATOM_DESC = 0.0, 153 + (2 * 19 + 4 * 171) + 18 * 6 + 110.0, 7000.0 + 2 * 1430 + 3 * 190
 FLOP_PAIR_FORCE, FLOP_NBR_FORCE, FLOP_ATOM_FORCE = 0.0, 2 * (16 * 6 + 4 * 120 + 2 + 35 + 12 * 18 + 8) + 158.0, 760.0 + 2860.0
 #     ... and the pair-loop kernels they replaced (ANNP_HIP_FE_DESC=pairs ANNP_HIP_FE_FORCE=pairs, or a system with more than
 #     128 neighbours per atom): pass 1: cos 5, weights 3, T_2..T_18 recurrence + accumulate 68; pass 3: cos 5, Horner P 36 +
@@ -63,7 +64,7 @@ FLOP_MLP = 2500.0
 # (b) SURVEY.md 8d's budget for the reference formulation (T and T' recurrences for every function in both
 #     passes): 350 flop per pair + 175 per neighbour + 1.6 k = 2.20 MFLOP per atom-step at n = 112
 SURVEY_FLOP_PAIR, SURVEY_FLOP_NBR, SURVEY_FLOP_MLP = 350.0, 175.0, 1600.0
-BYTES_ATOM_STEP = 9960.0 + 2 * 384 * 8            # gathered bytes per atom-step + the moments written and read back
+BYTES_ATOM_STEP = 9960.0 + 2 * 380 * 8            # gathered bytes per atom-step + the moments written and read back
 PEAK_FP64_VECTOR = 78.6                           # TFLOP/s, MI355X (MI355X_MICROARCH.md: half of FP32 vector 157.3)
 PEAK_HBM = 8000.0                                 # GB/s spec
 # Ni (Behler G2/G4), counted from the kernels: per candidate (j,k) pair the distance pre-pass of the descriptor

@@ -507,6 +507,10 @@ int launch_fe_desc(annp_hip_handle *h, FeArgs a, int inum, int cap_list, int max
     if (fix && (rc = ensure(h, h->ovf_desc, (size_t)inum))) return rc;
     a.n_cap = cap;
     h->sh_cap_used = cap;
+    if (!a.A) {         // the kernel sums monomial moments and changes basis in the atom's moment row: it needs one, whoever reads it afterwards
+        if ((rc = ensure(h, h->mom, (size_t)inum * SH_MPAD))) return rc;
+        a.A = h->mom.p;
+    }
     a.ovf_count = h->d_flags + 3; a.ovf_list = fix ? h->ovf_desc.p : nullptr; a.ovf_cap = fix ? inum : 0;
     // waves per workgroup: as many waves per CU as the LDS allows, and of those shapes the largest workgroup (measured at
     // 1 M atoms, 8 waves per CU each: 5.8 ms with 4 waves per workgroup, 6.3 with 1)

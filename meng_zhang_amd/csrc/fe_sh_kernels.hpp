@@ -43,7 +43,12 @@ static_assert(SH_LMAX == FE_NT - 1, "tables are generated for T_0..T_18");
 __constant__ double annp_sh_q[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_Q_INIT;
 __constant__ double annp_sh_kappa[SH_NMOM + 16] = ANNP_SH_KAPPA_INIT;      // (+16: a lane past the last batch's end reads a zero)
 __constant__ double annp_sh_ml[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_ML_INIT;
-constexpr int SH_MPAD = 384;      // doubles per atom in the moment buffer: (cosine, sine) of (l = m+k, m) at 2 (shf_toff(m) + 18-m-k), sh_tables.hpp
+// doubles per atom in the moment buffer: (cosine, sine) of (l = m+k, m) at 2 (shf_toff(m) + 18-m-k), sh_tables.hpp; 380 used,
+// 20 zeros behind them (sh_legendre reads a few positions past its column's last entry with a zero coefficient); 25 lines of 128 bytes
+constexpr int SH_MPAD = 400;
+__constant__ unsigned short annp_shd_info[SHD_NROUND * 16] = ANNP_SHD_INFO_INIT;
+__constant__ double annp_shd_kappa[SHD_NROUND * 16] = ANNP_SHD_KAPPA_INIT;
+__constant__ double annp_shd_coef[SHD_TFIRST[SHD_NROUND] * 16] = ANNP_SHD_COEF_INIT;
 __host__ __device__ constexpr int sh_apos(int m, int k) { return 2 * (shf_toff(m) + SH_LMAX - m - k); }
 
 constexpr int SH_R = 3;           // neighbours per lane whose state stays in registers (ShRegs)
@@ -55,11 +60,18 @@ constexpr int SH_CAP_MIN = SH_GL * SH_R + 16;
 // MI355X_MICROARCH.md, LDS) on the four 64-byte quarters of the bank row (128 mod 256 bytes), and the eight 32-byte runs
 // of a 32-lane group of ds_read_b64 on its eight eighths (64 or 192 mod 256 bytes).
 __host__ __device__ constexpr int sh_pitch(int capl) { return capl + 8; }
+// After the last column the neighbour arrays are dead and the atoms' monomial moments take their place (sh_legendre): 190 (cosine,
+// sine) pairs per atom from the wave's first byte, pw and the radial totals in the last 1152 bytes of the wave's share.
+constexpr int SH_MOMB = SH_GA * SHF_NE * 16;         // 12 160
+constexpr int SH_PWB = (SH_GA * 20 + SH_GA * 16) * 8;
+__host__ __device__ constexpr size_t sh_lds_arrays(int n_cap) { return (size_t)SH_GA * sh_pitch(n_cap - SH_GL * SH_R) * 40; }
 __host__ __device__ constexpr size_t sh_lds_per_wave(int n_cap)
 {
-    return (size_t)SH_GA * sh_pitch(n_cap - SH_GL * SH_R) * 40 + SH_GL * SH_R * 32;
+    const size_t a = sh_lds_arrays(n_cap) + SH_GL * SH_R * 32, b = (size_t)SH_MOMB + SH_PWB;
+    return a > b ? a : b;
 }
-static_assert(SH_GL * SH_R * 32 >= (SH_GA * 20 + SH_GA * 16) * 8, "pw and the radial totals live where the staging rows were");
+static_assert(3 * 4 * sh_lds_per_wave(112) <= 160 * 1024, "bcc Fe (112 neighbours in 6.5 A): three workgroups of four waves per CU");
+static_assert(SH_GL * SH_R * 32 >= SH_PWB, "pw and the radial totals live where the staging rows were");
 
 // ---- sums over the 16 lanes of an atom ------------------------------------------------------------------------------
 // Lane λ of the wave works for atom g = (λ >> 2) & 3 as its lane l = 4 (λ >> 4) + (λ & 3): the four atoms are interleaved quad
@@ -140,8 +152,12 @@ typedef double shf_v2d __attribute__((ext_vector_type(2)));
 struct ShLane {
     unsigned a_sa, a_sc, a_sz;     // LDS byte addresses of this lane's first slot of (e_x,e_y), of the running power and of z
     double *pwg;           // pw of this lane's atom
-    double *Aout;          // nullable: the atom's row of the moment buffer
+    double *Abase;         // the moment row of the wave's first atom (uniform) ...
+    unsigned arow;         // ... and the byte offset of this lane's atom's row from it (a lane without an atom: 0, and alive = false)
+    bool alive;
+    unsigned a_mom;        // LDS byte address of the atom's monomial moments (sh_legendre)
     int iters;             // LDS-resident neighbours per lane to walk (uniform, may be 0)
+    int l16;               // the lane's number among the 16 of its atom
     int jrev;              // which of a batch's 16 totals this lane ends up with: wave lane bits 5,4,1,0 -> bits 0,1,2,3
     bool bit1, bit0;       // wave lane bits 1 and 0
 };
@@ -149,11 +165,11 @@ struct ShLane {
 // neighbour are what bounds the waves a CU holds, and with them the kernel's speed
 struct ShRegs { double z[SH_R], ex[SH_R], ey[SH_R], pc[SH_R], ps[SH_R]; };
 
-// batch B of column M: moments 16B .. 16B+R-1 of the column (cosine l = M..18, then sine l = M..18) summed over the atom's
-// lanes; the lane that ends up with moment j adds kappa |A|^2 to pw_l.  kap = this lane's kappa of this batch, fetched before
-// the neighbour loop (sh_column).
+// batch B of column M: sums 16B .. 16B+R-1 of the column (cosine j = 0..K-1, then sine j = 0..K-1) added up over the atom's
+// lanes; the lane that ends up with a total parks it in the atom's moment row in HBM -- the registers are needed for the next
+// column, and LDS is full of neighbours until the last one is done (sh_fetch_totals brings the row back in one go).
 template <int M, int B>
-__device__ __forceinline__ void sh_batch(const ShLane &w, const double *ac, const double *as, double kap)
+__device__ __forceinline__ void sh_batch(const ShLane &w, const double *ac, const double *as)
 {
     constexpr int K = SH_LMAX + 1 - M;
     constexpr int NV = (M > 0 ? 2 : 1) * K;
@@ -169,13 +185,12 @@ __device__ __forceinline__ void sh_batch(const ShLane &w, const double *ac, cons
     const double t = sh_row_reduce<RP>(v, w.bit1, w.bit0);
     const int j = w.jrev & (RP - 1);
     const int vv = 16 * B + j;
-    const int ll = M + (vv < K ? vv : vv - K);
-    if ((w.jrev & (16 - RP)) == 0 && j < R) {       // one lane per moment
-        atomicAdd(w.pwg + ll, kap * (t * t));
-        if (w.Aout) {                     // kappa_lm A_lm: what annp_fe_force_sh multiplies W_l with
-            w.Aout[sh_apos(M, ll - M) + (vv < K ? 0 : 1)] = kap * t;
-            if (M == 0) w.Aout[sh_apos(M, ll - M) + 1] = 0.0;            // (column 0 has no sine moments: the pair's other half)
-        }
+    const int jj = vv < K ? vv : vv - K;
+    if ((w.jrev & (16 - RP)) == 0 && j < R && w.alive) {       // one lane per total
+        // (one uniform base and a 32-bit offset per lane: the 32 batches would otherwise keep a 64-bit address each)
+        const unsigned off = w.arow + 8u * (unsigned)(sh_apos(M, 0) + (vv < K ? 0 : 1)) - 16u * (unsigned)jj;
+        *reinterpret_cast<double *>(reinterpret_cast<char *>(w.Abase) + off) = t;
+        if (M == 0) *reinterpret_cast<double *>(reinterpret_cast<char *>(w.Abase) + off + 8u) = 0.0;      // (column 0 has no sine moments: the pair's other half)
     }
 }
 
@@ -186,26 +201,25 @@ __device__ __forceinline__ void sh_column(const ShLane &w, ShRegs &st)
     constexpr int NV = (M > 0 ? 2 : 1) * K;
     constexpr int NB = (NV + 15) / 16;
     static_assert(NB <= 3, "three batches per column at most");
-    // this lane's kappa for each batch of the column: in flight behind the neighbour loop
-    const double *kp = annp_sh_kappa + SH_COL_OFF[M] + w.jrev;
-    const double kap0 = kp[0], kap1 = NB > 1 ? kp[16] : 0.0, kap2 = NB > 2 ? kp[32] : 0.0;
     double ac[K], as[K];
-    // one neighbour: Pm_k(z), k = 0..K-1, times its power (cx, cy) = fc (x+iy)^M into the accumulators (the first one sets them)
-    auto neighbour = [&](auto first, const double z, const double cx, const double cy) {
+    // one neighbour: z^j, j = 0..K-1, times its power (cx, cy) = fc (x+iy)^M into the accumulators (the first one sets them)
+    auto neighbour = [&](auto first, double z, const double cx, const double cy) {
         constexpr bool FIRST = decltype(first)::value;
+        // (the powers of z are the same in every column: left to itself the compiler keeps those of the register-resident neighbours
+        // for all nineteen -- a hundred registers, a wave less per SIMD.  One multiply per power is what they cost here.)
+        asm volatile("" : "+v"(z));
         ac[0] = FIRST ? cx : ac[0] + cx;
         as[0] = (M > 0) ? (FIRST ? cy : as[0] + cy) : 0.0;
         if (K > 1) {
             ac[1] = FIRST ? z * cx : fma(z, cx, ac[1]);
             as[1] = (M > 0) ? (FIRST ? z * cy : fma(z, cy, as[1])) : 0.0;
         }
-        double P2 = 1.0, P1 = z;
+        double P = z;
 #pragma unroll
         for (int k = 2; k < K; k++) {
-            const double P = fma(z, P1, -(sh_gamma(M, k) * P2));
+            P *= z;
             ac[k] = FIRST ? P * cx : fma(P, cx, ac[k]);
             as[k] = (M > 0) ? (FIRST ? P * cy : fma(P, cy, as[k])) : 0.0;
-            P2 = P1; P1 = P;
         }
     };
 #pragma unroll
@@ -262,9 +276,9 @@ __device__ __forceinline__ void sh_column(const ShLane &w, ShRegs &st)
             left -= 2;
         }
     }
-    sh_batch<M, 0>(w, ac, as, kap0);
-    if (NB > 1) sh_batch<M, (NB > 1 ? 1 : 0)>(w, ac, as, kap1);
-    if (NB > 2) sh_batch<M, (NB > 2 ? 2 : 0)>(w, ac, as, kap2);
+    sh_batch<M, 0>(w, ac, as);
+    if (NB > 1) sh_batch<M, (NB > 1 ? 1 : 0)>(w, ac, as);
+    if (NB > 2) sh_batch<M, (NB > 2 ? 2 : 0)>(w, ac, as);
 }
 template <int M>
 struct ShColumns {
@@ -278,6 +292,69 @@ template <>
 struct ShColumns<SH_LMAX + 1> {
     static __device__ __forceinline__ void run(const ShLane &, ShRegs &) {}
 };
+
+// ---- monomial moments (LDS) -> moments of the Pm^(m)_k (the atom's moment row in HBM); kappa |A|^2 into pw_l.
+// A_(m+k,m) = sum_(j = k, k-2, ..) M^(m)_kj Mom_jm (Pm^(m)_k = sum_j M_kj z^j, exact rationals): 715 coefficients, 190 entries,
+// sixteen per round -- one per lane of an atom -- in descending k (tools/gen_sh_tables.py::tail_schedule): the lanes of a round have
+// k within a few of each other; a lane with fewer terms than the round walks multiplies the positions behind its column's last
+// by zero (they hold the next column, the next atom's first, or pw: numbers).  The next round's coefficients are requested
+// before this round's arithmetic.  (Tried first: changing basis in place in the moment row in HBM -- twelve rounds of cache
+// latency per wave ate what the cheaper columns had saved, 5.5 ms either way; and keeping the 32 totals of a lane in registers
+// until the last column -- 76 of them spilled, 5.75 ms.)
+template <int R>
+struct ShTailOps {
+    static constexpr int T = SHD_TRIPS[R];
+    double c[T];
+    double2 mv[T];
+    int info;
+    double kap;
+    __device__ __forceinline__ void load(const ShLane &w)
+    {
+        // (tables: a uniform address and the lane's 32-bit byte offset, so that the twelve rounds share one offset register
+        // instead of keeping a 64-bit address each)
+        const unsigned lo = (unsigned)w.l16;
+        info = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(annp_shd_info + R * 16) + 2u * lo);
+        kap = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(annp_shd_kappa + R * 16) + 8u * lo);
+#pragma unroll
+        for (int t = 0; t < T; t++)
+            c[t] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(annp_shd_coef + (SHD_TFIRST[R] + t) * 16) + 8u * lo);
+        asm volatile("" ::: "memory");          // (two rounds in flight, not all twelve rounds' coefficients: registers)
+    }
+    __device__ __forceinline__ void finish(const ShLane &w)
+    {
+        typedef __attribute__((address_space(3))) shf_v2d *l2p;
+        const unsigned mo = w.a_mom + 16u * (unsigned)(info & 255);
+#pragma unroll
+        for (int t = 0; t < T; t++) { const shf_v2d q = *(l2p)(uintptr_t)(mo + 32u * t); mv[t] = make_double2(q.x, q.y); }
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int t = T - 1; t >= 0; t--) { a0 = fma(c[t], mv[t].x, a0); a1 = fma(c[t], mv[t].y, a1); }       // (small powers first)
+        if ((info & 0x8000) && w.alive) {
+            atomicAdd(w.pwg + ((info >> 8) & 31), kap * fma(a0, a0, a1 * a1));
+            *reinterpret_cast<double2 *>(reinterpret_cast<char *>(w.Abase) + (w.arow + 16u * (unsigned)(info & 255))) = make_double2(kap * a0, kap * a1);        // kappa_lm A_lm: what annp_fe_force_sh multiplies W_l with
+        }
+    }
+};
+template <int R>
+struct ShTail {
+    static __device__ __forceinline__ void run(const ShLane &w, ShTailOps<R> &cur)
+    {
+        if constexpr (R + 1 < SHD_NROUND) {
+            ShTailOps<R + 1> nxt;
+            nxt.load(w);
+            cur.finish(w);
+            ShTail<R + 1>::run(w, nxt);
+        } else {
+            cur.finish(w);
+        }
+    }
+};
+__device__ __forceinline__ void sh_legendre(const ShLane &w)
+{
+    ShTailOps<0> first;
+    first.load(w);
+    ShTail<0>::run(w, first);
+}
 
 // fe_geometry with the sincos coefficients from scalar registers (annp_common.hpp)
 __device__ __forceinline__ FeNbr sh_geometry(double2 R0, double2 R1, double pi_over_rc)
@@ -294,7 +371,7 @@ __device__ __forceinline__ FeNbr sh_geometry(double2 R0, double2 R1, double pi_o
 }
 
 template <int NP, int NT>
-__global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
+__global__ __launch_bounds__(256, 3) void annp_fe_desc_sh(FeArgs p)
 {
     static_assert(NT == SH_LMAX + 1 && NP + NT <= ANNP_GPAD && NP + 1 <= 16, "layout of the output row");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -309,9 +386,9 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
     double2 *SA = reinterpret_cast<double2 *>(wbase);
     double2 *SC = SA + SH_GA * PL;
     double *SZ = reinterpret_cast<double *>(SC + SH_GA * PL);
-    double *pw = SZ + SH_GA * PL;                    // [4][20], then radial totals [4][16]; before that ...
+    double *pw = reinterpret_cast<double *>(wbase + sh_lds_per_wave(cap) - SH_PWB);      // [4][20], then radial totals [4][16]: the wave's last bytes
     double *rt = pw + SH_GA * 20;
-    double2 *stA = reinterpret_cast<double2 *>(pw);  // ... the staging rows of the register-resident entries: raw (dx,dy)[48], (dz,r^2)[48]
+    double2 *stA = reinterpret_cast<double2 *>(SZ + SH_GA * PL);  // behind the arrays: the staging rows of the register-resident entries, raw (dx,dy)[48], (dz,r^2)[48]
     double2 *stB = stA + SH_GL * SH_R;
     const int g = (lane >> 2) & 3, l = ((lane >> 4) << 2) | (lane & 3);      // atoms interleaved quad by quad (sh_row_reduce)
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
@@ -487,7 +564,11 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
     w.a_sz = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(SZ + g * PL + l);
     w.pwg = pw + g * 20;
     w.iters = iters;
-    w.Aout = (p.A && !dead) ? p.A + (size_t)(ii0 + g) * SH_MPAD : nullptr;
+    w.Abase = p.A + (size_t)ii0 * SH_MPAD;
+    w.alive = !dead;
+    w.arow = dead ? 0u : (unsigned)(g * SH_MPAD * 8);
+    w.l16 = l;
+    w.a_mom = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)wbase + (unsigned)(g * SHF_NE * 16);
     w.jrev = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 1) & 1) << 2) | ((lane & 1) << 3);
     w.bit1 = (lane & 2) != 0; w.bit0 = (lane & 1) != 0;
     {
@@ -496,8 +577,38 @@ __global__ __launch_bounds__(256) void annp_fe_desc_sh(FeArgs p)
     }
     wave_lds_sync();
 
-    // ---- the moments, column by column
+    // ---- the monomial moments, column by column, parked in the atoms' moment rows; then, the neighbour arrays being done with,
+    //      back into LDS in one go (whole rows: 12 loads per lane, one trip through the cache) and from there into the moments of
+    //      the Pm^(m)_k: pw_l, and the moment row again, for the force pass
     ShColumns<0>::run(w, st);
+    // (the wave reads back what its own lanes stored: rows are whole 128-byte lines nobody else touches, and the stores are
+    // complete before the first load is issued)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wave_lds_sync();
+    {
+        double2 *mom = reinterpret_cast<double2 *>(wbase);
+        const unsigned long long deadmask = __ballot(dead);
+#pragma unroll
+        for (int ga = 0; ga < SH_GA; ga++) {
+            // a row nobody wrote (no such atom, or one that went to the fix-up queue) reads as zeros: its neighbour in LDS multiplies
+            // a few of its entries by zero (sh_legendre)
+            const bool ok = ((deadmask >> (4 * ga)) & 1ull) == 0;
+            const double2 *row = reinterpret_cast<const double2 *>(w.Abase + (size_t)(ok ? ga : 0) * SH_MPAD);
+#pragma unroll
+            for (int u = 0; u < (SHF_NE + 63) / 64; u++) {
+                const int pos = lane + 64 * u;
+                if (pos < SHF_NE) {
+                    const double2 q = row[pos];
+                    mom[ga * SHF_NE + pos] = ok ? q : make_double2(0.0, 0.0);
+                }
+            }
+        }
+        // ... and behind the wave's last atom pw -- or, where the neighbour arrays are longer than the moments, whatever they held
+        if (sh_lds_per_wave(cap) - SH_PWB != (size_t)SH_MOMB && lane < 12) reinterpret_cast<double *>(wbase + SH_MOMB)[lane] = 0.0;
+    }
+    wave_lds_sync();
+    sh_legendre(w);
     wave_lds_sync();
 
     // ---- output row: slots l and l + 16 of the atom's 32

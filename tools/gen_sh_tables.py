@@ -112,6 +112,33 @@ def conv_records():
     return recs, first
 
 
+def tail_schedule():
+    """The descriptor pass sums MONOMIAL moments sum_b fc_b z_b^j w_b^m (round 4b) and turns them into the moments of the
+    Pm^(m)_k afterwards, A_(m+k,m) = sum_{j = k, k-2, ..} M^(m)_kj Mom_jm, sixteen entries (m, k) per round, one per lane of an
+    atom, in place.  Entries in descending k: an entry only reads powers j <= k of its own column, so nothing a round reads
+    was overwritten by an earlier one, and the lanes of a round have nearly the same number of terms.
+    Returns (rounds, trips): rounds[r] = list of 16 (m, k) or None; trips[r] = terms a lane of round r walks."""
+    ent = sorted(((m, k) for m in range(L + 1) for k in range(L + 1 - m)), key=lambda e: (-e[1], e[0]))
+    rounds = [ent[i:i + 16] for i in range(0, len(ent), 16)]
+    trips = [r[0][1] // 2 + 1 for r in rounds]
+    rounds = [r + [None] * (16 - len(r)) for r in rounds]
+    return rounds, trips
+
+
+def tail_tables():
+    """info[r][lane] = position of entry (m, k) in the moment row | (m + k) << 8 | 1 << 15 (a lane without an entry: position of
+    (0, 0), no flag); kappa[r][lane]; coef[first trip of r + t][lane] = M^(m)_(k, k-2t), 0 past the last term."""
+    rounds, trips = tail_schedule()
+    polys = {m: pm_monomials(m) for m in range(L + 1)}
+    info, kap, coef = [], [], []
+    for r, T in zip(rounds, trips):
+        info.append([(shf_toff(e[0]) + L - e[0] - e[1]) | ((e[0] + e[1]) << 8) | (1 << 15) if e else shf_toff(0) + L for e in r])
+        kap.append([kappa(e[0] + e[1], e[0]) if e else Fr(0) for e in r])
+        for t in range(T):
+            coef.append([polys[e[0]][e[1]][e[1] - 2 * t] if e and e[1] - 2 * t >= 0 else Fr(0) for e in r])
+    return info, kap, coef, trips
+
+
 def sqrt_to_double(x):
     getcontext().prec = 80
     return float((Decimal(x.numerator) / Decimal(x.denominator)).sqrt())
@@ -154,6 +181,14 @@ def render():
               "constexpr int SHF_CONV_NREC = %d;" % len(conv_records()[0]),
               "constexpr int SHF_CONV_FIRST[SH_LMAX + 1][2] = {" + ", ".join("{%d, %d}" % (conv_records()[1].get((m, 0), -1), conv_records()[1].get((m, 16), -1)) for m in range(L + 1)) + "};",
               "#define ANNP_SHF_CONV_INIT { \\"] + ["    " + ", ".join(float(v).hex() for v in row) + ", \\" for row in conv_records()[0]] + ["}", "",
+              "// descriptor pass, round 4b: monomial moments -> moments of the Pm^(m)_k (tail_schedule / tail_tables of the generator):",
+              "// SHD_NROUND rounds of 16 entries, SHD_TRIPS[r] terms per lane, SHD_TFIRST[r] = first row of round r in the coefficients",
+              "constexpr int SHD_NROUND = %d;" % len(tail_tables()[3]),
+              "constexpr int SHD_TRIPS[SHD_NROUND] = {" + ", ".join(str(t) for t in tail_tables()[3]) + "};",
+              "constexpr int SHD_TFIRST[SHD_NROUND + 1] = {" + ", ".join(str(sum(tail_tables()[3][:r])) for r in range(len(tail_tables()[3]) + 1)) + "};",
+              "#define ANNP_SHD_INFO_INIT { " + ", ".join(str(v) for row in tail_tables()[0] for v in row) + " }",
+              "#define ANNP_SHD_KAPPA_INIT { \\"] + ["    " + ", ".join(float(v).hex() for v in row) + ", \\" for row in tail_tables()[1]] + ["}",
+              "#define ANNP_SHD_COEF_INIT { \\"] + ["    " + ", ".join(float(v).hex() for v in row) + ", \\" for row in tail_tables()[2]] + ["}", "",
               "// z^k = sum_l ml[k][l] P_l(z): the network pass hands the angular polynomial over in powers of z (coef), the force",
               "// pass wants it in Legendre polynomials, W_l = sum_k p_k ml[k][l]",
               "#define ANNP_SH_ML_INIT { \\"] + ["    " + ", ".join(float(v).hex() for v in (mono_to_legendre(k) + [Fr(0)] * (L - k))) + ", \\" for k in range(L + 1)] + ["}", "",
