@@ -269,7 +269,7 @@ int annp_hip_sync(annp_hip_handle *handle);
 /* Facts about the most recent evaluation (waits for its flag words only):
  *   info4[0] largest in-cutoff neighbour count   info4[1] atoms (Behler: groups of four atoms) that went through the fix-up launch
  *   info4[2] neighbours per atom its force pass had room for (Chebyshev, moment kernels: the state the descriptor and force
- *            passes share, 64..128; pair-loop kernels and Behler: LDS records)   info4[3] what the next evaluation will use */
+ *            passes share, 96..128; pair-loop kernels and Behler: LDS records)   info4[3] what the next evaluation will use */
 int annp_hip_eval_info(annp_hip_handle *handle, int *info4);
 
 /* Which kernels the NEXT evaluation will run (after the most recent one's flag words, which this waits for):

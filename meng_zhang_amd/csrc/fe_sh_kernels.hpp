@@ -51,7 +51,7 @@ __constant__ double annp_shd_kappa[SHD_NROUND * 16] = ANNP_SHD_KAPPA_INIT;
 __constant__ double annp_shd_coef[SHD_TFIRST[SHD_NROUND] * 16] = ANNP_SHD_COEF_INIT;
 __host__ __device__ constexpr int sh_apos(int m, int k) { return 2 * (shf_toff(m) + SH_LMAX - m - k); }
 
-constexpr int SH_R = 3;           // neighbours per lane whose state stays in registers (ShRegs)
+constexpr int SH_R = 5;           // neighbours per lane whose state stays in registers (ShRegs)
 constexpr int SH_CAP_MIN = SH_GL * SH_R + 16;
 
 // LDS of one wave, capl = cap - 48 slots per atom: (e_x,e_y)[4][capl+8] | (pc,ps)[4][capl+8] | z[4][capl+8] | 1536 bytes: first the

@@ -140,7 +140,7 @@ def test_fe_compiled_capacity_kernel_on_ragged_clusters(fe_pot, seed, density, k
             if density >= 0.09:
                 assert cap == 128                        # the densest clusters run in the compiled-capacity kernel
         else:
-            assert cap == max(64, min(primed, row_cap)) and (nfix > 0) == (mx > cap)
+            assert cap == max(96, min(primed, row_cap)) and (nfix > 0) == (mx > cap)        # (96 = SH_CAP_MIN: five neighbours of a lane in registers, one in LDS)
     finally:
         p.close()
     scale = max(1.0, np.abs(o["f"]).max())
