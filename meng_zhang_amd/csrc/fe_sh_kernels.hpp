@@ -11,19 +11,23 @@
 //     pw_l   = sum_{a,b} fc_a fc_b P_l(e_a.e_b) = sum_m kappa_lm |A_lm|^2
 //     G_{9+n} = 1/2 ( sum_l q_nl pw_l - sum_a fc_a^2 ),       T_n((z+1)/2) = sum_{l<=n} q_nl P_l(z)
 // -- the same numbers (the identities are exact; the constants are exact rationals rounded once, tools/gen_sh_tables.py;
-// measured difference to the pair loop: a few 1e-13 relative), for 112 x 190 recurrence steps instead of 6 216 x 17.
+// measured difference to the pair loop: a few 1e-13 relative; 2e-14 of the row's size since round 4b), for 112 x 190 steps
+// instead of 6 216 x 17.
 // The T_0 / T_1 closed forms of annp_fe_desc are the l = 0, 1 cases of this.
 //
 // Work decomposition of the descriptor pass: a wave takes FOUR atoms, 16 lanes each; a lane owns neighbours l, l+16, l+32, ..
-// of its atom, the first three in registers (ShRegs), the others in LDS.
+// of its atom, the first SH_R = 5 in registers (ShRegs), the others in LDS.
 //   stage A  headers of the four atoms, the index loads of all four list rows, all coordinate gathers (two dependent round
 //            trips through memory for the wave), ballot compaction row by row; every lane turns its raw entries into
 //            (e_x,e_y), z, (fc,0) -- the running power fc (x+iy)^m starts at m = 0 -- and sums the radial functions.
-//   columns  m = 0..18, unrolled: a lane walks its neighbours, runs the recurrence in l = m..18 (2 instructions per step, the
-//            constant a literal) and adds Pm (x+iy)^m fc into its 2(19-m) accumulators (2 per step); the power is advanced.
-//            Then the accumulators are summed over the atom's 16 lanes -- a transposing butterfly: 16 registers x 16 lanes
-//            -> one register whose 16 lanes hold the 16 totals, ~3.6 instructions per total for four atoms at once -- and
-//            kappa |A|^2 is added to pw_l in LDS; the scaled moments go to HBM for the force pass.
+//   columns  m = 0..18, unrolled: a lane walks its neighbours and adds z^j (x+iy)^m fc, j = 0..18-m, into its 2(19-m) accumulators
+//            (a multiply for the power, two FMAs: round 4b; rounds 3-4 ran the recurrence of the Pm_k here, a multiply and an
+//            FMA per step); the power of x+iy is advanced.  Then the accumulators are summed over the atom's 16 lanes -- a
+//            transposing butterfly: 16 registers x 16 lanes -> one register whose 16 lanes hold the 16 totals, ~3.6 instructions
+//            per total for four atoms at once.  The totals are MONOMIAL moments; they wait in the atom's moment row.
+//   basis    after the last column the four rows come back into the LDS the neighbours have left, and twelve rounds of sixteen
+//            entries change basis, A_(m+k,m) = sum_j M_kj Mom_jm (sh_legendre): kappa |A|^2 into pw_l, kappa A into the moment
+//            row for the force pass.
 //   final    lane n of an atom: G_{9+n} from the 19 pw_l (q from constant memory), the radial sums, one 32-double row out.
 // An atom with more in-cutoff neighbours than the launch has state for (n_cap, at most 128) is queued for
 // annp_fe_desc_fixup (the pair-loop kernel with room for a whole list row) instead.
@@ -161,7 +165,7 @@ struct ShLane {
     int jrev;              // which of a batch's 16 totals this lane ends up with: wave lane bits 5,4,1,0 -> bits 0,1,2,3
     bool bit1, bit0;       // wave lane bits 1 and 0
 };
-// the first SH_R neighbours of a lane (l, l+16, l+32 of its atom) stay in registers for the whole kernel: 40 bytes of LDS per
+// the first SH_R neighbours of a lane (l, l+16, l+32, .. of its atom) stay in registers for the whole kernel: 40 bytes of LDS per
 // neighbour are what bounds the waves a CU holds, and with them the kernel's speed
 struct ShRegs { double z[SH_R], ex[SH_R], ey[SH_R], pc[SH_R], ps[SH_R]; };
 
