@@ -45,8 +45,6 @@ constexpr int SH_CAP_MAX = 128;   // state slots per atom the launch may ask for
 static_assert(SH_LMAX == FE_NT - 1, "tables are generated for T_0..T_18");
 
 __constant__ double annp_sh_q[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_Q_INIT;
-__constant__ double annp_sh_kappa[SH_NMOM + 16] = ANNP_SH_KAPPA_INIT;      // (+16: a lane past the last batch's end reads a zero)
-__constant__ double annp_sh_ml[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_ML_INIT;
 // doubles per atom in the moment buffer: (cosine, sine) of (l = m+k, m) at 2 (shf_toff(m) + 18-m-k), sh_tables.hpp; 380 used,
 // 20 zeros behind them (sh_legendre reads a few positions past its column's last entry with a zero coefficient); 25 lines of 128 bytes
 constexpr int SH_MPAD = 400;

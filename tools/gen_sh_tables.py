@@ -149,27 +149,9 @@ def render():
     lines = ["// sh_tables.hpp -- GENERATED by tools/gen_sh_tables.py (exact rationals rounded once); do not edit.",
              "#pragma once", "", "namespace annp {", "",
              "constexpr int SH_LMAX = %d;" % L, "",
-             "// gamma(m,k) of the monic recurrence is a ratio of small integers: computed where it is used",
-             "__host__ __device__ constexpr double sh_gamma(int m, int k)",
-             "{ return (double)((k - 1) * (k - 1 + 2 * m)) / (double)((2 * k + 2 * m - 1) * (2 * k + 2 * m - 3)); }", "",
-             "// kappa[l][m] in the order the kernel produces the moments: column m = 0..18, in it the cosine moments l = m..18,",
-             "// then (m > 0) the sine moments l = m..18; SH_COL_OFF[m] = first entry of column m",
-             "#define ANNP_SH_KAPPA_INIT { \\"]
-    offs, off = [], 0
-    for m in range(L + 1):
-        offs.append(off)
-        vals = [float(kappa(l, m)).hex() for l in range(m, L + 1)]
-        if m > 0:
-            vals = vals + vals
-        off += len(vals)
-        lines.append("    " + ", ".join(vals) + ", \\")
-    lines += ["}", "constexpr int SH_NMOM = %d;" % off,
-              "constexpr int SH_COL_OFF[SH_LMAX + 2] = {" + ", ".join(str(o) for o in offs + [off]) + "};", "",
-              "// force pass (annp_fe_force_sh): its table has one entry per recurrence step (m, k), column after column;",
-              "// SHF_OFF[m] = first entry of column m, ANNP_SHF_MK = m | k << 8 of every entry",
-              "constexpr int SHF_NE = %d;" % sum(L + 1 - m for m in range(L + 1)),
-              "constexpr int SHF_OFF[SH_LMAX + 2] = {" + ", ".join(str(sum(L + 1 - mm for mm in range(m))) for m in range(L + 2)) + "};",
-              "#define ANNP_SHF_MK_INIT { " + ", ".join(str(m | (k << 8)) for m in range(L + 1) for k in range(L + 1 - m)) + " }", "",
+             "// entries of the moment row / of the force pass's table: one per (m, k), 190",
+             "constexpr int SHF_NE = %d;" % sum(L + 1 - m for m in range(L + 1)), ""]
+    lines += [
               "// force pass on monomials (annp_fe_force_sh, round 4): its table holds, for column m = 18..0, the coefficients of z^j,",
               "// j = K-1..0 (K = 19-m), of beta_m(z) -- the order Horner's rule walks them in; entry (m, j) sits at shf_toff(m) + K-1-j.",
               "// The moment buffer of annp_fe_desc_sh has the same order: (cosine, sine) of (l = m+k, m) at 2 (shf_toff(m) + K-1-k).",
@@ -189,9 +171,6 @@ def render():
               "#define ANNP_SHD_INFO_INIT { " + ", ".join(str(v) for row in tail_tables()[0] for v in row) + " }",
               "#define ANNP_SHD_KAPPA_INIT { \\"] + ["    " + ", ".join(float(v).hex() for v in row) + ", \\" for row in tail_tables()[1]] + ["}",
               "#define ANNP_SHD_COEF_INIT { \\"] + ["    " + ", ".join(float(v).hex() for v in row) + ", \\" for row in tail_tables()[2]] + ["}", "",
-              "// z^k = sum_l ml[k][l] P_l(z): the network pass hands the angular polynomial over in powers of z (coef), the force",
-              "// pass wants it in Legendre polynomials, W_l = sum_k p_k ml[k][l]",
-              "#define ANNP_SH_ML_INIT { \\"] + ["    " + ", ".join(float(v).hex() for v in (mono_to_legendre(k) + [Fr(0)] * (L - k))) + ", \\" for k in range(L + 1)] + ["}", "",
               "// q[n][l]: T_n((z+1)/2) = sum_{l<=n} q[n][l] P_l(z)",
               "#define ANNP_SH_Q_INIT { \\"]
     for n in range(L + 1):
