@@ -587,23 +587,29 @@ __global__ __launch_bounds__(256, 3) void annp_fe_desc_sh(FeArgs p)
     // complete before the first load is issued)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the fences of this scope leave the stores' completion to the hardware's ordering: say it)
     wave_lds_sync();
     {
         double2 *mom = reinterpret_cast<double2 *>(wbase);
         const unsigned long long deadmask = __ballot(dead);
+        constexpr int NU = (SHF_NE + 63) / 64;
+        double2 q[SH_GA][NU];
+        // a row nobody wrote (no such atom, or one that went to the fix-up queue) reads as zeros: its neighbour in LDS multiplies
+        // a few of its entries by zero (sh_legendre).  All twelve loads first, then the twelve writes: one trip, not twelve.
 #pragma unroll
         for (int ga = 0; ga < SH_GA; ga++) {
-            // a row nobody wrote (no such atom, or one that went to the fix-up queue) reads as zeros: its neighbour in LDS multiplies
-            // a few of its entries by zero (sh_legendre)
             const bool ok = ((deadmask >> (4 * ga)) & 1ull) == 0;
             const double2 *row = reinterpret_cast<const double2 *>(w.Abase + (size_t)(ok ? ga : 0) * SH_MPAD);
 #pragma unroll
-            for (int u = 0; u < (SHF_NE + 63) / 64; u++) {
+            for (int u = 0; u < NU; u++) q[ga][u] = row[min(lane + 64 * u, SHF_NE - 1)];
+        }
+#pragma unroll
+        for (int ga = 0; ga < SH_GA; ga++) {
+            const bool ok = ((deadmask >> (4 * ga)) & 1ull) == 0;
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
                 const int pos = lane + 64 * u;
-                if (pos < SHF_NE) {
-                    const double2 q = row[pos];
-                    mom[ga * SHF_NE + pos] = ok ? q : make_double2(0.0, 0.0);
-                }
+                if (pos < SHF_NE) mom[ga * SHF_NE + pos] = ok ? q[ga][u] : make_double2(0.0, 0.0);
             }
         }
         // ... and behind the wave's last atom pw -- or, where the neighbour arrays are longer than the moments, whatever they held
