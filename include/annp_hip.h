@@ -284,7 +284,9 @@ int annp_hip_eval_info(annp_hip_handle *handle, int *info4);
  * atom_modify sort, the default) needs ~18 memory requests per atom for them, atoms in random order 113 and up to 2.3 times
  * the time of that pass (results are the same).  The notice appears when more than eight contributions per atom found no bucket. */
 int annp_hip_eval_path(annp_hip_handle *handle);
-/* `file` is a FILE * (or NULL: silent, the default).  One line per event, prefixed "annp/hip:". */
+/* `file` is a FILE * (or NULL: silent, the default).  One line per event, prefixed "annp/hip:".  The library keeps the pointer and
+ * writes to it from whichever call notices the event: pass NULL (or clear the handle, as annp_gpu_clear does)
+ * before closing the file. */
 int annp_hip_set_notice(annp_hip_handle *handle, void *file);
 
 /* Kernel timing with HIP events recorded on the stream the kernels are launched on.
