@@ -337,6 +337,9 @@ struct ShfBuild {
     {
         if constexpr (M >= 0) {
             shf_convert_column<M>(tb, dump, conv, l);
+#ifdef SHP_FENCE_COLUMNS
+            asm volatile("" ::: "memory");
+#endif
             ShfBuild<WQ, IDX + 1>::convert(tb, dump, conv, l);
         }
     }
@@ -350,18 +353,21 @@ struct ShfBuild<WQ, 8> {
 
 // a wave's neighbours of a lane: geometry and radial term (fe:648), U and grad U from the table, force assembly (fe:190-213),
 // into the force table.  Nothing in here waits for memory.
-template <int NP, int CC, bool VIRIAL>
-__device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, const int a0, const int (&jn)[SHF_CC], const double (&dx)[SHF_CC],
+// `mid` runs between the columns and the force assembly (the persistent kernel issues the next unit's position loads there).
+struct ShfNoMid { __device__ __forceinline__ void operator()() const {} };
+template <int NP, int CC, bool VIRIAL, class Mid = ShfNoMid>
+__device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, const bool (&has_nbr)[SHF_CC], const int (&jn)[SHF_CC], const double (&dx)[SHF_CC],
                                          const double (&dy)[SHF_CC], const double (&dz)[SHF_CC], const double *crl, const double pi_over_rc,
-                                         const double two_over_rcp, const unsigned tb, const ShfTable &tab, double (&fi)[3], double (&vs)[6])
+                                         const double two_over_rcp, const unsigned tb, const ShfTable &tab, double (&fi)[3], double (&vs)[6],
+                                         const Mid &mid = Mid())
 {
     // F_n = e [ al (e . grad U) - be U + g0 ] - al grad U  with e = (wx, wy, z), al = fc / r, be = fc', g0 = -R + P(1) fc fc'
     double z[CC], wx[CC], wy[CC], al[CC], be[CC], g0[CC], rr[VIRIAL ? CC : 1];
 #pragma unroll
     for (int u = 0; u < CC; u++) {
-        const bool has = a0 + SHF_GL * u < at.n;
-        double2 R0 = make_double2(dx[u], dy[u]), R1 = make_double2(dz[u], dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u]);
-        if (!has) { R0 = make_double2(0.0, 0.0); R1 = make_double2(1.0, 1.0); }
+        // (a slot without a neighbour holds the centre's own position: r = 0, and what follows from it in that lane -- infinities,
+        // NaNs -- stays in that lane and is dropped where the forces are assembled)
+        const double2 R0 = make_double2(dx[u], dy[u]), R1 = make_double2(dz[u], dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u]);
         const FeNbr g = sh_geometry(R0, R1, pi_over_rc);
         const double xr = g.r * two_over_rcp - 1.0;
         const double y2 = 2.0 * xr;
@@ -379,9 +385,9 @@ __device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, con
         }
         const double R = fma(sd * two_over_rcp, g.fc, st * g.dfc);        // d/dr of the radial part
         z[u] = g.ez; wx[u] = g.ex; wy[u] = g.ey;
-        al[u] = has ? g.fc * g.rinv : 0.0;
-        be[u] = has ? g.dfc : 0.0;
-        g0[u] = has ? fma(at.pone * g.fc, g.dfc, -R) : 0.0;
+        al[u] = g.fc * g.rinv;
+        be[u] = g.dfc;
+        g0[u] = fma(at.pone * g.fc, g.dfc, -R);
         if (VIRIAL) rr[u] = g.r;
         // one neighbour after the other (the sine and cosine series of one are two independent chains, and three other waves share
         // the SIMD); both at once is where the 128 registers of a wave run out
@@ -394,9 +400,10 @@ __device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, con
 #else
     shf_evaluate<CC>(tb, z, wx, wy, U, Ux, Uy, Uz);
 #endif
+    mid();
 #pragma unroll
     for (int u = 0; u < CC; u++) {
-        if (a0 + SHF_GL * u < at.n) {
+        if (has_nbr[u]) {
             const double ed = fma(wx[u], Ux[u], fma(wy[u], Uy[u], z[u] * Uz[u]));
             const double t = fma(al[u], ed, fma(-be[u], U[u], g0[u]));
             const double f0 = fma(t, wx[u], -al[u] * Ux[u]);
@@ -530,8 +537,11 @@ __global__ __launch_bounds__(64 * SHF_WAVES, 4) void annp_fe_force_sh(FeArgs p)
     if (cc > 0) {
         at.pone = crl[NP];
         double fi[3] = {0.0, 0.0, 0.0}, vs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (cc == 1) shf_turn<NP, 1, VIRIAL>(p, at, a0, jn, dx, dy, dz, crl, pi_over_rc, two_over_rcp, tb, tab, fi, vs);
-        else shf_turn<NP, 2, VIRIAL>(p, at, a0, jn, dx, dy, dz, crl, pi_over_rc, two_over_rcp, tb, tab, fi, vs);
+        bool has_nbr[SHF_CC];
+#pragma unroll
+        for (int u = 0; u < SHF_CC; u++) has_nbr[u] = a0 + SHF_GL * u < at.n;
+        if (cc == 1) shf_turn<NP, 1, VIRIAL>(p, at, has_nbr, jn, dx, dy, dz, crl, pi_over_rc, two_over_rcp, tb, tab, fi, vs);
+        else shf_turn<NP, 2, VIRIAL>(p, at, has_nbr, jn, dx, dy, dz, crl, pi_over_rc, two_over_rcp, tb, tab, fi, vs);
         SHF_STAMP(5);
         // ---- the centre's share: sums over the atom's 16 lanes end up in the row's last lane
 #pragma unroll
