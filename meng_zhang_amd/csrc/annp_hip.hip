@@ -30,7 +30,6 @@
 #include "annp_common.hpp"
 #include "fe_sh_kernels.hpp"
 #include "fe_shf_kernels.hpp"
-#include "fe_shp_kernels.hpp"
 #include "mlp_kernels.hpp"
 #include "neigh_kernels.hpp"
 #include "ni_kernels.hpp"
@@ -129,9 +128,7 @@ struct annp_hip_handle {
     int sh_cap = SH_CAP_MAX;            // Chebyshev descriptor pass (annp_fe_desc_sh): state slots per atom for the next evaluation
     bool fe_desc_pairs = false;         // ANNP_HIP_FE_DESC=pairs: the pair-loop descriptor kernel (annp_fe_desc) for every atom
     bool fe_force_pairs = false;        // ANNP_HIP_FE_FORCE=pairs: the pair-loop force kernel (annp_fe_force) for every atom
-    bool fe_force_r4 = true;            // ANNP_HIP_FE_FORCE=walk: annp_fe_force_shp (a workgroup walks a run of units, fe_shp_kernels.hpp) instead of annp_fe_force_sh -- measured 3 % slower, developer A/B switch
-    int shp_roles_by_number = 0;        // ANNP_HIP_SHP_ROLES=number: the light wave of a group is its fourth wave, wherever it sits (developer A/B switch)
-    int shp_run = 0;                    // ANNP_HIP_SHP_RUN: units a workgroup of annp_fe_force_shp walks (0: chosen from the size)
+    int shf_places_by_number = 0;       // ANNP_HIP_SHF_PLACES=number: the one-slot wave of a group is its fourth wave, wherever it sits (developer A/B switch)
     FILE *notice = nullptr;             // annp_hip_set_notice: where a change of kernel path is announced (once per change)
     bool fe_dense_said = false;
     int sh_cap_used = 0;                // state slots the last annp_fe_desc_sh launch had (= atoms with moments have at most that many neighbours)
@@ -551,8 +548,8 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     if ((rc = poll_flags(h, false))) return rc;      // an error of an earlier evaluation, reported once
     if (inum <= 0) return 0;
     if ((rc = ensure(h, h->G, (size_t)inum * ANNP_GPAD))) return rc;
-    // (coefficient rows start out as zeros, and there are rows behind the last list entry's: annp_fe_force_shp copies the rows of a
-    // group of four entries into LDS whether the network pass wrote them or not, fe_shp_kernels.hpp)
+    // (coefficient rows start out as zeros, and there are rows behind the last list entry's: the force pass multiplies a few entries of
+    // a neighbouring row by zero: they must be numbers, whether the network pass wrote them or not)
     if ((rc = ensure(h, h->coef, (size_t)(inum + SHF_GA) * ANNP_CPAD, true))) return rc;
     if ((rc = ensure(h, h->ncount, (size_t)inum))) return rc;
     if (h->reset_err) {
@@ -625,18 +622,11 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             a.ovf_count = h->d_flags + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
             if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
             a.tab_spills = h->d_flags + 4;
-            if (!h->fe_force_r4) {
-                // a workgroup walks a run of units (fe_shp_kernels.hpp): long enough that its start-up is paid seldom, short enough
-                // that the grid still has many rounds of workgroups to even out (512 are resident)
-                const int nunits = (inum + SHF_GROUPS * SHF_GA - 1) / (SHF_GROUPS * SHF_GA);
-                int run = h->shp_run > 0 ? h->shp_run : std::min(16, std::max(1, nunits / 4096));
-                a.shp_run = run;
-                a.shp_roles_by_number = h->shp_roles_by_number;
-                a.shp_pi_over_rc = ANNP_MY_PI / a.rc_list; a.shp_two_over_rcp = 2.0 / a.rc_par;
-                const int blocks = (nunits + run - 1) / run;
-                if (vir) hipLaunchKernelGGL((annp_fe_force_shp<FE_NP, FE_NT, true>), dim3(blocks), dim3(64 * SHF_WAVES), shp_lds_per_block(), s, a);
-                else hipLaunchKernelGGL((annp_fe_force_shp<FE_NP, FE_NT, false>), dim3(blocks), dim3(64 * SHF_WAVES), shp_lds_per_block(), s, a);
-            } else {
+            a.shf_places_by_number = h->shf_places_by_number;
+            {
+#ifdef ANNP_SHF_CHECK
+                a.chk_nall = nall;                          // (developer build: the kernel checks its indices against it)
+#endif
                 const int apb = SHF_GROUPS * SHF_GA;        // atoms per workgroup
                 if (vir) hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, true>), dim3((inum + apb - 1) / apb), dim3(64 * SHF_WAVES), shf_lds_per_block(), s, a);
                 else hipLaunchKernelGGL((annp_fe_force_sh<FE_NP, FE_NT, false>), dim3((inum + apb - 1) / apb), dim3(64 * SHF_WAVES), shf_lds_per_block(), s, a);
@@ -1023,9 +1013,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (const char *e = std::getenv("ANNP_HIP_NI_PAIRS")) h->ni_no_pairs = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_NI_FIXUP")) h->ni_no_fixup = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_FE_DESC")) h->fe_desc_pairs = std::strcmp(e, "pairs") == 0;
-    if (const char *e = std::getenv("ANNP_HIP_FE_FORCE")) { h->fe_force_pairs = std::strcmp(e, "pairs") == 0; h->fe_force_r4 = std::strcmp(e, "walk") != 0; }
-    if (const char *e = std::getenv("ANNP_HIP_SHP_ROLES")) h->shp_roles_by_number = std::strcmp(e, "number") == 0;
-    if (const char *e = std::getenv("ANNP_HIP_SHP_RUN")) h->shp_run = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("ANNP_HIP_FE_FORCE")) h->fe_force_pairs = std::strcmp(e, "pairs") == 0;
+    if (const char *e = std::getenv("ANNP_HIP_SHF_PLACES")) h->shf_places_by_number = std::strcmp(e, "number") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SH_WPB")) h->sh_wpb = std::min(4, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("ANNP_HIP_SH_CAP")) h->sh_cap = std::min((int)SH_CAP_MAX, std::max((int)SH_CAP_MIN, round_up(std::atoi(e), 16)));
     h->cutsq = cutsq_all;
@@ -1243,8 +1232,6 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc_fixup<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh<FE_NP, FE_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh<FE_NP, FE_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
-        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_shp<FE_NP, FE_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
-        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_shp<FE_NP, FE_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force<FE_NP, FE_NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));

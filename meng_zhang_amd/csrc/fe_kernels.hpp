@@ -64,9 +64,8 @@ struct FeArgs {
     double *A;
     int *nbrs;                 // nullable [inum][128]: the in-cutoff neighbours of every atom in list order, annp_fe_desc_sh -> annp_fe_force_sh
     int *tab_spills;           // nullable device int: contributions annp_fe_force_sh's force tables had no bucket for
-    int shp_run;               // annp_fe_force_shp: units of eight atoms a workgroup walks
-    int shp_roles_by_number;   // ... and (developer A/B switch) roles by wave number instead of by SIMD
-    double shp_pi_over_rc, shp_two_over_rcp;      // ... and pi / rc_list, 2 / rc_par from the host (kernel arguments are scalar registers)
+    int shf_places_by_number;  // annp_fe_force_sh (developer A/B switch): the one-slot wave of a group by wave number, not by SIMD
+    int chk_nall;              // ... (developer build -DANNP_SHF_CHECK) nall, to check indices against
 };
 
 // LDS layout of one wave.  A record is two 16-byte halves (e_x,e_y) and (e_z,fc), kept in two

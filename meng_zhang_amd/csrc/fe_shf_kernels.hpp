@@ -51,10 +51,14 @@ __constant__ double annp_shf_conv[SHF_CONV_NREC * 16] = ANNP_SHF_CONV_INIT;
 
 // LDS of a workgroup: the force table | per group: the four tables + 32 bytes of slack (look-ahead reads, idle lanes' writes) |
 // per wave: c_m [9] and P(1) of its four atoms
+// (round 5: 256 bytes of zeros in front of the first group's tables -- the change of basis reads up to 240 bytes below a table with
+// a zero coefficient, and what lies there must be a finite number -- and per wave 1 KB where the lanes that have nothing to
+// write write, a slot each)
 constexpr int SHF_WPAD = 10;
-__host__ __device__ constexpr size_t shf_lds_table() { return (size_t)SHF_NBUCK * (SHF_BATOMS * 24 + 16); }
+constexpr int SHF_ZPAD = 256, SHF_DUMP = 1024;
+__host__ __device__ constexpr size_t shf_lds_table() { return (size_t)SHF_NBUCK * (SHF_BATOMS * 24 + 16) + SHF_ZPAD; }
 __host__ __device__ constexpr size_t shf_lds_per_group() { return (size_t)SHF_GA * SHF_TBYTES + 32; }
-__host__ __device__ constexpr size_t shf_lds_per_wave() { return (size_t)SHF_GA * SHF_WPAD * 8; }
+__host__ __device__ constexpr size_t shf_lds_per_wave() { return (size_t)SHF_GA * SHF_WPAD * 8 + SHF_DUMP; }
 __host__ __device__ constexpr size_t shf_lds_per_block() { return shf_lds_table() + SHF_GROUPS * shf_lds_per_group() + SHF_WAVES * shf_lds_per_wave(); }
 static_assert(shf_lds_per_group() % 16 == 0 && shf_lds_table() % 16 == 0, "b128 alignment of every group's tables");
 
@@ -76,8 +80,14 @@ struct ShfTable {
     int *key;          // [SHF_NBUCK]: index >> 3 of the bucket's atoms, -1 = free; key[SHF_NBUCK]: contributions that found no bucket
     double *acc;       // [SHF_NBUCK][8][3]
     double *f;
+#ifdef ANNP_SHF_CHECK      // developer build: every index that comes from data is checked against nall, a bad one is reported through the error word instead of used
+    int nall; int *err;
+#endif
     __device__ __forceinline__ void add(int j, double fx, double fy, double fz) const
     {
+#ifdef ANNP_SHF_CHECK
+        if ((unsigned)j >= (unsigned)nall) { atomicMax(err, 3000000 + (blockIdx.x & 0xffff)); return; }
+#endif
         const int b = j >> 3;
         unsigned h = ((unsigned)b * 0x9E3779B1u) >> (32 - SHF_BBITS);
 #pragma unroll 1
@@ -119,6 +129,10 @@ struct ShfTable {
             for (int it = 0; it < SHF_NBUCK / PB; it++) {
                 const int b = key[h0 + PB * it];
                 const double v = acc[tid + PB * SHF_BATOMS * 3 * it];
+#ifdef ANNP_SHF_CHECK
+                if (b >= 0 && v != 0.0 && (size_t)b * (SHF_BATOMS * 3) + r >= (size_t)nall * 3) { atomicMax(err, 4000000 + (h0 + PB * it) * 1000 + (tid & 511)); continue; }
+                if (b < -1) { atomicMax(err, 5000000 + (h0 + PB * it)); continue; }
+#endif
                 if (b >= 0 && v != 0.0) atomicAdd(&f[(size_t)b * (SHF_BATOMS * 3) + r], v);
             }
         }
@@ -351,6 +365,77 @@ struct ShfBuild<WQ, 8> {
     static __device__ __forceinline__ void convert(const unsigned, const unsigned, const double *, const int) {}
 };
 
+// ---- the change of basis, round 5: every address an immediate.  Power k of column M sits at tb + 16 (toff(M) + K-1-k); lane l
+// reads the powers BLK + l + 2t at tl + 16 (toff(M) + K-1-BLK) - 32 t, tl = tb - 16 l, and writes power BLK + l.  A lane without
+// the power, or past the column's top, reads up to 240 bytes below its column -- the column before, the table before, the zeros
+// in front of the first table: finite numbers all (every wave of the workgroup has staged its columns: the barrier in front) --
+// with a zero coefficient; round 4 clamped each address into the column instead (two instructions per term, as many as the
+// arithmetic) and took the coefficients through per-term 64-bit address sums (four more).  Now a term is its two multiply-adds.
+// No branch around a write (the compiler sinks the reads into it and waits for each where it is used): a lane that has nothing
+// to write writes its slot of the wave's dump.  And the order is pinned -- coefficients of a piece requested while the piece
+// before is worked on, a piece's reads together -- because under this kernel's register limit the compiler otherwise issues one
+// read, waits, issues the next.
+typedef const double __attribute__((address_space(1))) *shf_gcp;
+typedef const char __attribute__((address_space(1))) *shf_gbp;
+typedef __attribute__((address_space(3))) shf_v2d *shf_tab_wptr;
+// lanes l < n of every atom, as an execution mask turned select (no compare: a literal in scalar registers)
+__device__ __forceinline__ bool shf_lanes_below(const int n)
+{
+    const unsigned long long m16 = n >= 16 ? 0xffffull : ((1ull << n) - 1ull);
+    return __builtin_amdgcn_inverse_ballot_w64(m16 * 0x0001000100010001ull);
+}
+struct ShfPiece { int m, blk; };         // the powers blk .. blk + 15 of column m
+constexpr int SHF_WNP[SHF_GW] = {5, 5, 5, 7};
+constexpr ShfPiece SHF_WPIECE[SHF_GW][7] = {{{0, 0}, {0, 16}, {5, 0}, {9, 0}, {15, 0}, {-1, 0}, {-1, 0}},
+                                            {{1, 0}, {1, 16}, {4, 0}, {10, 0}, {13, 0}, {-1, 0}, {-1, 0}},
+                                            {{2, 0}, {2, 16}, {3, 0}, {11, 0}, {12, 0}, {-1, 0}, {-1, 0}},
+                                            {{6, 0}, {7, 0}, {8, 0}, {14, 0}, {16, 0}, {17, 0}, {18, 0}}};
+constexpr int SHF_MAXT = (SH_LMAX + 2) / 2;          // terms of the longest piece
+template <int WQ, int P>
+struct ShfConv {
+    static constexpr int M = SHF_WPIECE[WQ][P].m, BLK = SHF_WPIECE[WQ][P].blk;
+    static constexpr int K = SH_LMAX + 1 - M;
+    static constexpr int first = SHF_CONV_FIRST[M][BLK / 16];
+    static constexpr int nt = (K - BLK + 1) / 2;
+    static constexpr unsigned a0 = 16u * (unsigned)(shf_toff(M) + K - 1 - BLK);
+    static_assert(a0 + 32u >= 32u * nt && nt <= SHF_MAXT, "no read below the column before");
+    static __device__ __forceinline__ void request(const shf_gbp convl, double (&mv)[SHF_MAXT])
+    {
+#pragma unroll
+        for (int t = 0; t < nt; t++) mv[t] = *(shf_gcp)(convl + (first + t) * 128);        // 0 where l + 2t > K-1
+    }
+};
+template <int WQ, int P>
+__device__ __forceinline__ void shf_convert_pieces(const unsigned tl, const unsigned dump, const shf_gbp convl, const double (&mv)[SHF_MAXT])
+{
+    if constexpr (P < SHF_WNP[WQ]) {
+        typedef ShfConv<WQ, P> C;
+        double mvn[SHF_MAXT];
+        if constexpr (P + 1 < SHF_WNP[WQ]) ShfConv<WQ, P + 1>::request(convl, mvn);
+        shf_v2d b[C::nt];
+#pragma unroll
+        for (int t = 0; t < C::nt; t++) b[t] = *(shf_tab_ptr)(uintptr_t)(tl + C::a0 - 32u * (unsigned)t);
+        __builtin_amdgcn_sched_barrier(0);
+        double ax = 0.0, ay = 0.0;
+#pragma unroll
+        for (int t = 0; t < C::nt; t++) { ax = fma(mv[t], b[t].x, ax); ay = fma(mv[t], b[t].y, ay); }
+        shf_v2d r; r.x = ax; r.y = ay;
+        *(shf_tab_wptr)(uintptr_t)(shf_lanes_below(C::K - C::BLK) ? tl + C::a0 : dump) = r;
+        __builtin_amdgcn_sched_barrier(0);
+        shf_convert_pieces<WQ, P + 1>(tl, dump, convl, mvn);
+    }
+}
+template <int WQ>
+__device__ __forceinline__ void shf_convert_wave(const unsigned tb, const unsigned dump, const int l)
+{
+    unsigned long long cb = (unsigned long long)(const void *)annp_shf_conv;
+    asm volatile("" : "+s"(cb));            // (one base in scalar registers and immediate offsets)
+    const shf_gbp convl = (shf_gbp)cb + (unsigned long long)(8u * (unsigned)l);
+    double mv[SHF_MAXT];
+    ShfConv<WQ, 0>::request(convl, mv);
+    shf_convert_pieces<WQ, 0>(tb - 16u * (unsigned)l, dump, convl, mv);
+}
+
 // a wave's neighbours of a lane: geometry and radial term (fe:648), U and grad U from the table, force assembly (fe:190-213),
 // into the force table.  Nothing in here waits for memory.
 // `mid` runs between the columns and the force assembly (the persistent kernel issues the next unit's position loads there).
@@ -442,16 +527,47 @@ __global__ __launch_bounds__(64 * SHF_WAVES, 4) void annp_fe_force_sh(FeArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
-    const int grp = wave / SHF_GW, wq = wave % SHF_GW;               // the wave's group in the workgroup, its place in the group
+    const int grp = wave / SHF_GW;                                   // the wave's group in the workgroup
+    // ---- its place in the group: which two neighbour slots of a lane, which columns of the table.  bcc Fe has 16 x 7 neighbours, so
+    // place 3 has ONE slot, half the columns' work of the others -- and the hardware deals a workgroup's eight waves over the CU's
+    // four SIMDs in a fixed pattern (waves w and w + 4 share a SIMD, the four waves of a group sit on four SIMDs: measured,
+    // round 5), so with the place tied to the wave's number both light waves of a workgroup sit on one SIMD and three SIMDs carry
+    // heavy waves only.  The place follows the SIMD the wave finds itself on instead: the two workgroups resident on a CU
+    // (thread-group slots 0 and 1) put their light waves on SIMDs 0, 1 and 2, 3 -- one light and three heavy waves per SIMD.
+    // Nothing depends on that pattern for its result: the waves of a group say which place they took, and if the four places
+    // are not all there the wave's number decides, as in round 4.
+    int wq = wave % SHF_GW;
+    {
+        const unsigned hwid = __builtin_amdgcn_s_getreg(0xF804);                 // HW_ID: SIMD [5:4], thread-group slot [19:16]
+        const int place = ((int)(hwid >> 4) - (((int)(hwid >> 16) & 15) * SHF_GROUPS + grp) + 3) & 3;     // 3: the light wave
+        int *said = reinterpret_cast<int *>(lds_raw);                            // (the force table's first words: cleared behind the next barrier)
+        if (lane == 0) said[wave] = place;
+        __syncthreads();
+        int seen = 0;
+#pragma unroll
+        for (int k = 0; k < SHF_WAVES; k++) seen |= 1 << ((k / SHF_GW) * SHF_GW + (said[k] & 3));
+        const bool all_there = seen == (1 << SHF_WAVES) - 1;
+        // (the "& 3" behind the read is for the compiler: with a place it knows nothing about, hipcc 7.2 built the switches below
+        // wrongly -- the fourth place's first moment loads went out from registers nobody had written: a memory fault, round 5)
+        if (uniform(all_there) && !p.shf_places_by_number) wq = uniform(place) & 3;
+    }
     ShfTable tab;
     tab.key = reinterpret_cast<int *>(lds_raw + (size_t)SHF_NBUCK * SHF_BATOMS * 24);
     tab.acc = reinterpret_cast<double *>(lds_raw);
     tab.f = p.f;
+#ifdef ANNP_SHF_CHECK
+    tab.nall = p.chk_nall; tab.err = p.errflag;
+#endif
     unsigned char *gbase = lds_raw + shf_lds_table() + (size_t)grp * shf_lds_per_group();
     const int g = lane >> 4, l = lane & 15;
     double2 *T = reinterpret_cast<double2 *>(gbase + (size_t)g * SHF_TBYTES);
-    double2 *dump = reinterpret_cast<double2 *>(gbase + (size_t)SHF_GA * SHF_TBYTES) + 1;      // (the slack behind the group's tables)
-    double *crl = reinterpret_cast<double *>(lds_raw + shf_lds_table() + SHF_GROUPS * shf_lds_per_group() + (size_t)wave * shf_lds_per_wave()) + g * SHF_WPAD;
+    unsigned char *wbase = lds_raw + shf_lds_table() + SHF_GROUPS * shf_lds_per_group() + (size_t)wave * shf_lds_per_wave();
+    double *crl = reinterpret_cast<double *>(wbase) + g * SHF_WPAD;
+    double2 *dump = reinterpret_cast<double2 *>(wbase + (size_t)SHF_GA * SHF_WPAD * 8) + lane;     // this lane's slot of the wave's dump
+    // the zeros in front of the first table, and the slack behind each group's tables (the change of basis reads them with a zero
+    // coefficient: they must be numbers)
+    if (threadIdx.x < SHF_ZPAD / 8) reinterpret_cast<double *>(lds_raw + shf_lds_table() - SHF_ZPAD)[threadIdx.x] = 0.0;
+    if (wq == 0 && lane < 4) reinterpret_cast<double *>(gbase + (size_t)SHF_GA * SHF_TBYTES)[lane] = 0.0;
     const double pi_over_rc = ANNP_MY_PI / p.rc_list;
     const double two_over_rcp = 2.0 / p.rc_par;
 
@@ -490,7 +606,6 @@ __global__ __launch_bounds__(64 * SHF_WAVES, 4) void annp_fe_force_sh(FeArgs p)
     am_w[1] = cf[NP + NT + max(2 - l, 0)];                             // ... of p = 16 + lane (lanes 0..2)
     const double c_l = cf[l < NP ? l : NP + 2 * NT];                   // c_m, m = lane; lanes >= 9: P(1)
     at.xi = p.x[3 * (size_t)at.i]; at.yi = p.x[3 * (size_t)at.i + 1]; at.zi = p.x[3 * (size_t)at.i + 2];
-    tab.clear(threadIdx.x);
     if (!exists) at.n = 0;
     if (p.type && !type_mapped(p.active, p.type[at.i])) at.n = 0;
     if (at.n > p.n_cap) {            // no moments for this atom: the pair loop takes it (annp_fe_force_fixup)
@@ -511,24 +626,37 @@ __global__ __launch_bounds__(64 * SHF_WAVES, 4) void annp_fe_force_sh(FeArgs p)
 #pragma unroll
     for (int u = 0; u < SHF_CC; u++) {
         if (!(a0 + SHF_GL * u < at.n)) jn[u] = at.i;
+#ifdef ANNP_SHF_CHECK
+        if ((unsigned)jn[u] >= (unsigned)p.chk_nall) { atomicMax(p.errflag, 2000000 + (blockIdx.x & 0xffff)); jn[u] = 0; }
+#endif
         dx[u] = at.xi - p.x[3 * (size_t)jn[u]]; dy[u] = at.yi - p.x[3 * (size_t)jn[u] + 1]; dz[u] = at.zi - p.x[3 * (size_t)jn[u] + 2];
     }
     if (l <= NP) crl[l] = c_l;                                         // [0..8] c_m, [9] P(1)
     // ---- the wave's columns of the table: B = W kappa A, then the change of basis in place
     const unsigned tb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)T;
-    if (nmax > 0) {
-        const unsigned dumpb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)dump;
-        const double *conv = annp_shf_conv;
-        asm volatile("" : "+s"(conv));          // (one base in scalar registers and immediate offsets, not a program-counter relative address per load)
+    const unsigned dumpb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)dump;
+    {
+        // (a group without a single neighbour stages zeros: its tables are what the next group's change of basis reads below its own)
         if (at.n == 0) {
 #pragma unroll
             for (int k = 0; k < SHF_NSTAGE; k++) am[k] = make_double2(0.0, 0.0);
         }
         switch (wq) {
-        case 0: ShfBuild<0, 0>::stage(T, dump, l, am_w, am); wave_lds_sync(); SHF_STAMP(2); ShfBuild<0, 0>::convert(tb, dumpb, conv, l); break;
-        case 1: ShfBuild<1, 0>::stage(T, dump, l, am_w, am); wave_lds_sync(); SHF_STAMP(2); ShfBuild<1, 0>::convert(tb, dumpb, conv, l); break;
-        case 2: ShfBuild<2, 0>::stage(T, dump, l, am_w, am); wave_lds_sync(); SHF_STAMP(2); ShfBuild<2, 0>::convert(tb, dumpb, conv, l); break;
-        default: ShfBuild<3, 0>::stage(T, dump, l, am_w, am); wave_lds_sync(); SHF_STAMP(2); ShfBuild<3, 0>::convert(tb, dumpb, conv, l); break;
+        case 0: ShfBuild<0, 0>::stage(T, dump, l, am_w, am); break;
+        case 1: ShfBuild<1, 0>::stage(T, dump, l, am_w, am); break;
+        case 2: ShfBuild<2, 0>::stage(T, dump, l, am_w, am); break;
+        default: ShfBuild<3, 0>::stage(T, dump, l, am_w, am); break;
+        }
+    }
+    SHF_STAMP(2);
+    __syncthreads();                                         // every column of every table is staged (and every wave has read who is who)
+    tab.clear(threadIdx.x);
+    if (nmax > 0) {
+        switch (wq) {
+        case 0: shf_convert_wave<0>(tb, dumpb, l); break;
+        case 1: shf_convert_wave<1>(tb, dumpb, l); break;
+        case 2: shf_convert_wave<2>(tb, dumpb, l); break;
+        default: shf_convert_wave<3>(tb, dumpb, l); break;
         }
     }
     SHF_STAMP(3);

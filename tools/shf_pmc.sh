@@ -4,8 +4,8 @@
 out=gpurun_out/$1
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for variant in new r4; do
-  if [ $variant = new ]; then export ANNP_HIP_FE_FORCE=walk; else unset ANNP_HIP_FE_FORCE; fi
+for variant in ${VARIANTS:-r5}; do
+  if [ $variant != r5 ]; then export ANNP_HIP_LIBRARY=$PWD/meng_zhang_amd/libannp_hip_$variant.so; else unset ANNP_HIP_LIBRARY; fi
   n=0
   for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \
              "SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS" \
@@ -16,10 +16,10 @@ for variant in new r4; do
         > $out/${variant}_pmc$n.json 2> $out/${variant}_pmc$n.err || { echo "pass $variant $n failed"; tail -5 $out/${variant}_pmc$n.err; exit 1; }
   done
 done
-python3 - $out <<'PY'
+python3 - $out ${VARIANTS:-r5} <<'PY'
 import collections, csv, glob, sys
 out = sys.argv[1]
-for variant in ("new", "r4"):
+for variant in sys.argv[2:] or ["r5"]:
     res = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob("%s/%s_pmc*/**/*counter_collection.csv" % (out, variant), recursive=True):
         for r in csv.DictReader(open(f)):
