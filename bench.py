@@ -52,10 +52,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 #     spectrum 3 x 190.
 #     Force pass (round 4: Horner's rule on monomial coefficients), per in-cutoff neighbour: columns of K >= 3 entries start with
 #     6 FMAs for three entries and take 4 FMAs per entry after that (16 x 6 + 4 x 120 = 576 FMAs), the two-entry column 2, the
-#     cosine-only column m = 0 3 + 2 x 16 = 35, Horner's rule in w 12 FMAs per column and 8 at the end (224): 837 FMAs = 1 674 flop;
+#     cosine-only column m = 0 3 + 2 x 16 = 35, Horner's rule in w 12 FMAs per column end (17 of them: behind m = 17 .. 1) and 8 at the end
+#     (212): 825 FMAs = 1 650 flop;
 #     geometry, radial T and T', force assembly 158.  Per atom: B = W kappa A 760, change of basis 1 430 FMAs = 2 860.
 FLOP_PAIR_DESC, FLOP_NBR_DESC, FLOP_ATOM_DESC = 0.0, 153 + (2 * 19 + 4 * 171) + 18 * 6 + 110.0, 7000.0 + 2 * 1430 + 3 * 190
-FLOP_PAIR_FORCE, FLOP_NBR_FORCE, FLOP_ATOM_FORCE = 0.0, 2 * (16 * 6 + 4 * 120 + 2 + 35 + 12 * 18 + 8) + 158.0, 760.0 + 2860.0
+FLOP_PAIR_FORCE, FLOP_NBR_FORCE, FLOP_ATOM_FORCE = 0.0, 2 * (16 * 6 + 4 * 120 + 2 + 35 + 12 * 17 + 8) + 158.0, 760.0 + 2860.0
 #     ... and the pair-loop kernels they replaced (ANNP_HIP_FE_DESC=pairs ANNP_HIP_FE_FORCE=pairs, or a system with more than
 #     128 neighbours per atom): pass 1: cos 5, weights 3, T_2..T_18 recurrence + accumulate 68; pass 3: cos 5, Horner P 36 +
 #     dP 34, dP fc_b 1, a-side 8, b-side 4
@@ -169,18 +170,23 @@ class Leg:
 
     def __init__(self, args, wl, cells, dev, tp, dry, local_rank, wire_self=False, wire_lib=False):
         import torch
-        from meng_zhang_amd.workloads import A_FE, A_NI, ANNA_POT, FE_POT, NI_POT, bcc, fcc, perturb
+        from meng_zhang_amd.workloads import A_FE, A_NI, ANNA_POT, FE_POT, NI_POT, bcc, fcc, load_fe_st, perturb
         from meng_zhang_amd.domain import SlabDomain
         self.args, self.wl, self.dev, self.dry, self.torch = args, wl, dev, dry, torch
         self.rc_list = 7.055 if wl == "anna" else 8.5
-        if wl == "ni":
-            x0, box = fcc(cells // 2, cells // 2, cells, A_NI)
+        periodic = (1, 1, 1)
+        if wl == "fe_st":                   # the reference's published deck: its own data file, `boundary m p m`, atoms in id order
+            xg, box = load_fe_st()
+            periodic = (0, 1, 0)
         else:
-            x0, box = bcc(cells, cells, cells, A_FE)
-        xg = perturb(x0, 12345, 0.05)
+            if wl == "ni":
+                x0, box = fcc(cells // 2, cells // 2, cells, A_NI)
+            else:
+                x0, box = bcc(cells, cells, cells, A_FE)
+            xg = perturb(x0, 12345, 0.05)
         self.natoms = xg.shape[0]
         self.potfile, element, style, self.mass = {"fe": (FE_POT, "Fe", "annp", 55.847), "ni": (NI_POT, "Ni", "annp", 58.6934),
-                                                   "anna": (ANNA_POT, "Fe", "anna_adp", 55.847)}[wl]
+                                                   "anna": (ANNA_POT, "Fe", "anna_adp", 55.847), "fe_st": (FE_POT, "Fe", "annp", 55.847)}[wl]
         self.lib = self.h = self.pair = None
         if not dry:
             from meng_zhang_amd import PairANNP
@@ -195,13 +201,15 @@ class Leg:
         if wire_lib:
             from meng_zhang_amd.domain import LibTransport
             tp = LibTransport(self.lib, self.h, tp, dev)
-        self.dom = SlabDomain.from_global(xg, box, (1, 1, 1), self.rc_list, dev, tp, extra={"v": np.zeros_like(xg)}, hip=hip, wire_self=wire_self)
+        self.dom = SlabDomain.from_global(xg, box, periodic, self.rc_list, dev, tp, extra={"v": np.zeros_like(xg)}, hip=hip, wire_self=wire_self)
         self.p_num, self.p_first, self.p_neigh, self.mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
         self.eng = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.vir = torch.zeros(6, dtype=torch.float64, device=dev) if wl == "fe_st" else None       # vflag_global of every NPT step
         ftm2v = 1.0 / 1.0364269e-4          # LAMMPS metal units: (eV/A)/(g/mol) -> A/ps^2
         self.dtf = 0.5 * args.dt * ftm2v / self.mass
         self.reissued = 0
         self.halo_marks = None              # when a list: (before, between, after) marks of the two exchanges of every step
+        self.mark_pool = []
         self.build_list()
 
     def stream(self):
@@ -224,10 +232,12 @@ class Leg:
         if self.dry:
             return
         d = self.dom
+        if self.vir is not None:
+            self.vir.zero_()
         for attempt in range(2):
             rc = self.lib.annp_hip_compute_device(self.h, d.nlocal, d.nall, d.x.data_ptr(), None, None, self.p_num, self.p_first,
-                                                  self.p_neigh, self.mx.value, d.f.data_ptr(), None, self.eng.data_ptr(), None, None,
-                                                  self.stream())
+                                                  self.p_neigh, self.mx.value, d.f.data_ptr(), None, self.eng.data_ptr(),
+                                                  self.vir.data_ptr() if self.vir is not None else None, None, self.stream())
             if rc == -7 and attempt == 0:       # a deferred Behler capacity error: the capacity has been raised, issue this one again
                 self.reissued += 1
                 continue
@@ -265,9 +275,17 @@ class Leg:
             return None
         if self.dry:
             return time.perf_counter()
-        ev = self.torch.cuda.Event(enable_timing=True)
+        if not self.mark_pool:              # (the events are made before the timed region, ADVICE r4: making four per step inside it is
+            ev = self.torch.cuda.Event(enable_timing=True)      # host time that the N = 8 steps of 1.5 ms would feel)
+        else:
+            ev = self.mark_pool.pop()
         ev.record(self.torch.cuda.current_stream(self.dev))
         return ev
+
+    def reserve_marks(self, steps):
+        """events for `steps` steps of marks, made ahead of the timed region"""
+        if not self.dry:
+            self.mark_pool = [self.torch.cuda.Event(enable_timing=True) for _ in range(4 * steps)]
 
     def halo_ms(self):
         """mean milliseconds per step in the forward and in the reverse exchange (device time between the marks)"""
@@ -360,6 +378,33 @@ def secondary_ni(args, dev, local_rank):
     return out
 
 
+def secondary_fe_st(args, dev, local_rank):
+    """The reference's own published deck as a short extra leg: fe_st.dat, 152 880 Fe atoms, `boundary m p m`
+    (free surfaces in x and z, ragged neighbour counts, atoms in the data file's id order), the global virial tallied every step
+    as the deck's `fix npt` has it, list built on the device.  BASELINE.md's only published throughput belongs to this
+    file: 85.4 k atom-steps/s on 2 GPUs of the reference's mixed-precision build (zip log_relaxing_new.lammps:1168-1176,
+    NPT, 1000 steps) -- another machine, another precision, an NPT integrator this leg does not run (it steps NVE with the
+    virial on): the figure stands beside the leg's, it is not a ratio."""
+    from meng_zhang_amd.domain import NoTransport
+    leg = Leg(args, "fe_st", 0, dev, NoTransport(), False, local_rank)
+    steps, warmup = 10, 2
+    dt, ms4, ns = leg.timed(steps, warmup)
+    n = leg.counts()
+    e, vir = float(leg.eng.item()), leg.vir.cpu().numpy()
+    out = {"workload": "fe_st.dat of the reference's performance test (%d Fe atoms, boundary m p m, id order), fe_annp_potential_2.ann, "
+                       "device-built list at 8.5 A, global virial every step, NVE dt = %g ps" % (leg.natoms, args.dt),
+           "value": leg.natoms * steps / dt, "unit": "atom-steps/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+           "kernel_ms": {"descriptor": float(ms4[0]), "network": float(ms4[1]), "force": float(ms4[2]), "evaluation": float(ms4[3]), "samples": ns},
+           "neighbors_in_cutoff_mean": float(n.mean()), "neighbors_in_cutoff_max": int(n.max()), "list_neighbors_max": int(leg.mx.value),
+           "energy_last_step_eV": e, "pressure_virial_last_step_bar": float(vir[:3].sum() / (3 * 1773495.9) * 1.6021765e6),
+           "eval_path": int(leg.lib.annp_hip_eval_path(leg.h)),
+           "reference_published": {"value": 85.4e3, "unit": "atom-steps/s", "n_gpus": 2, "precision": "mixed (reference GPU build)",
+                                   "run": "fix npt, 1000 steps", "source": "performance test.zip log_relaxing_new.lammps:1168-1176 (BASELINE.md)",
+                                   "note": "other hardware, other precision, NPT: shown beside this leg, no ratio is formed"}}
+    leg.close()
+    return out
+
+
 def main():
     run_rank(parse_args())
 
@@ -448,6 +493,7 @@ def run_rank(args):
     barrier()
     if not dry:
         check(lib.annp_hip_set_timing(h, 1), "set_timing")
+    leg.reserve_marks(args.steps)
     leg.halo_marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -674,7 +720,7 @@ def run_rank(args):
             except Exception as exc:    # the metric's line must not be lost to a baseline
                 out["cpu_baseline"]["matrix_error"] = repr(exc)
     out["config"]["evaluations_reissued"] = leg.reissued
-    # ---- BASELINE.json config 5 as a short second leg of the default run --------------------
+    # ---- BASELINE.json config 5, and the reference's published deck, as short extra legs of the default run ----
     if world == 1 and wl == "fe" and args.secondary and not use_dist:
         leg.close()
         del leg, dom
@@ -683,21 +729,32 @@ def run_rank(args):
             out["secondary"] = {"ni": secondary_ni(args, dev, local_rank)}
         except Exception as exc:        # the metric's line must not be lost to the extra leg
             out["secondary"] = {"ni": {"error": repr(exc)}}
+        torch.cuda.empty_cache()
+        try:                            # the reference's own published deck
+            out["secondary"]["fe_st"] = secondary_fe_st(args, dev, local_rank)
+        except Exception as exc:
+            out["secondary"]["fe_st"] = {"error": repr(exc)}
     _RESULT_LINE.append(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
 
 
-def _pmc_profile(natoms):
+def _pmc_profile(natoms, kernel=None, element=None):
     """the newest committed counter summary of this command at this size (profiles/r*_pmc_counters.json, written by
-    tools/summarise_profiles.py from tools/collect_profiles.sh's passes), or (None, None)"""
+    tools/summarise_profiles.py from tools/collect_profiles.sh's passes) that has an entry for `kernel` -- a run with the
+    pair-loop kernels finds the round that profiled them, not the newest file -- and names `element` in its workload;
+    or (None, None)"""
     import glob
     best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json"))):
         try:
             d = json.load(open(f))
-            if natoms is not None and str(natoms) in d.get("workload", "") and "anna" not in d.get("workload", ""):
-                best, src = d["per_launch_mean"], os.path.relpath(f, ROOT)
+            w = d.get("workload", "")
+            if natoms is None or str(natoms) not in w or "anna" in w or (element and element not in w):
+                continue
+            if kernel is not None and _pmc_kernel(d["per_launch_mean"], kernel) is None:
+                continue
+            best, src = d["per_launch_mean"], os.path.relpath(f, ROOT)
         except Exception:
             pass
     return best, src
@@ -715,7 +772,7 @@ def _pmc_traffic(kernel, natoms):
     (profiles/r*_pmc_counters.json: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950, i.e. the upper bound).  None when no matching profile exists:
     the counters cannot be read from inside an un-profiled run.  Returns (bytes, where they came from)."""
-    prof, f = _pmc_profile(natoms)
+    prof, f = _pmc_profile(natoms, kernel)
     e = _pmc_kernel(prof, kernel)
     if e is None:
         return None, None
@@ -727,7 +784,7 @@ def _pmc_extras(natoms, force_kernel):
     """What north_star asks rocprof to show, from the same committed passes: the shader clock the chip held under the force pass
     (GRBM_GUI_ACTIVE / 8 XCDs / the kernel's mean duration in the kernel trace of the same command), the descriptor pass's HBM
     bytes per second, the network pass's FP64-MFMA rate and matrix-pipe busy share.  Empty when no profile of this size exists."""
-    prof, f = _pmc_profile(natoms)
+    prof, f = _pmc_profile(natoms, force_kernel)
     out = {}
     e = _pmc_kernel(prof, force_kernel)
     if e and e.get("clock_GHz"):

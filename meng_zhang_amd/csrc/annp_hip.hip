@@ -373,11 +373,13 @@ void digest_flags(annp_hip_handle *h)
         }
         h->info[3] = (h->fe_dense || h->fe_desc_pairs || h->fe_force_pairs) ? h->fe_cap : h->sh_cap;     // capacity of the next force pass
         // The force table of annp_fe_force_sh keeps eight atoms with consecutive indices per bucket, and counts the contributions that
-        // found none (each is three memory requests, where a bucket leaves with three for all its contributions).  Eight per atom --
-        // 7 % of a bcc-Fe neighbourhood -- is where the pass starts to take visibly longer: the caller should know that sorting
-        // its atoms in space buys up to a factor 2.3 in that pass.
+        // found none (each is three memory requests, where a bucket leaves with three for all its contributions).  Measured at 1 M
+        // atoms (round 5, tools/kbench.py): atoms in the order LAMMPS' atom_modify sort leaves them (bins of half the neighbour
+        // cutoff, no order inside a bin) lose 12.8 contributions per atom that way and the pass 4 % (5.45 -> 5.67 ms); atoms in
+        // random order lose ~100 per atom and the pass takes 2.3 times as long.  The caller is told from 40 per atom on -- a third
+        // of a bcc-Fe neighbourhood: sorting its atoms in space then buys up to that factor.
         if (h->flags_sh) {
-            h->shf_scattered = h->h_flags[4] > 8 * (long long)h->flags_inum;
+            h->shf_scattered = h->h_flags[4] > 40 * (long long)h->flags_inum;
             if (h->shf_scattered != h->shf_scattered_said) {
                 h->shf_scattered_said = h->shf_scattered;
                 if (h->notice) {

@@ -34,7 +34,10 @@ constexpr int SHF_GL = 16;            // lanes per atom
 constexpr int SHF_GW = 4;             // waves per group
 constexpr int SHF_CC = 2;             // neighbours of a lane in a wave's registers: SHF_GW * SHF_CC * 16 = 128 slots per atom
 #ifndef ANNP_SHF_GROUPS
-#define ANNP_SHF_GROUPS 2
+#define ANNP_SHF_GROUPS 1
+#endif
+#ifndef ANNP_SHF_WPS
+#define ANNP_SHF_WPS 4          // resident waves per SIMD the kernel is compiled for
 #endif
 constexpr int SHF_GROUPS = ANNP_SHF_GROUPS;        // groups per workgroup
 constexpr int SHF_WAVES = SHF_GW * SHF_GROUPS;     // waves per workgroup
@@ -521,7 +524,7 @@ __device__ __forceinline__ void shf_turn(const FeArgs &p, const ShfAtom &at, con
 #endif
 
 template <int NP, int NT, bool VIRIAL>
-__global__ __launch_bounds__(64 * SHF_WAVES, 4) void annp_fe_force_sh(FeArgs p)
+__global__ __launch_bounds__(64 * SHF_WAVES, ANNP_SHF_WPS) void annp_fe_force_sh(FeArgs p)
 {
     static_assert(NT == SH_LMAX + 1 && NP + 2 * NT + 1 <= ANNP_CPAD && NP + 1 <= SHF_GL, "coefficient row: c_m | p_k | W_l | P(1)");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];

@@ -2,12 +2,14 @@
 create_atoms + atom_modify sort leave: atoms that are close in space are close in index) with counter-based displacements
 (element-wise splitmix64, so that any slice of a box can be generated without the rest), and where the
 potential files live.  No arithmetic of the hot path in here."""
+import gzip
 import os
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-POTENTIALS = os.path.join(ROOT, "tests", "golden", "potentials")      # the reference's own data files (MPL-2.0 notice beside them)
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")       # the reference's own data files (MPL-2.0 notice beside them)
+POTENTIALS = os.path.join(DATA, "potentials")
+FE_ST = os.path.join(DATA, "fe_st.dat.gz")        # the reference's published benchmark configuration (perf zip fe_st.dat, gzip)
 FE_POT = os.path.join(POTENTIALS, "fe_annp_potential_2.ann")
 NI_POT = os.path.join(POTENTIALS, "ni_annp_potential_2.ann")
 ANNA_POT = os.path.join(POTENTIALS, "fe_adp_potential_2310.anna")
@@ -54,3 +56,30 @@ def fcc(nx, ny, nz, a):
 def perturb(x, seed=12345, amp=0.05):
     u = uniform_counter(x.size, seed).reshape(x.shape)
     return x + (2.0 * u - 1.0) * amp
+
+
+def lammps_sort_order(x, box, binsize=4.25, seed=7):
+    """The order `atom_modify sort` (LAMMPS' default: every 1000 steps, bins of half the neighbour cutoff) leaves atoms in: by spatial
+    bin, x fastest (Atom::sort: ibin = iz * nbiny * nbinx + iy * nbinx + ix), in no particular order inside a bin (here: random).
+    Returns the permutation; x[perm] is the sorted array."""
+    lo, hi = np.asarray(box[:3]), np.asarray(box[3:])
+    nb = np.maximum(1, np.floor((hi - lo) / binsize).astype(np.int64))
+    ib = np.minimum(nb - 1, np.maximum(0, np.floor((x - lo) / (hi - lo) * nb).astype(np.int64)))
+    key = (ib[:, 2] * nb[1] + ib[:, 1]) * nb[0] + ib[:, 0]
+    tie = np.random.default_rng(seed).permutation(x.shape[0])
+    return np.lexsort((tie, key))
+
+
+def load_fe_st():
+    """The reference's own benchmark configuration (perf zip fe_st.dat, 152 880 Fe atoms, `boundary m p m`): positions in id
+    order, box (xlo, ylo, zlo, xhi, yhi, zhi)."""
+    with gzip.open(FE_ST, "rt") as fh:
+        lines = fh.read().split("\n")
+    n = int(lines[1].split()[0])
+    xlo, xhi = map(float, lines[3].split()[:2])
+    ylo, yhi = map(float, lines[4].split()[:2])
+    zlo, zhi = map(float, lines[5].split()[:2])
+    start = next(i for i, l in enumerate(lines) if l.startswith("Atoms")) + 2
+    arr = np.loadtxt(lines[start:start + n])
+    x = np.ascontiguousarray(arr[np.argsort(arr[:, 0]), 2:5])
+    return x, np.array([xlo, ylo, zlo, xhi, yhi, zhi])

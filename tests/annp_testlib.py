@@ -266,18 +266,7 @@ def oracle_vatom(pot, sysm, kind=KIND_FE, cutsq=None, ni_calls=1):
     return v
 
 
-def load_fe_st():
-    """The reference's own benchmark configuration (perf zip fe_st.dat): positions, box."""
-    with gzip.open(os.path.join(GOLDEN, "fe_st.dat.gz"), "rt") as fh:
-        lines = fh.read().split("\n")
-    n = int(lines[1].split()[0])
-    xlo, xhi = map(float, lines[3].split()[:2])
-    ylo, yhi = map(float, lines[4].split()[:2])
-    zlo, zhi = map(float, lines[5].split()[:2])
-    start = next(i for i, l in enumerate(lines) if l.startswith("Atoms")) + 2
-    arr = np.loadtxt(lines[start:start + n])
-    x = np.ascontiguousarray(arr[np.argsort(arr[:, 0]), 2:5])
-    return x, np.array([xlo, ylo, zlo, xhi, yhi, zhi])
+from meng_zhang_amd.workloads import load_fe_st  # noqa: E402,F401  (the reference's own benchmark configuration)
 
 
 # ---------------------------------------------------------------- the reference's own minimisation log

@@ -4,7 +4,8 @@
    python tools/kbench.py ni 40 40 80  # fcc Ni 40x40x80 cells (512 000 atoms)
    python tools/kbench.py anna 80      # bcc Fe, pair_style anna_adp (list cutoff 5.055 + 2 A)
    KBENCH_VIRIAL=1 python tools/kbench.py fe 80     # with the global virial tallied (vflag_global of an NPT step)
-   KBENCH_SHUFFLE=1 python tools/kbench.py fe 40    # atoms in random order (no locality of index: the slow path of the force tables)"""
+   KBENCH_SHUFFLE=1 python tools/kbench.py fe 40    # atoms in random order (no locality of index: the slow path of the force tables)
+   KBENCH_ORDER=lammps python tools/kbench.py fe 80 # atoms in the order LAMMPS' atom_modify sort leaves them (bins of 4.25 A, x fastest, random inside a bin)"""
 import ctypes as C
 import os
 import sys
@@ -39,6 +40,9 @@ def main():
         x0, box = fcc(*dims, A_NI)
         pot, el = NI_POT, "Ni"
     xg = perturb(x0, 12345, 0.05)
+    if os.environ.get("KBENCH_ORDER") == "lammps":          # what a LAMMPS caller delivers between two sorts
+        from meng_zhang_amd.workloads import lammps_sort_order
+        xg = xg[lammps_sort_order(xg, box)]
     if os.environ.get("KBENCH_SHUFFLE"):          # atoms in random order: what the force tables do for a caller that does not sort its atoms
         xg = xg[np.random.default_rng(1).permutation(xg.shape[0])]
     lib = load_library()
