@@ -443,10 +443,28 @@ def run_rank(args):
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        import datetime
+        # a wire that hangs must end the run by itself, with one line on stderr, not at the driver's limit:
+        # the collectives get a timeout, and until the first whole step has run a watchdog stands behind everything
+        # (set-up exchanges of the decomposition, the first point-to-point group, the first all-reduce)
+        wire_timeout = float(os.environ.get("ANNP_BENCH_WIRE_TIMEOUT", "240"))
+        tmo = datetime.timedelta(seconds=wire_timeout)
         if dry or staged:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
+        import threading
+
+        def _wire_hung():
+            sys.stderr.write("bench.py: rank %d of %d: the first exchanges over the %s backend did not complete within %.0f s "
+                             "(ANNP_BENCH_WIRE_TIMEOUT): giving up\n" % (rank, world, "gloo" if (dry or staged) else "nccl (RCCL)", wire_timeout))
+            sys.stderr.flush()
+            os._exit(4)
+        watchdog = threading.Timer(wire_timeout, _wire_hung)
+        watchdog.daemon = True
+        watchdog.start()
+        if os.environ.get("ANNP_BENCH_TEST_HANG_RANK") == str(rank):       # (tests/test_bench_launcher.py: a rank that never answers)
+            time.sleep(1e6)
         if dist.get_world_size() != args.gpus and not (world == 1 and args.gpus == 1):
             sys.stderr.write("bench.py: the process group has %d ranks, --gpus says %d\n" % (dist.get_world_size(), args.gpus))
             raise SystemExit(2)
@@ -490,7 +508,10 @@ def run_rank(args):
     leg.prime()
     for _ in range(args.warmup):
         step_thermo()
+    thermo()                            # (an all-reduce before the timed region, whatever --thermo is)
     barrier()
+    if use_dist:
+        watchdog.cancel()               # every kind of exchange of a step has completed once
     if not dry:
         check(lib.annp_hip_set_timing(h, 1), "set_timing")
     leg.reserve_marks(args.steps)

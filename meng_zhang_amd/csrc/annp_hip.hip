@@ -349,8 +349,13 @@ int ni_next_cap(int mx) { return std::max(8, round_up(mx + std::max(2, mx / 8), 
 // device-side capacity error into sticky_rc.
 void digest_flags(annp_hip_handle *h)
 {
-    const int over = h->h_flags[0], mx = h->h_flags[1], nfix = h->h_flags[2];
+    int over = h->h_flags[0];
+    const int mx = h->h_flags[1], nfix = h->h_flags[2];
     h->info[0] = mx; h->info[1] = nfix; h->info[2] = h->cap_last;
+    if (over >= ANNP_REPLAN_BAD_TARGET) {        // not a neighbour count: annp_hip_replan_fold_plan was handed a target outside [0, nkeys)
+        h->sticky_rc = fail(h, ANNP_HIP_EARG, "replan_fold_plan: a target index lay outside [0, nkeys); it was left out of the plan");
+        over = 0;
+    }
     if (mx > 0) h->sh_cap = sh_next_cap(mx);
     if (h->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
         h->fe_cap = fe_next_cap(mx);
@@ -1618,7 +1623,8 @@ int annp_hip_replan_exchange(annp_hip_handle *h, int n, double *d_x, const long 
                              const double *box6, const int *periodic3, int world, int rank, int has_left, int has_right,
                              double *d_keep, double *d_send, int *counts3, void *stream)
 {
-    if (!h || n < 0 || !box6 || !periodic3 || world < 1 || w0 < 0 || w1 < 0 || (n > 0 && !d_x) || (world > 1 && (!d_ids || !d_keep || !d_send || !counts3)))
+    if (!h || n < 0 || !box6 || !periodic3 || world < 1 || w0 < 0 || w1 < 0 || (n > 0 && !d_x) || (world > 1 && (!d_ids || !d_keep || !d_send || !counts3)) ||
+        (world > 1 && ((w0 > 0 && !d_e0) || (w1 > 0 && !d_e1))))           // (annp_replan_pack reads w0 / w1 columns of them)
         return h ? fail(h, ANNP_HIP_EARG, "replan_exchange: bad argument") : ANNP_HIP_EARG;
     if (counts3) { counts3[0] = n; counts3[1] = counts3[2] = 0; }
     if (n == 0) return 0;
@@ -1743,12 +1749,12 @@ int annp_hip_replan_fold_plan(annp_hip_handle *h, int m, const int *d_targets, i
     if ((rc = ensure(h, h->rp_cnt, 2 * (size_t)nkeys + 8)) || (rc = rp_scratch(h, 8, (size_t)nkeys + 8))) return rc;
     int *cnt = h->rp_cnt.p, *cursor = cnt + nkeys + 4;
     HIP_TRY(h, hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)nkeys, s));
-    if (m > 0) hipLaunchKernelGGL(annp_replan_count, dim3((m + 255) / 256), dim3(256), 0, s, m, d_targets, cnt);
+    if (m > 0) hipLaunchKernelGGL(annp_replan_count, dim3((m + 255) / 256), dim3(256), 0, s, m, d_targets, nkeys, cnt, h->d_flags);
     rp_scan(h, cnt, nkeys, h->rp_pos.p, h->rp_bs.p, 0, s);
     HIP_TRY(h, hipMemcpyAsync(h->rp_pos.p + nkeys, h->rp_tot, sizeof(long long), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(annp_replan_start32, dim3((nkeys + 256) / 256), dim3(256), 0, s, nkeys, h->rp_pos.p, d_start, cursor);
     if (m > 0) {
-        hipLaunchKernelGGL(annp_replan_fill, dim3((m + 255) / 256), dim3(256), 0, s, m, d_targets, cursor, d_perm);
+        hipLaunchKernelGGL(annp_replan_fill, dim3((m + 255) / 256), dim3(256), 0, s, m, d_targets, nkeys, cursor, d_perm);
         hipLaunchKernelGGL(annp_replan_sort_segments, dim3((nkeys + 255) / 256), dim3(256), 0, s, nkeys, d_start, d_perm);
     }
     HIP_TRY(h, hipGetLastError());

@@ -45,8 +45,9 @@ constexpr int SH_CAP_MAX = 128;   // state slots per atom the launch may ask for
 static_assert(SH_LMAX == FE_NT - 1, "tables are generated for T_0..T_18");
 
 __constant__ double annp_sh_q[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_Q_INIT;
-// doubles per atom in the moment buffer: (cosine, sine) of (l = m+k, m) at 2 (shf_toff(m) + 18-m-k), sh_tables.hpp; 380 used,
-// 20 zeros behind them (sh_legendre reads a few positions past its column's last entry with a zero coefficient); 25 lines of 128 bytes
+// doubles per atom in the moment buffer: (cosine, sine) of (l = m+k, m) at 2 (shf_toff(m) + 18-m-k), sh_tables.hpp; 380 used, the
+// 20 behind them only round the row up to 25 whole lines of 128 bytes: nothing writes them after the buffer's allocation (which
+// zeroes it), nothing may rely on what they hold (sh_legendre reads the copy in LDS, not the row)
 constexpr int SH_MPAD = 400;
 __constant__ unsigned short annp_shd_info[SHD_NROUND * 16] = ANNP_SHD_INFO_INIT;
 __constant__ double annp_shd_kappa[SHD_NROUND * 16] = ANNP_SHD_KAPPA_INIT;

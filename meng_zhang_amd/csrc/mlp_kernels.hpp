@@ -43,7 +43,7 @@ struct MlpArgs {
     int inum;
     const int *ilist;             // nullable
     int nsf, nnod, nl;            // nl = ntl-1 weight layers
-    int ncoef;                    // rows of coef the force pass reads (Behler: nsf; Chebyshev: 9 + 19 + 18)
+    int ncoef;                    // rows of coef the force pass reads (Behler: nsf; Chebyshev: c_m | p_k | W_l | P(1) = 9 + 19 + 19 + 1 = 48)
     int act[MLP_MAXL];
     int act_plain;                // ni: activations 3,4 are plain tanh
     const double *img;            // device: the MFMA operand image, [MlpSlots::total][64] (mlp_build_image)

@@ -142,10 +142,15 @@ __global__ __launch_bounds__(256) void annp_replan_image_make(int cur, int np0, 
 
 // ---- the plan of annp_hip_reverse_fold: items k = 0..m-1 with targets t[k] in [0, nkeys), grouped by target in ascending k.
 // count -> exclusive scan -> fill through a cursor (any order) -> every target's few entries put in ascending order.
-__global__ __launch_bounds__(256) void annp_replan_count(int m, const int *__restrict__ t, int *cnt)
+// (a target outside [0, nkeys) is a caller's mistake the host cannot see: it is left out and reported through the handle's sticky
+// error word, never used as an index)
+constexpr int ANNP_REPLAN_BAD_TARGET = 0x40000000;
+__global__ __launch_bounds__(256) void annp_replan_count(int m, const int *__restrict__ t, int nkeys, int *cnt, int *errflag)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k < m) atomicAdd(&cnt[t[k]], 1);
+    if (k >= m) return;
+    if ((unsigned)t[k] < (unsigned)nkeys) atomicAdd(&cnt[t[k]], 1);
+    else atomicMax(errflag, ANNP_REPLAN_BAD_TARGET);
 }
 __global__ __launch_bounds__(256) void annp_replan_start32(int nkeys, const long long *__restrict__ first, int *start, int *cursor)
 {
@@ -153,10 +158,10 @@ __global__ __launch_bounds__(256) void annp_replan_start32(int nkeys, const long
     if (k <= nkeys) start[k] = (int)first[k];
     if (k < nkeys) cursor[k] = (int)first[k];
 }
-__global__ __launch_bounds__(256) void annp_replan_fill(int m, const int *__restrict__ t, int *cursor, int *perm)
+__global__ __launch_bounds__(256) void annp_replan_fill(int m, const int *__restrict__ t, int nkeys, int *cursor, int *perm)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k < m) perm[atomicAdd(&cursor[t[k]], 1)] = k;
+    if (k < m && (unsigned)t[k] < (unsigned)nkeys) perm[atomicAdd(&cursor[t[k]], 1)] = k;
 }
 __global__ __launch_bounds__(256) void annp_replan_sort_segments(int nkeys, const int *__restrict__ start, int *perm)
 {

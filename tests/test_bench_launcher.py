@@ -72,3 +72,16 @@ def test_world_size_mismatch_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--cells", "8"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+
+
+def test_a_wire_that_hangs_ends_the_run_by_itself():
+    """A rank that never takes part in the first exchange (stand-in for a hung RCCL wire): every rank gives up after
+    ANNP_BENCH_WIRE_TIMEOUT with one line on stderr and a non-zero exit code, instead of sitting until somebody kills the job."""
+    import time
+    env = dict(os.environ, ANNP_BENCH_DRYRUN="1", ANNP_BENCH_WIRE_TIMEOUT="8", ANNP_BENCH_TEST_HANG_RANK="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", "8", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "0", "--secondary", "0"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    assert "did not complete within" in r.stderr
+    assert time.time() - t0 < 120
