@@ -168,7 +168,14 @@ struct annp_hip_handle {
                                         //     seen it), [1] max in-cutoff n, [2] length of the force fix-up queue, [3] of the descriptor fix-up queue,
                                         //     [4] contributions annp_fe_force_sh's force tables had no bucket for; [1..] per evaluation
     int *h_flags = nullptr;             // pinned mirror, copied back behind every evaluation
-    hipEvent_t ev_flags = nullptr;      // ... that copy has landed
+    hipEvent_t ev_flags = nullptr;      // ... that copy has landed (and, behind it on the same side stream, words [1..] are clear again)
+    hipStream_t stream_flags = nullptr; // the copy and the clearing run beside the caller's stream, not in it (round 5: at 128 000 atoms the
+    hipEvent_t ev_tail = nullptr;       // copy held the next step's first kernel back by 33 us, the clearing cost two fill kernels)
+    int *fw = nullptr;                  // the per-evaluation words of the evaluation being issued: d_flags + 8 or + 16, turn about (fw[1..7]; word 0 of
+    int flags_par = 0;                  // d_flags is the sticky one) -- an evaluation never waits for the copy + clear behind the one before it
+    hipEvent_t ev_set[2] = {nullptr, nullptr};   // the side stream has cleared that set again
+    bool set_used[2] = {false, false};
+    bool flags_dirty = false;           // an evaluation set out and never reached its tail (an error on the way): clear the words in-stream
     int sticky_rc = 0;                  // error found in a landed copy, returned by the next call on the handle
     bool reset_err = false;             // d_flags[0] was seen non-zero: clear it before the next evaluation
     int info[4] = {0, 0, 0, 0};         // annp_hip_eval_info
@@ -520,7 +527,7 @@ int launch_fe_desc(annp_hip_handle *h, FeArgs a, int inum, int cap_list, int max
         if ((rc = ensure(h, h->mom, (size_t)(inum + SHF_GA) * SH_MPAD, true))) return rc;      // (sized and zeroed as the force pass wants it, below)
         a.A = h->mom.p;
     }
-    a.ovf_count = h->d_flags + 3; a.ovf_list = fix ? h->ovf_desc.p : nullptr; a.ovf_cap = fix ? inum : 0;
+    a.ovf_count = h->fw + 3; a.ovf_list = fix ? h->ovf_desc.p : nullptr; a.ovf_cap = fix ? inum : 0;
     // waves per workgroup: as many waves per CU as the LDS allows, and of those shapes the largest workgroup (measured at
     // 1 M atoms, 8 waves per CU each: 5.8 ms with 4 waves per workgroup, 6.3 with 1)
     int wpb = h->sh_wpb;
@@ -547,6 +554,14 @@ int launch_fe_desc(annp_hip_handle *h, FeArgs a, int inum, int cap_list, int max
 // Nothing here waits for the device in the steady state: capacities come from the previous evaluation's flag
 // words (whenever their copy has landed), this evaluation's flag words are copied back behind its last kernel.
 // Only the first evaluation on a handle (and the one after a Behler capacity error) sizes itself synchronously.
+// the sticky word and the current evaluation's words into the host mirror, in the layout digest_flags reads
+int copy_flags(annp_hip_handle *h, hipStream_t st)
+{
+    HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(h->h_flags + 1, h->fw + 1, (ANNP_NFLAGS - 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
 int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_x, const int *d_type, const int *d_ilist,
                         const int *d_numneigh, const long long *d_first, const int *d_neigh, int max_numneigh,
                         double *d_f, double *d_eatom, double *d_eng, double *d_virial, double *d_vatom, hipStream_t s)
@@ -559,11 +574,20 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     // a neighbouring row by zero: they must be numbers, whether the network pass wrote them or not)
     if ((rc = ensure(h, h->coef, (size_t)(inum + SHF_GA) * ANNP_CPAD, true))) return rc;
     if ((rc = ensure(h, h->ncount, (size_t)inum))) return rc;
-    if (h->reset_err) {
-        HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, ANNP_NFLAGS * sizeof(int), s));
-        h->reset_err = false;
+    // The flag words [1..] are clear: at start they are, and behind every evaluation the side stream copies them to the host and
+    // clears them again (below); this evaluation's kernels only have to come after that.  Word [0] is cleared here once the host
+    // has seen it.
+    if (h->flags_dirty) {               // (the evaluation before this one left early: its set was never handed to the side stream)
+        HIP_TRY(h, hipMemsetAsync(h->fw + 1, 0, (ANNP_NFLAGS - 1) * sizeof(int), s));
     } else {
-        HIP_TRY(h, hipMemsetAsync(h->d_flags + 1, 0, (ANNP_NFLAGS - 1) * sizeof(int), s));
+        h->flags_par ^= 1;
+        h->fw = h->d_flags + ANNP_NFLAGS * (1 + h->flags_par);
+        if (h->set_used[h->flags_par]) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_set[h->flags_par], 0));      // cleared two evaluations ago
+    }
+    h->flags_dirty = true;
+    if (h->reset_err) {
+        HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
+        h->reset_err = false;
     }
     if (h->timing) {
         h->ev = h->evring.data() + 4 * (size_t)(h->ev_count % annp_hip_handle::kRing);
@@ -608,8 +632,10 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             if ((rc = ensure(h, h->mom, (size_t)(inum + SHF_GA) * SH_MPAD, true)) || (rc = ensure(h, h->fe_nbrs, (size_t)inum * SH_CAP_MAX))) return rc;
             a.A = h->mom.p; a.nbrs = h->fe_nbrs.p;
         }
+        a.nmax_word = h->fw + 1;           // (annp_fe_desc_sh raises it itself; the pair-loop descriptor kernel does not)
+        const bool desc_sh = !h->fe_desc_pairs && !h->fe_dense;
         if ((rc = launch_fe_desc(h, a, inum, cap_list, max_numneigh, s))) return rc;
-        hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
+        if (!desc_sh) hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->fw + 1);
         HIP_TRY(h, hipGetLastError());
         if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], s));
         // pass 2
@@ -626,9 +652,9 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             const bool fixup = cap_list > cap;
             if (fixup && (rc = ensure(h, h->ovf, (size_t)inum))) return rc;
             a.n_cap = cap;
-            a.ovf_count = h->d_flags + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
+            a.ovf_count = h->fw + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
             if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
-            a.tab_spills = h->d_flags + 4;
+            a.tab_spills = h->fw + 4;
             a.shf_places_by_number = h->shf_places_by_number;
             {
 #ifdef ANNP_SHF_CHECK
@@ -653,7 +679,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             // first evaluation on this handle: read the maximum just measured, once.  Also whenever a whole list row would not
             // fit the fix-up launch's LDS (very long rows): nothing would stand behind a stale capacity then
             if (h->fe_cap == 0 || (!fix_possible && h->fe_cap < cap_list)) {
-                HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, ANNP_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, s));
+                if (int rc2 = copy_flags(h, s)) return rc2;
                 HIP_TRY(h, hipStreamSynchronize(s));
                 if (h->h_flags[0] > 0) {
                     h->reset_err = true;
@@ -667,7 +693,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
             if ((rc = ensure(h, h->ovf, (size_t)inum))) return rc;
             a.n_cap = cap3;
             const bool fixup = cap3 < cap_list && fix_possible;
-            a.ovf_count = h->d_flags + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
+            a.ovf_count = h->fw + 2; a.ovf_list = fixup ? h->ovf.p : nullptr; a.ovf_cap = fixup ? inum : 0;
             if (fe_force_lds_per_wave(cap3) * fe_wpb_force() > 160 * 1024)
                 return fail(h, ANNP_HIP_ENEIGHCAP, "too many in-cutoff neighbours for LDS (%d)", cap3);
             if (h->pre_force_wait) { HIP_TRY(h, hipStreamWaitEvent(s, h->pre_force_wait, 0)); h->pre_force_wait = nullptr; }
@@ -689,8 +715,10 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
         a.cutsq = h->cutsq; a.rc_list = h->cut; a.rc_par = h->cut;          // fc and the radial argument both use the file's cutoff (adp:105,130,588)
         a.G = h->G.p; a.ncount = h->ncount.p; a.errflag = h->d_flags;
+        a.nmax_word = h->fw + 1;           // (annp_fe_desc_sh raises it itself; the pair-loop descriptor kernel does not)
+        const bool desc_sh = !h->fe_desc_pairs && !h->fe_dense;
         if ((rc = launch_fe_desc(h, a, inum, cap_list, max_numneigh, s))) return rc;
-        hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
+        if (!desc_sh) hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->fw + 1);
         HIP_TRY(h, hipGetLastError());
         if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[1], s)); HIP_TRY(h, hipEventRecord(h->ev[2], s)); }
         // pass 2: network, ADP sums, energy, forces
@@ -744,7 +772,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         const int cap_big = std::min(cap_max, std::max(a.n_cap, round_up(std::max(max_numneigh, 8), 8)));
         const bool fixup = cap_big > a.n_cap && !h->ni_no_fixup;
         const int ngroups = (inum + NI_GA - 1) / NI_GA;
-        a.ovf_count = h->d_flags + 2; a.ovf_list = nullptr; a.ovf_cap = 0; a.fix = 0; a.skip_above = a.n_cap;
+        a.ovf_count = h->fw + 2; a.ovf_list = nullptr; a.ovf_cap = 0; a.fix = 0; a.skip_above = a.n_cap;
         if (fixup) {
             if ((rc = ensure(h, h->ovf, (size_t)ngroups)) || (rc = ensure(h, h->ni_fix_nbr, (size_t)ngroups * NI_GA * cap_big))) return rc;
             a.ovf_list = h->ovf.p; a.ovf_cap = ngroups;
@@ -754,11 +782,11 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         ni_launch_desc(a, h->ni_shape, s);
         HIP_TRY(h, hipGetLastError());
         if (fixup) { ni_launch_desc_fix(b, h->ni_shape, s); HIP_TRY(h, hipGetLastError()); }
-        hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->d_flags + 1);
+        hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(inum)), dim3(256), 0, s, h->ncount.p, inum, h->fw + 1);
         HIP_TRY(h, hipGetLastError());
         cap_force = a.n_cap;
         if (!h->ni_primed) {    // first evaluation on the handle (or the one after an error): look at the counts once
-            HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, ANNP_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, s));
+            if (int rc2 = copy_flags(h, s)) return rc2;
             HIP_TRY(h, hipStreamSynchronize(s));
             if (h->h_flags[0] > 0) {
                 h->reset_err = true;
@@ -786,9 +814,14 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         HIP_TRY(h, hipGetLastError());
     }
     // flag words of this evaluation, for whoever looks next (poll_flags)
-    HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, ANNP_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipEventRecord(h->ev_flags, s));
-    h->flags_pending = true;
+    HIP_TRY(h, hipEventRecord(h->ev_tail, s));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream_flags, h->ev_tail, 0));
+    if (int rc2 = copy_flags(h, h->stream_flags)) return rc2;
+    HIP_TRY(h, hipEventRecord(h->ev_flags, h->stream_flags));
+    HIP_TRY(h, hipMemsetAsync(h->fw + 1, 0, (ANNP_NFLAGS - 1) * sizeof(int), h->stream_flags));
+    HIP_TRY(h, hipEventRecord(h->ev_set[h->flags_par], h->stream_flags));
+    h->set_used[h->flags_par] = true;
+    h->flags_pending = true; h->flags_dirty = false;
     h->flags_sh = h->fe_last_sh; h->flags_inum = h->fe_last_inum;      // (what digest_flags judges the queue length by)
 
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[3], s)); h->ev_count++; }
@@ -918,6 +951,9 @@ void annp_hip_clear(annp_hip_handle *h)
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     if (h->ev_flags) (void)hipEventDestroy(h->ev_flags);
+    if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
+    for (int k = 0; k < 2; k++) if (h->ev_set[k]) (void)hipEventDestroy(h->ev_set[k]);
+    if (h->stream_flags) (void)hipStreamDestroy(h->stream_flags);
     if (h->reg_x.ok && hipHostUnregister(const_cast<void *>(h->reg_x.ptr)) != hipSuccess) (void)hipGetLastError();
     if (h->reg_f.ok && hipHostUnregister(const_cast<void *>(h->reg_f.ptr)) != hipSuccess) (void)hipGetLastError();
     if (h->pin_x) (void)hipHostFree(h->pin_x);
@@ -1010,6 +1046,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     INIT_TRY(guard_.err);
     INIT_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     INIT_TRY(hipEventCreateWithFlags(&h->ev_flags, hipEventDisableTiming));
+    INIT_TRY(hipStreamCreateWithFlags(&h->stream_flags, hipStreamNonBlocking));
+    INIT_TRY(hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
     INIT_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     INIT_TRY(hipEventCreateWithFlags(&h->ev_f_up, hipEventDisableTiming));
     if (const char *e = std::getenv("ANNP_HIP_REGISTER")) h->use_register = std::atoi(e) != 0;
@@ -1226,8 +1264,11 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     }
     INIT_TRY(hipMalloc((void **)&h->d_scalars, 8 * sizeof(double)));
     INIT_TRY(hipMalloc((void **)&h->d_vslots, sizeof(double) * 8 * ANNP_VSLOTS));
-    INIT_TRY(hipMalloc((void **)&h->d_flags, ANNP_NFLAGS * sizeof(int)));
-    INIT_TRY(hipMemset(h->d_flags, 0, ANNP_NFLAGS * sizeof(int)));
+    INIT_TRY(hipMalloc((void **)&h->d_flags, 3 * ANNP_NFLAGS * sizeof(int)));       // the sticky word's row and two sets of per-evaluation words
+    INIT_TRY(hipMemset(h->d_flags, 0, 3 * ANNP_NFLAGS * sizeof(int)));
+    h->fw = h->d_flags + ANNP_NFLAGS;
+    INIT_TRY(hipEventCreateWithFlags(&h->ev_set[0], hipEventDisableTiming));
+    INIT_TRY(hipEventCreateWithFlags(&h->ev_set[1], hipEventDisableTiming));
     INIT_TRY(hipHostMalloc((void **)&h->h_flags, ANNP_NFLAGS * sizeof(int)));
     INIT_TRY(hipHostMalloc((void **)&h->h_scalars, 8 * sizeof(double)));
     h->bytes += 8 * sizeof(double) + ANNP_NFLAGS * sizeof(int) + sizeof(double) * 8 * ANNP_VSLOTS;

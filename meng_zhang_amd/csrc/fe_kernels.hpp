@@ -53,6 +53,7 @@ struct FeArgs {
     double *virial;            // nullable: the evaluation's virial table [ANNP_VSLOTS][8] (annp_common.hpp), accumulated into
     double *vatom;             // nullable, [nall][6] accumulated (needs the VIRIAL kernel variant)
     int *ncount;               // nullable [inum]: in-cutoff neighbour count
+    int *nmax_word;            // nullable device int: annp_fe_desc_sh raises it to the largest count it finds (otherwise annp_max_int does, in a launch of its own)
     int *errflag;              // device int: max n seen when n > n_cap and nothing can take the atom over
     // force pass only: atoms whose in-cutoff count exceeds n_cap are queued for annp_fe_force_fixup, which
     // runs them with the list-length capacity on the same stream (nullable: report through errflag instead)

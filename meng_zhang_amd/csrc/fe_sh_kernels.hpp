@@ -420,10 +420,12 @@ __global__ __launch_bounds__(256, 3) void annp_fe_desc_sh(FeArgs p)
         if (pos < SH_GL * SH_R) { stA[pos] = make_double2(dx, dy); stB[pos] = make_double2(dz, rsq); }
         else if (pos < cap) { SA[ga * PL + pos - SH_GL * SH_R] = make_double2(dx, dy); SC[ga * PL + pos - SH_GL * SH_R] = make_double2(dz, rsq); }
     };
+    int ntrue = 0;               // largest in-cutoff count of the wave's atoms, whether the launch has state for it or not (uniform)
     auto settle = [&](int ga, int n, bool gone) {         // row ga is filtered, n = its in-cutoff count (uniform)
         const int ii = ii0 + ga;
         if (!gone) {
             if (p.ncount && lane == 0) p.ncount[ii] = n;
+            ntrue = max(ntrue, n);
             if (n > cap) {                  // more than this launch has room for: the pair-loop kernel takes the atom
                 if (lane == 0) {
                     const int k = p.ovf_list ? atomicAdd(p.ovf_count, 1) : p.ovf_cap;
@@ -520,6 +522,9 @@ __global__ __launch_bounds__(256, 3) void annp_fe_desc_sh(FeArgs p)
             settle(ga, uniform(n), jn < 0);
         }
     }
+    // the evaluation's largest count, for the host's sizing of the next one: a wave that has nothing to add to what it reads there
+    // (all but the first few of a launch) does not touch the word
+    if (p.nmax_word && lane == 0 && ntrue > __hip_atomic_load(p.nmax_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.nmax_word, ntrue);
     if (lane < SH_GA * 20) pw[lane] = 0.0;           // (the staging rows are done with: settle ended on a barrier)
     if (lane + 64 < SH_GA * 20) pw[lane + 64] = 0.0;
 
