@@ -438,7 +438,16 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     NB_TRY(hipStreamSynchronize(s));
     nb.max_numneigh = (int)(hres[0] & 0xffffffffll);
     const long long total = hres[1];
-    if (nb_alloc(nb.neigh, nb.cap_neigh, (size_t)std::max<long long>(total, 1), nb.bytes, msg)) return -3;
+    // Room for the pitched layout of the NEXT build too, where that build will take it (the same test as above): otherwise the first
+    // rebuild frees and allocates the whole list again -- a gigabyte at 1 M atoms, tens of milliseconds when the driver is slow about
+    // it (the occasional 37-70 ms rebuild of rounds 3-5).
+    learn_pitch();
+    size_t want_entries = (size_t)std::max<long long>(total, 1);
+    {
+        const double mean = nlocal > 0 ? (double)total / (double)nlocal : 0.0;
+        if ((long long)nlocal * nb.pitch < (1ll << 33) && nb.pitch <= 1.5 * mean + 8.0) want_entries = std::max(want_entries, (size_t)nlocal * nb.pitch);
+    }
+    if (nb_alloc(nb.neigh, nb.cap_neigh, want_entries, nb.bytes, msg)) return -3;
     hipLaunchKernelGGL((annp_neigh_tile<true>), dim3((unsigned)nbins), dim3(256), tlds, s, d_x, nb.xs, nlocal, g, rc2, nb.binstart, nb.binitems,
                        nb.numneigh, (const long long *)nb.first, nb.neigh, 0);
     NB_TRY(hipGetLastError());

@@ -14,7 +14,7 @@ if [ "$wl" != "fe" ]; then suffix="_$wl"; wlargs="--workload $wl"; fi
 out=gpurun_out/${tag}prof${suffix}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py $wlargs --steps 20 --warmup 5 --cpu-sample 0 \
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py $wlargs --steps 20 --warmup 5 --cpu-sample 0 --secondary 0 \
     > $out/bench_under_rocprof.json 2> $out/trace.err
 echo "trace done"
 n=0
