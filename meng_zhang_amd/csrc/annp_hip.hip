@@ -154,6 +154,8 @@ struct annp_hip_handle {
     NiShape ni_shape = {0, 0, 0};       // {lambda} x {eta} x {zeta} product shape of the angular set (0 = none)
     std::vector<double> sym_rad, sym_ang;
     // work buffers
+    DevBuf<double> fscratch;            // forces of one evaluation by themselves, when the global virial is taken as sum x (x) f (annp_fdotr_add)
+    bool virial_tally = false;          // ANNP_HIP_VIRIAL=tally: the pairwise tally inside the force kernels instead (what per-atom virials always use)
     DevBuf<double> G, coef, x, f, eatom, vatom, mom;        // mom: moments of the neighbourhoods, descriptor pass -> force pass (fe_sh_kernels.hpp)
     DevBuf<int> type, ilist, numneigh, neigh, ncount, ni_nbr, ni_npair, ni_fix_nbr, ovf, ovf_desc, fe_nbrs;
     DevBuf<unsigned short> ni_pairs;    // Behler: in-range (j,k) pairs per atom, descriptor pass -> force pass
@@ -569,6 +571,19 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     int rc;
     if ((rc = poll_flags(h, false))) return rc;      // an error of an earlier evaluation, reported once
     if (inum <= 0) return 0;
+    // The global virial without per-atom virials (every step of an NPT run): the evaluation's forces go to a scratch array, and one
+    // streaming kernel behind the passes adds them onto the caller's f and sums x (x) f over owned atoms and ghosts -- the reference's
+    // own route (virial_fdotr_compute), equal to the pairwise tally to round-off, and 50 us where the tally cost the force pass 6 %.
+    double *f_caller = nullptr, *virial_caller = nullptr;
+    // (Chebyshev potentials only: the reference's Behler file tallies its virial from the forces BEFORE their unit conversion
+    // (ni/src/pair_annp.cpp:188-198: f gets Fj * CFFORCE, ev_tally_xyz gets Fj), so there the tally and sum x (x) f differ by that factor,
+    // and the boundary's virial is the tally's; anna_adp keeps the tally too)
+    if (d_virial && !d_vatom && !h->virial_tally && h->descriptor == ANNP_HIP_DESC_CHEBYSHEV) {
+        if ((rc = ensure(h, h->fscratch, (size_t)nall * 3))) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->fscratch.p, 0, sizeof(double) * 3 * (size_t)nall, s));
+        f_caller = d_f; virial_caller = d_virial;
+        d_f = h->fscratch.p; d_virial = nullptr;
+    }
     if ((rc = ensure(h, h->G, (size_t)inum * ANNP_GPAD))) return rc;
     // (coefficient rows start out as zeros, and there are rows behind the last list entry's: the force pass multiplies a few entries of
     // a neighbouring row by zero: they must be numbers, whether the network pass wrote them or not)
@@ -809,6 +824,13 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         HIP_TRY(h, hipGetLastError());
         if (fixup) { ni_launch_force_fix(b, h->ni_shape, d_virial != nullptr || d_vatom != nullptr, s); HIP_TRY(h, hipGetLastError()); }
     }
+    if (virial_caller) {
+        vtab = h->d_vslots;
+        HIP_TRY(h, hipMemsetAsync(vtab, 0, sizeof(double) * 8 * ANNP_VSLOTS, s));
+        hipLaunchKernelGGL(annp_fdotr_add, dim3(std::max(1, std::min(ANNP_VSLOTS, (nall + 255) / 256))), dim3(256), 0, s, nall, d_x, h->fscratch.p, f_caller, vtab);
+        HIP_TRY(h, hipGetLastError());
+        d_virial = virial_caller;
+    }
     if (vtab) {
         hipLaunchKernelGGL(annp_virial_fold, dim3(1), dim3(1024), 0, s, vtab, d_virial);
         HIP_TRY(h, hipGetLastError());
@@ -940,7 +962,7 @@ void annp_hip_clear(annp_hip_handle *h)
     if (h->d_net) (void)hipFree(h->d_net);
     release(h, h->G); release(h, h->coef); release(h, h->x); release(h, h->f); release(h, h->eatom); release(h, h->vatom);
     release(h, h->type); release(h, h->ilist); release(h, h->numneigh); release(h, h->neigh); release(h, h->ncount); release(h, h->ni_nbr); release(h, h->ni_npair); release(h, h->ni_fix_nbr); release(h, h->ni_pairs); release(h, h->ovf);
-    release(h, h->mom); release(h, h->fe_nbrs); release(h, h->ovf_desc);
+    release(h, h->mom); release(h, h->fe_nbrs); release(h, h->ovf_desc); release(h, h->fscratch);
     release(h, h->rp_flag); release(h, h->rp_cnt); release(h, h->rp_pos); release(h, h->rp_bs);
     if (h->rp_tot) (void)hipFree(h->rp_tot);
     if (h->rp_tot_h) (void)hipHostFree(h->rp_tot_h);
@@ -1059,6 +1081,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (const char *e = std::getenv("ANNP_HIP_NI_FIXUP")) h->ni_no_fixup = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_FE_DESC")) h->fe_desc_pairs = std::strcmp(e, "pairs") == 0;
     if (const char *e = std::getenv("ANNP_HIP_FE_FORCE")) h->fe_force_pairs = std::strcmp(e, "pairs") == 0;
+    if (const char *e = std::getenv("ANNP_HIP_VIRIAL")) h->virial_tally = std::strcmp(e, "tally") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SHF_PLACES")) h->shf_places_by_number = std::strcmp(e, "number") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SH_WPB")) h->sh_wpb = std::min(4, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("ANNP_HIP_SH_CAP")) h->sh_cap = std::min((int)SH_CAP_MAX, std::max((int)SH_CAP_MIN, round_up(std::atoi(e), 16)));

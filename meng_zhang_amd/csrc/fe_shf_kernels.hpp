@@ -119,7 +119,12 @@ struct ShfTable {
         for (int k = 0; k < (NT2 + TH - 1) / TH; k++)
             if (k * TH + TH <= NT2 || tid + k * TH < NT2) a2[tid + k * TH] = make_double2(0.0, 0.0);
         if (tid <= SHF_NBUCK) key[tid] = tid < SHF_NBUCK ? -1 : 0;
+        if (tid < 6) vacc()[tid] = 0.0;
     }
+    // six doubles behind the keys: the workgroup's share of the global virial (round 5: gathered here and sent to the evaluation's
+    // virial table as ONE six-lane atomic per workgroup; every wave sending its atoms' six sums itself was 24 requests per workgroup on
+    // one 64-byte line, and same-line float atomics are served one after the other: the virial cost the pass 6.7 %)
+    __device__ __forceinline__ double *vacc() const { return reinterpret_cast<double *>(key + SHF_NBUCK + 2 + ((SHF_NBUCK + 2) & 1)); }
     // thread t < 384 takes double t % 24 of buckets t / 24, t / 24 + 16, ..: a wave-instruction still writes 64 consecutive doubles of
     // the table (2.7 buckets = 8-9 lines of f)
     __device__ __forceinline__ void flush(int tid, int *spills) const
@@ -683,9 +688,9 @@ __global__ __launch_bounds__(64 * SHF_WAVES, ANNP_SHF_WPS) void annp_fe_force_sh
             for (int k = 0; k < 6; k++) vs[k] = row16_sum_to_last(vs[k]);
             if (l == 15 && at.n > 0) {
                 if (p.virial) {
-                    double *vr = virial_row(p.virial);          // (annp_common.hpp: the global virial)
+                    double *va = tab.vacc();                    // (the workgroup's sums: they leave behind the last barrier)
 #pragma unroll
-                    for (int k = 0; k < 6; k++) atomicAdd(&vr[k], vs[k]);
+                    for (int k = 0; k < 6; k++) atomicAdd(&va[k], vs[k]);
                 }
                 if (p.vatom) {
                     double *vi = p.vatom + 6 * (size_t)at.i;
@@ -701,6 +706,7 @@ __global__ __launch_bounds__(64 * SHF_WAVES, ANNP_SHF_WPS) void annp_fe_force_sh
 #ifndef ANNP_SHF_SKIP_FLUSH
     tab.flush(threadIdx.x, p.tab_spills);          // the workgroup's table, in memory order
 #endif
+    if (VIRIAL && p.virial && threadIdx.x < 6) atomicAdd(&virial_row(p.virial)[threadIdx.x], tab.vacc()[threadIdx.x]);     // (annp_common.hpp: the global virial)
     SHF_STAMP(8);
 }
 

@@ -69,4 +69,34 @@ __global__ __launch_bounds__(256) void annp_verlet_half(long long n3, double *x,
     }
 }
 
+// The global virial as LAMMPS' Pair::virial_fdotr_compute has it (the route the reference takes under fix npt: fe_v2/src/pair_annp.cpp:216,
+// `if (vflag_fdotr) virial_fdotr_compute()`): W = sum over owned atoms and ghosts of x_i (x) f_i, with f the forces of THIS evaluation
+// only -- they were gathered in a scratch array `fs`, which this kernel also adds onto the caller's `f` (the boundary accumulates into
+// f).  xx yy zz xy xz yz.  A block's six sums go to one row of the evaluation's virial table (annp_common.hpp), folded by
+// annp_virial_fold.  120 bytes per atom streamed once: 50 us per 1.25 M atoms, where the pairwise tally inside the force pass cost it 6 %.
+__global__ __launch_bounds__(256) void annp_fdotr_add(int nall, const double *__restrict__ x, const double *__restrict__ fs, double *f, double *vtable)
+{
+    __shared__ double part[4][6];
+    double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nall; i += (long long)gridDim.x * 256) {
+        const double f0 = fs[3 * i], f1 = fs[3 * i + 1], f2 = fs[3 * i + 2];
+        if (f0 != 0.0 || f1 != 0.0 || f2 != 0.0) {
+            const double x0 = x[3 * i], x1 = x[3 * i + 1], x2 = x[3 * i + 2];
+            f[3 * i] += f0; f[3 * i + 1] += f1; f[3 * i + 2] += f2;
+            v[0] = fma(x0, f0, v[0]); v[1] = fma(x1, f1, v[1]); v[2] = fma(x2, f2, v[2]);
+            v[3] = fma(x0, f1, v[3]); v[4] = fma(x0, f2, v[4]); v[5] = fma(x1, f2, v[5]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const double t = wave_sum(v[k]);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const double t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (t != 0.0) atomicAdd(&virial_row(vtable)[threadIdx.x], t);
+    }
+}
+
 }  // namespace annp
