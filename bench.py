@@ -249,6 +249,21 @@ class Leg:
             self.check(rc, "compute_device")
             return
 
+    def spin_up(self, min_ms):
+        """Force evaluations (no MD step: positions do not change, f is cleared by prime() afterwards) until the device has been busy for
+        min_ms: after the host-bound set-up the chip takes 20-30 ms of work to reach the clocks it then holds (measured at 128 000
+        atoms: the first 10 steps behind 2 warm-up steps ran 1.52 ms each, the same steps behind 20 warm-up steps 1.37), and W warm-up
+        steps of a small system are over before that.  Returns the number of evaluations issued (reported in config.spin_up)."""
+        if self.dry or min_ms <= 0:
+            return 0
+        n, t0 = 0, time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < min_ms and n < 400:
+            for _ in range(4):
+                self.force_eval()
+            n += 4
+            self.torch.cuda.synchronize(self.dev)
+        return n
+
     def prime(self):
         self.dom.forward(clear_forces=True, eng=self.eng)
         self.force_eval()
@@ -308,6 +323,7 @@ class Leg:
     def timed(self, steps, warmup):
         """(seconds, HIP-event means of the kernels) of `steps` steps; single rank, no thermo"""
         torch = self.torch
+        self.spin_up(float(os.environ.get("ANNP_BENCH_SPINUP_MS", "60")))
         self.prime()
         for _ in range(warmup):
             self.step()
@@ -511,6 +527,7 @@ def run_rank(args):
             dist.barrier()
         sync()
 
+    spun = leg.spin_up(float(os.environ.get("ANNP_BENCH_SPINUP_MS", "60")))
     leg.prime()
     for _ in range(args.warmup):
         step_thermo()
@@ -747,6 +764,9 @@ def run_rank(args):
             except Exception as exc:    # the metric's line must not be lost to a baseline
                 out["cpu_baseline"]["matrix_error"] = repr(exc)
     out["config"]["evaluations_reissued"] = leg.reissued
+    out["config"]["spin_up"] = {"evaluations": spun, "note": "untimed force evaluations on the start configuration before the W warm-up steps, until the device "
+                                                               "has been busy for ANNP_BENCH_SPINUP_MS (60) ms: the chip needs 20-30 ms of work after the host-bound "
+                                                               "set-up to reach the clocks it then holds; no MD step, no work of the timed region is done there"}
     # ---- BASELINE.json config 5, and the reference's published deck, as short extra legs of the default run ----
     if world == 1 and wl == "fe" and args.secondary and not use_dist:
         leg.close()

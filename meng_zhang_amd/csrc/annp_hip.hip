@@ -589,9 +589,10 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
     // a neighbouring row by zero: they must be numbers, whether the network pass wrote them or not)
     if ((rc = ensure(h, h->coef, (size_t)(inum + SHF_GA) * ANNP_CPAD, true))) return rc;
     if ((rc = ensure(h, h->ncount, (size_t)inum))) return rc;
-    // The flag words [1..] are clear: at start they are, and behind every evaluation the side stream copies them to the host and
-    // clears them again (below); this evaluation's kernels only have to come after that.  Word [0] is cleared here once the host
-    // has seen it.
+    // The per-evaluation flag words come in two sets that take turns (h->fw): behind every evaluation a side stream copies its set to
+    // the host and clears it again (the tail of this function), so no memset and no copy stands in the caller's stream between two
+    // evaluations, and an evaluation only waits for the clearing of ITS set, two evaluations old.  Word [0] of d_flags is the sticky
+    // one, shared by both sets, cleared here once the host has seen it.
     if (h->flags_dirty) {               // (the evaluation before this one left early: its set was never handed to the side stream)
         HIP_TRY(h, hipMemsetAsync(h->fw + 1, 0, (ANNP_NFLAGS - 1) * sizeof(int), s));
     } else {

@@ -451,7 +451,6 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     hipLaunchKernelGGL((annp_neigh_tile<true>), dim3((unsigned)nbins), dim3(256), tlds, s, d_x, nb.xs, nlocal, g, rc2, nb.binstart, nb.binitems,
                        nb.numneigh, (const long long *)nb.first, nb.neigh, 0);
     NB_TRY(hipGetLastError());
-    learn_pitch();
     nb.nlocal = nlocal; nb.nall = nall; nb.valid = true; nb.pitched = false; nb.pitch_used = 0;
     nb.mean_exact = nlocal > 0 ? (double)total / (double)nlocal : 0.0;      // 0 = unknown
     return 0;
