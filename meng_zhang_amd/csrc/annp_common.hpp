@@ -222,6 +222,37 @@ __device__ __forceinline__ double exp_neg_s(double x)
     return __builtin_ldexp(p, (int)kf);
 }
 
+// two arguments at once: the coefficient loads are shared and the two Horner chains interleave
+__device__ __forceinline__ void sincos_0_pi_s2(double t0, double t1, double &sn0, double &cs0, double &sn1, double &cs1)
+{
+    const annp_cptr T = mtab_scalar();
+    const double h0 = t0 - T[21], h1 = t1 - T[21];
+    const double a0 = h0 * h0, a1 = h1 * h1;
+    double ps0 = T[0], ps1 = T[0];
+#pragma unroll
+    for (int k = 1; k < 10; k++) { ps0 = fma_vvs(ps0, a0, T[k]); ps1 = fma_vvs(ps1, a1, T[k]); }
+    double pc0 = T[10], pc1 = T[10];
+#pragma unroll
+    for (int k = 11; k < 21; k++) { pc0 = fma_vvs(pc0, a0, T[k]); pc1 = fma_vvs(pc1, a1, T[k]); }
+    sn0 = fma(-a0, pc0, 1.0); sn1 = fma(-a1, pc1, 1.0);
+    cs0 = -fma(-(h0 * a0), ps0, h0); cs1 = -fma(-(h1 * a1), ps1, h1);
+}
+
+__device__ __forceinline__ void exp_neg_s2(double x0, double x1, double &e0, double &e1)
+{
+    const annp_cptr T = mtab_scalar();
+    const double k0 = rint(x0 * T[22]), k1 = rint(x1 * T[22]);
+    double r0 = fma(-k0, T[23], x0), r1 = fma(-k1, T[23], x1);
+    r0 = fma(-k0, T[24], r0); r1 = fma(-k1, T[24], r1);
+    double p0 = T[25], p1 = T[25];
+#pragma unroll
+    for (int k = 26; k < ANNP_MTAB; k++) { p0 = fma_vvs(p0, r0, T[k]); p1 = fma_vvs(p1, r1, T[k]); }
+    p0 = fma(p0, r0, 0.5); p1 = fma(p1, r1, 0.5);
+    p0 = fma(p0, r0, 1.0); p1 = fma(p1, r1, 1.0);
+    p0 = fma(p0, r0, 1.0); p1 = fma(p1, r1, 1.0);
+    e0 = __builtin_ldexp(p0, (int)k0); e1 = __builtin_ldexp(p1, (int)k1);
+}
+
 // fast_rsqrt written so that its only constant (0.5) is an inline operand
 __device__ __forceinline__ double fast_rsqrt_ic(double x)
 {

@@ -761,6 +761,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.npsf = h->npsf; a.ntsf = h->ntsf; a.sym = h->d_sym; a.isym = h->d_isym; a.compat = h->ni_compat;
         a.type = types; a.active = h->active;
         a.rc_rad = h->sym_rad[2]; a.rc_ang = h->sym_ang[3];
+        a.por_rad = ANNP_MY_PI / a.rc_rad; a.por_ang = ANNP_MY_PI / a.rc_ang;
         a.rad_em = h->ni_rad_em;
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = vtab; a.vatom = d_vatom; a.ncount = h->ncount.p; a.errflag = h->d_flags;
         if (a.npsf > NI_MAXP || a.ntsf > NI_MAXT)
@@ -998,6 +999,20 @@ void annp_hip_clear(annp_hip_handle *h)
     delete h;
 }
 
+// Order in which the Behler kernels visit the angular functions: by (lambda, eta, zeta) -- one squaring ladder per lambda, one exp per
+// pair.  perm[pos] = index of the function in the file's order.
+static std::vector<int> ni_visit_order(const double *ang, int nt)
+{
+    std::vector<int> perm(nt);
+    for (int m = 0; m < nt; m++) perm[m] = m;
+    std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) {
+        if (ang[4 * x + 1] != ang[4 * y + 1]) return ang[4 * x + 1] < ang[4 * y + 1];
+        if (ang[4 * x] != ang[4 * y]) return ang[4 * x] < ang[4 * y];
+        return ang[4 * x + 2] < ang[4 * y + 2];
+    });
+    return perm;
+}
+
 int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device,
                   int nlocal_hint, int nall_hint, int max_nbors_hint)
 {
@@ -1177,7 +1192,11 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
                 for (int n = 0; n < nt; n++) T[(size_t)(np_ + nt + l) * nsf + np_ + n] = shq[n * nt + l];
             for (int n = 0; n < nt; n++) T[(size_t)(np_ + 2 * nt) * nsf + np_ + n] = 1.0L;
         } else {
-            for (int k = 0; k < nsf; k++) T[(size_t)k * nsf + k] = 1.0L;
+            // radial weights as they are, angular ones in the order the kernels visit the functions (ni_visit_order: the force
+            // pass copies its coefficient rows straight from memory)
+            const std::vector<int> perm = ni_visit_order(p->cofsymang, p->ntsf);
+            for (int k = 0; k < np_; k++) T[(size_t)k * nsf + k] = 1.0L;
+            for (int pos = 0; pos < nt; pos++) T[(size_t)(np_ + pos) * nsf + np_ + perm[pos]] = 1.0L;
         }
         // one operand image per element: its weights (layer 0 in the device layout), biases and coefmat
         std::vector<double> img_all;
@@ -1213,14 +1232,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
         h->sym_ang.assign(p->cofsymang, p->cofsymang + 4 * p->ntsf);
         // visit order (lambda, eta, zeta): one squaring ladder per lambda, one exp per pair
         const int nt = p->ntsf;
-        std::vector<int> perm(nt);
-        for (int m = 0; m < nt; m++) perm[m] = m;
+        const std::vector<int> perm = ni_visit_order(p->cofsymang, nt);
         const double *ang = p->cofsymang;
-        std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) {
-            if (ang[4 * x + 1] != ang[4 * y + 1]) return ang[4 * x + 1] < ang[4 * y + 1];
-            if (ang[4 * x] != ang[4 * y]) return ang[4 * x] < ang[4 * y];
-            return ang[4 * x + 2] < ang[4 * y + 2];
-        });
         std::vector<double> etas;
         std::vector<int> eidx(nt), zint(nt);
         for (int pos = 0; pos < nt; pos++) {

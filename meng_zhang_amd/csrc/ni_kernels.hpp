@@ -54,7 +54,11 @@ __host__ __device__ constexpr int ni_plist(bool force) { return ni_ch(force) * 1
 #endif
 constexpr int NI_RUN = NI_RUN_GROUPS;
 constexpr int NI_TSLOTS = 128;
-constexpr int NI_TPROBE = 8;
+constexpr int NI_XSTAGE = 4096 + 128;   // bytes of the force pass's landing area for positions fetched ahead (ni_preload)
+#ifndef NI_TPROBE_N
+#define NI_TPROBE_N 8
+#endif
+constexpr int NI_TPROBE = NI_TPROBE_N;
 #ifndef NI_WAVES_PER_SIMD
 #define NI_WAVES_PER_SIMD 4     // descriptor pass: 512 / 4 = 128 VGPRs
 #endif
@@ -75,6 +79,8 @@ struct NiArgs {
     const double *sym;          // see "per-function tables" below
     const int *isym;
     double rc_rad, rc_ang;      // Bohr
+    double por_rad, por_ang;    // pi / rc_rad, pi / rc_ang, divided on the host (a wave-uniform double division is a dozen vector instructions and
+                                // a register pair that lives across the whole kernel)
     unsigned long long rad_em;  // byte m: eta_m / eta_0 of radial function m when that is a small integer (then
                                 // exp(-eta_m r^2) = exp(-eta_0 r^2)^k: one exp per neighbour instead of npsf), else 0
     double *G;
@@ -105,11 +111,16 @@ struct NiArgs {
 
 // per-wave LDS: records of NI_GA atoms (7 doubles + index; the force pass adds 3 accumulators and the
 // atoms' coefficient rows), or the reduction scratch of the descriptor pass, whichever is larger
-__host__ __device__ inline int ni_coef_stride(int nsf) { return nsf | 1; }
+// (the force pass's coefficient rows arrive by LDS-DMA, 256 B = 32 doubles per row -- nsf <= ANNP_GPAD = 32 is checked at init: a
+// stride of 34 doubles keeps the rows 16-byte aligned and the four atoms' copies of a weight in four different banks)
+constexpr int NI_CSTRIDE = 34;
+static_assert(ANNP_GPAD <= 32, "coefficient rows of the Behler force pass");
+__host__ __device__ inline int ni_coef_stride(int) { return NI_CSTRIDE; }
 __host__ __device__ inline size_t ni_lds_per_wave(int cap, bool force, int nsf, bool gpairs = false)
 {
     const size_t R = (size_t)NI_GA * cap + 2;          // + two dummy records for idle lanes
-    size_t b = R * 7 * 8 + (force ? R * 3 * 8 + (size_t)NI_GA * ni_coef_stride(nsf) * 8 + (size_t)NI_TSLOTS * (3 * 8 + 4) : 0) + R * 4 + NI_GA * 4 +
+    // (force pass: the seven record arrays double as the landing area of ni_preload, NI_XSTAGE bytes)
+    size_t b = (force ? (R * 7 * 8 > (size_t)NI_XSTAGE ? R * 7 * 8 : (size_t)NI_XSTAGE) : R * 7 * 8) + (force ? R * 3 * 8 + (size_t)NI_GA * ni_coef_stride(nsf) * 8 + (size_t)NI_TSLOTS * (3 * 8 + 4) + R * 4 + NI_GA * 4 : 0) + R * 4 + NI_GA * 4 +
                ((force && gpairs) ? 0 : (size_t)NI_GA * ni_plist(force) * 2);     // (pair lists read from memory need no room here)
     const size_t scratch = (size_t)NI_GA * NI_RED * NI_REDROW * 8;
     if (!force && b < scratch) b = scratch;
@@ -269,7 +280,7 @@ __device__ __forceinline__ NiConst ni_tables_fill(double *lds, const NiArgs &p, 
             }
         }
         if (lane >= NI_KE && lane < NI_KM) { if (lane - NI_KE < t.ne) v = t.etas[lane - NI_KE]; }
-        if (lane == NI_KM) v = ANNP_MY_PI / p.rc_ang;
+        if (lane == NI_KM) v = p.por_ang;
         if (lane == NI_KM + 1) v = p.rc_ang;
         if (lane == NI_KM + 2) v = ANNP_CFLENGTH;
         if (lane == NI_KM + 3) v = 1.0 / ANNP_CFLENGTH;
@@ -386,6 +397,7 @@ struct NiLds {
     int *tkey;                                    // [NI_TSLOTS]
     int *j;                                       // [NI_GA * cap]
     int *ci;                                      // [NI_GA] atom index of each group, -1 = none
+    int *sl, *cs;                                 // force pass: slot of the run's force table that takes neighbour s / centre g (-1: straight to memory)
     unsigned short *pl;                           // [NI_GA][ni_plist] in-range pairs of the current chunk
 };
 
@@ -397,13 +409,14 @@ __device__ __forceinline__ NiLds ni_carve(unsigned char *wbase, int cap, int cst
     double *d = reinterpret_cast<double *>(wbase);
     L.dx = d; L.dy = L.dx + R; L.dz = L.dy + R; L.r = L.dz + R; L.rinv = L.r + R; L.fc = L.rinv + R; L.dfc = L.fc + R;
     d = L.dfc + R;
+    if (FORCE && 7 * R * 8 < NI_XSTAGE) d = reinterpret_cast<double *>(wbase + NI_XSTAGE);
     L.a0 = L.a1 = L.a2 = L.coef = L.tacc = nullptr;
-    L.tkey = nullptr;
+    L.tkey = nullptr; L.sl = L.cs = nullptr;
     if (FORCE) { L.a0 = d; L.a1 = L.a0 + R; L.a2 = L.a1 + R; L.coef = L.a2 + R; L.tacc = L.coef + NI_GA * cstride; d = L.tacc + 3 * NI_TSLOTS; }
     L.j = reinterpret_cast<int *>(d);
     L.ci = L.j + R;
     int *after = L.ci + NI_GA;
-    if (FORCE) { L.tkey = after; after += NI_TSLOTS; }
+    if (FORCE) { L.tkey = after; after += NI_TSLOTS; L.sl = after; after += R; L.cs = after; after += NI_GA; }
     L.pl = reinterpret_cast<unsigned short *>(after);
     return L;
 }
@@ -431,7 +444,7 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
     }
     const double rcmax = fmax(p.rc_rad, p.rc_ang);
     const double rc2 = (rcmax / ANNP_CFLENGTH) * (rcmax / ANNP_CFLENGTH) * (1.0 + 1e-12);   // coarse filter in A^2
-    const double pi_over_rc = ANNP_MY_PI / p.rc_ang;
+    const double pi_over_rc = p.por_ang;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int g = lane >> 4, l = lane & 15;
     // first sweep, one row at a time (everything about the row is wave-uniform): cheap distance filter, survivors
@@ -606,51 +619,207 @@ __device__ __forceinline__ void ni_request(const NiArgs &p, int ii0, int row0, i
     q.j1 = (there && l + NI_GL < p.nbr_stride) ? row[l + NI_GL] : 0;
 }
 
-// Force pass: rebuild the records from the compact lists the descriptor pass left (same entries, same order).
-__device__ __forceinline__ int ni_stage_compact(const NiArgs &p, const NiAhead &q, int row0, const NiLds &L, const double *T, int lane, int &nl, int &npairs)
+// ---- force pass: the run's force table, and what a group needs from memory, fetched a group ahead ----------------------------
+// Timing builds (profiles/r05_ni_timing_builds.txt) showed the force pass spending 0.50 of its 0.82 ms OUTSIDE the pair loop, on a fifth of
+// its instructions: each group of a wave's run began with dependent round trips (permutation -> coefficient row; header -> row ->
+// positions) and ended with a chain of LDS round trips (one ds_cmpst per probe of the force table and neighbour, two passes over ~18
+// neighbours on 16 lanes), at three waves per SIMD.  Now
+//  * the coefficient rows arrive in visit order (annp_hip_init permutes the rows of the network's output map: no index load, no
+//    division by nsf) and are fetched -- with the centre's and the first two neighbours' positions per lane -- for the NEXT group
+//    right after the current group's pair loop, so the loads fly during its epilogue;
+//  * the force-table slot of every neighbour is found then as well, while those loads are in flight (all the probes of a lane in one
+//    loop: three ds_cmpst per trip instead of three loops), and kept in the record: the epilogue adds to a known slot;
+//  * staging and epilogue treat a lane's two neighbours (l and l + 16) side by side in straight-line code instead of two trips
+//    of a loop, so their sincos / exp chains interleave.
+// Key j's slot in the wave-private table, claimed if new; -1 after NI_TPROBE occupied slots (the contribution then goes straight to memory).
+// Up to three keys per lane are resolved together (want_k false: no key).
+__device__ __forceinline__ void ni_table_claim3(int *tkey, bool w0, int j0, bool w1, int j1, bool w2, int j2, int &r0, int &r1, int &r2)
+{
+    unsigned a0 = ((unsigned)j0 * 0x9E3779B1u) >> 25, a1 = ((unsigned)j1 * 0x9E3779B1u) >> 25, a2 = ((unsigned)j2 * 0x9E3779B1u) >> 25;
+    r0 = r1 = r2 = -1;
+#pragma unroll 1
+    for (int probe = 0; probe < NI_TPROBE; probe++) {
+        if (!__any(w0 || w1 || w2)) break;
+        int o0 = 0, o1 = 0, o2 = 0;
+        if (w0) o0 = atomicCAS(&tkey[a0], -1, j0);
+        if (w1) o1 = atomicCAS(&tkey[a1], -1, j1);
+        if (w2) o2 = atomicCAS(&tkey[a2], -1, j2);
+        if (w0 && (o0 == -1 || o0 == j0)) { r0 = (int)a0; w0 = false; }
+        if (w1 && (o1 == -1 || o1 == j1)) { r1 = (int)a1; w1 = false; }
+        if (w2 && (o2 == -1 || o2 == j2)) { r2 = (int)a2; w2 = false; }
+        a0 = (a0 + 1) & (NI_TSLOTS - 1); a1 = (a1 + 1) & (NI_TSLOTS - 1); a2 = (a2 + 1) & (NI_TSLOTS - 1);
+    }
+}
+
+// add to a slot of the table, or to memory
+__device__ __forceinline__ void ni_table_add(const NiLds &L, double *f, int slot, int j, double fx, double fy, double fz)
+{
+    if (slot >= 0) { atomicAdd(&L.tacc[3 * slot], fx); atomicAdd(&L.tacc[3 * slot + 1], fy); atomicAdd(&L.tacc[3 * slot + 2], fz); }
+    else { atomicAdd(&f[3 * (size_t)j], fx); atomicAdd(&f[3 * (size_t)j + 1], fy); atomicAdd(&f[3 * (size_t)j + 2], fz); }
+}
+
+typedef const __attribute__((address_space(1))) unsigned char *ni_gbp;
+typedef __attribute__((address_space(3))) unsigned char *ni_lbp;
+// The coefficient row of atom GA of a group (radial, then angular in visit order -- as it lies in memory) from memory into LDS: 16 lanes
+// x 16 bytes, one instruction per atom so that the rows land NI_CSTRIDE apart.  The rows' 16 GA bytes of extra stride go into the
+// instruction's immediate offset, which counts on both sides -- hence the source moved back by as much -- and the LDS base is the same
+// for all four: with a base per atom the compiler merges the four branches into one instruction whose base differs from lane to
+// lane, and the base is one scalar register, M0.
+template <int GA>
+__device__ __forceinline__ void ni_coef_row(const NiArgs &p, int ii0, const NiLds &L, int g, int l)
+{
+    if (g == GA) {
+        const ni_gbp src = (ni_gbp)(p.coef + (size_t)min(ii0 + GA, p.inum - 1) * ANNP_CPAD + 2 * l);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src - GA * (NI_CSTRIDE * 8 - 256)),
+                                         (__attribute__((address_space(3))) void *)(ni_lbp)(unsigned char *)L.coef, 16, GA * (NI_CSTRIDE * 8 - 256), 0);
+    }
+}
+
+// Positions, coefficient rows and table slots of the group whose headers `q` holds (ni_request: landed by now).  Nothing of it is
+// held in registers: 25 of them across the epilogue is what the compiler answered with scratch stores right behind each load
+// -- five exposed round trips instead of none.  The data goes from memory into LDS by itself (global_load_lds), the coefficient rows
+// to their place (dead since the pair loop ended: the radial weights were used when the records were made), the positions into the
+// record arrays dx..dfc, dead as well (the epilogue reads a0..a2, j and sl; the VIRIAL variant reads dx, dy, dz too and therefore
+// runs its epilogue first).  A position is 24 bytes; it comes as two overlapping 16-byte pieces per lane, (x, y) and (y, z); piece k of
+// every lane lies at 1024 k + 16 lane.
+//   [0, 4096)  neighbours l (pieces 0, 1) and l + 16 (pieces 2, 3)      [4096, 4224)  the four centres, two pieces of 64 bytes
+// limit: groups with more neighbours than this are not this launch's (their rows in p.nbr were never written: nothing of them is an index)
+__device__ __forceinline__ void ni_preload(const NiArgs &p, const NiAhead &q, int ii0, int limit, int cstride, const NiLds &L, int lane, int &s0, int &s1, int &sc)
+{
+    const int g = lane >> 4, l = lane & 15;
+    int nmax = 0;
+#pragma unroll
+    for (int ga = 0; ga < NI_GA; ga++) nmax = max(nmax, __builtin_amdgcn_readlane(q.hn, ga));
+    const int nlg = nmax > limit ? 0 : __shfl(q.hn, g, 64);
+    // (every lane loads: what a row holds beyond its atom's count is not an index -- atom 0 is read instead, as for an absent centre)
+    const size_t j0 = l < nlg ? (size_t)q.j0 : 0, j1 = l + NI_GL < nlg ? (size_t)q.j1 : 0;
+    const ni_lbp stage = (ni_lbp)(unsigned char *)L.dx;
+    const ni_gbp x0 = (ni_gbp)(p.x + 3 * j0), x1 = (ni_gbp)(p.x + 3 * j1);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)x0, (__attribute__((address_space(3))) void *)stage, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x0 + 8), (__attribute__((address_space(3))) void *)(stage + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)x1, (__attribute__((address_space(3))) void *)(stage + 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x1 + 8), (__attribute__((address_space(3))) void *)(stage + 3072), 16, 0, 0);
+    if (lane < NI_GA) {
+        const ni_gbp xc = (ni_gbp)(p.x + 3 * (size_t)max(q.hi, 0));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)xc, (__attribute__((address_space(3))) void *)(stage + 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xc + 8), (__attribute__((address_space(3))) void *)(stage + 4096 + 64), 16, 0, 0);
+    }
+    // the coefficient rows (radial, then angular in visit order -- as they lie in memory): 16 lanes x 16 bytes per atom, one
+    // instruction per atom so that the rows land cstride apart
+    ni_coef_row<0>(p, ii0, L, g, l); ni_coef_row<1>(p, ii0, L, g, l); ni_coef_row<2>(p, ii0, L, g, l); ni_coef_row<3>(p, ii0, L, g, l);
+    ni_table_claim3(L.tkey, l < nlg, q.j0, l + NI_GL < nlg, q.j1, lane < NI_GA && q.hi >= 0, q.hi, s0, s1, sc);
+}
+
+// W neighbours' records from their distance vectors, side by side (W = 2: a lane's neighbours l and l + 16; the coefficient loads of
+// the sincos / exp evaluations are shared and their chains interleave).  The force accumulators start from the radial part (ni:693-709:
+// -sum_m c_m d/dr [exp(-eta_m r^2) fc(r)] along -x_ij / r_ij) instead of zero: the epilogue that used to add it -- a sincos and an exp per
+// neighbour at the end of the group -- is then three reads and three adds.  cr: the radial weights of this lane's atom (LDS, written
+// before this is called).  When the radial and the angular functions share their cutoff (the shipped potential) its function is
+// evaluated once.
+template <int NP, int NL, unsigned EM, int W>
+__device__ __forceinline__ void ni_records(const NiArgs &p, const NiLds &L, const double *srad, const double *cr, const int (&s)[W], const bool (&there)[W],
+                                           const double (&dx)[W], const double (&dy)[W], const double (&dz)[W], const int (&j)[W], const int (&slot)[W])
+{
+    double rinv[W], r[W], rm[W], fc[W], dfc[W], fcr[W], dfcr[W], rmc[W], e0[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const double rsq = dx[w] * dx[w] + dy[w] * dy[w] + dz[w] * dz[w];
+        rinv[w] = fast_rsqrt_ic(rsq);
+        r[w] = rsq * rinv[w];
+        rm[w] = r[w] * ANNP_CFLENGTH;
+        rmc[w] = fmin(rm[w], p.rc_rad);
+    }
+    auto cut = [&](double rc, double por, double (&f)[W], double (&df)[W]) {      // (outside the cutoff the argument is pi: the values are dropped)
+        double sn[W], cs[W];
+        if constexpr (W == 2) sincos_0_pi_s2(por * fmin(rm[0], rc), por * fmin(rm[1], rc), sn[0], cs[0], sn[1], cs[1]);
+        else sincos_0_pi_s(por * fmin(rm[0], rc), sn[0], cs[0]);
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            const bool in = rm[w] < rc;
+            f[w] = in ? 0.5 * (cs[w] + 1.0) : 0.0;
+            df[w] = in ? (sn[w] * -0.5) * por : 0.0;
+        }
+    };
+    cut(p.rc_ang, p.por_ang, fc, dfc);
+    if (p.rc_rad != p.rc_ang) cut(p.rc_rad, p.por_rad, fcr, dfcr);
+    else {
+#pragma unroll
+        for (int w = 0; w < W; w++) { fcr[w] = fc[w]; dfcr[w] = dfc[w]; }
+    }
+    const double eta0 = srad[0];
+    if constexpr (W == 2) exp_neg_s2(-eta0 * rmc[0] * rmc[0], -eta0 * rmc[1] * rmc[1], e0[0], e0[1]);
+    else e0[0] = exp_neg_s(-eta0 * rmc[0] * rmc[0]);
+    double R[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) R[w] = 0.0;
+#pragma unroll
+    for (int m = 0; m < NP; m++)
+        if (m < p.npsf) {
+            const double eta = srad[3 * m], c = cr[m];
+            const int km = NL > 0 ? NI_BYTE(EM, m & 3) : (int)((p.rad_em >> (8 * m)) & 255ull);
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                const double em = km > 0 ? ni_powi(e0[w], km) : exp_neg_s(-eta * rmc[w] * rmc[w]);
+                R[w] = fma(c, em * (-fcr[w] * 2.0 * eta * rmc[w] + dfcr[w]), R[w]);
+            }
+        }
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const double sc = -R[w] * rinv[w];              // dr_dj = -xij/rij   (fcr = dfcr = 0 outside the radial cutoff)
+        if (there[w]) {
+            const int q = s[w];
+            L.dx[q] = dx[w]; L.dy[q] = dy[w]; L.dz[q] = dz[w]; L.j[q] = j[w]; L.sl[q] = slot[w];
+            L.r[q] = r[w]; L.rinv[q] = rinv[w]; L.fc[q] = fc[w]; L.dfc[q] = dfc[w];
+            L.a0[q] = sc * dx[w]; L.a1[q] = sc * dy[w]; L.a2[q] = sc * dz[w];
+        }
+    }
+}
+
+// Force pass: rebuild the records from the compact lists the descriptor pass left (same entries, same order) and from what
+// ni_preload sent into LDS.
+template <int NP, int NL, unsigned EM>
+__device__ __forceinline__ int ni_stage_compact(const NiArgs &p, const NiAhead &q, int s0, int s1, int sc, int row0, int nsf, int cstride, const double *srad,
+                                                const NiLds &L, int lane, int &nl, int &npairs)
 {
     const int cap = p.n_cap;
     const int hi = q.hi, hn = q.hn, hp = q.hp;
-    double hx = 0.0, hy = 0.0, hz = 0.0;
-    if (lane < NI_GA) {
-        if (hi >= 0) { hx = p.x[3 * (size_t)hi]; hy = p.x[3 * (size_t)hi + 1]; hz = p.x[3 * (size_t)hi + 2]; }
-        L.ci[lane] = hi;
-    }
+    if (lane < NI_GA) { L.ci[lane] = hi; L.cs[lane] = sc; }
     const int g = lane >> 4, l = lane & 15;
     nl = __shfl(hn, g, 64);
     npairs = __shfl(hp, g, 64);
-    const double xi = __shfl(hx, g, 64), yi = __shfl(hy, g, 64), zi = __shfl(hz, g, 64);
     int nmax = 0;
 #pragma unroll
     for (int ga = 0; ga < NI_GA; ga++) nmax = max(nmax, __builtin_amdgcn_readlane(hn, ga));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // what ni_preload sent has arrived
     if (nmax > cap) return nmax;
-    const double pi_over_rc = ANNP_MY_PI / p.rc_ang;
-    if (lane < 2) {     // dummy records, as in ni_stage
+    // positions out of the staging area (which is the record arrays: every lane reads before any lane writes)
+    const double2 *sw = reinterpret_cast<const double2 *>(L.dx);
+    const double2 cxy = sw[256 + g], cyz = sw[260 + g];
+    const double2 p0 = sw[lane], q0 = sw[64 + lane], p1 = sw[128 + lane], q1 = sw[192 + lane];
+    const double cx = cxy.x, cy = cxy.y, cz = cyz.y;
+    const double dx0 = cx - p0.x, dy0 = cy - p0.y, dz0 = cz - q0.y;
+    const double dx1 = cx - p1.x, dy1 = cy - p1.y, dz1 = cz - q1.y;
+    wave_lds_sync();
+    if (lane < 2) {     // dummy records, as in ni_stage (values made from the lane number: a double constant would be built in a
+                        // register pair, hoisted out of the run and spilled)
         const int s = NI_GA * cap + lane;
+        const double far = (double)(1000 + lane);
         L.dx[s] = lane == 0 ? 1.0 : 0.0; L.dy[s] = lane == 0 ? 0.0 : 1.0; L.dz[s] = 0.0;
-        L.r[s] = 1e3; L.rinv[s] = 1e-3; L.fc[s] = 0.0; L.dfc[s] = 0.0;
+        L.r[s] = far; L.rinv[s] = __builtin_amdgcn_rcp(far); L.fc[s] = 0.0; L.dfc[s] = 0.0;
     }
-    wave_lds_sync();        // math table and coefficient rows written above are visible from here on
-    const int *row = p.nbr + (size_t)(row0 + g) * p.nbr_stride;       // row0 = ii0, or 4 x the queue slot in a fix-up launch
-    for (int a = l; a < nmax; a += NI_GL) {
-        if (a < nl) {
-            const int s = g * cap + a;
-            const int j = a == l ? q.j0 : (a == l + NI_GL ? q.j1 : row[a]);
-            const double dx = xi - p.x[3 * (size_t)j], dy = yi - p.x[3 * (size_t)j + 1], dz = zi - p.x[3 * (size_t)j + 2];
-            const double rsq = dx * dx + dy * dy + dz * dz;
-            const double rinv = fast_rsqrt_ic(rsq);
-            const double r = rsq * rinv;
-            const double rm = r * ANNP_CFLENGTH;
-            double fc = 0.0, dfc = 0.0;
-            if (rm < p.rc_ang) {
-                double sn, cs;
-                sincos_0_pi_s(pi_over_rc * rm, sn, cs);
-                fc = 0.5 * (cs + 1.0);
-                dfc = -0.5 * pi_over_rc * sn;
-            }
-            L.dx[s] = dx; L.dy[s] = dy; L.dz[s] = dz; L.j[s] = j;
-            L.r[s] = r; L.rinv[s] = rinv; L.fc[s] = fc; L.dfc[s] = dfc;
-            L.a0[s] = 0.0; L.a1[s] = 0.0; L.a2[s] = 0.0;
+    const double *cr = L.coef + g * cstride;
+    if (nmax > NI_GL)
+        ni_records<NP, NL, EM, 2>(p, L, srad, cr, {g * cap + l, g * cap + l + NI_GL}, {l < nl, l + NI_GL < nl}, {dx0, dx1}, {dy0, dy1}, {dz0, dz1}, {q.j0, q.j1}, {s0, s1});
+    else
+        ni_records<NP, NL, EM, 1>(p, L, srad, cr, {g * cap + l}, {l < nl}, {dx0}, {dy0}, {dz0}, {q.j0}, {s0});
+    if (nmax > 2 * NI_GL) {         // rows longer than the two entries per lane that were fetched ahead (dense systems, the fix-up launch)
+        const int *row = p.nbr + (size_t)(row0 + g) * p.nbr_stride;       // row0 = ii0, or 4 x the queue slot in a fix-up launch
+        for (int a = l + 2 * NI_GL; a < nmax; a += NI_GL) {
+            const bool there = a < nl;
+            const int j = there ? row[a] : 0;
+            int slot, u1, u2;
+            ni_table_claim3(L.tkey, there, j, false, 0, false, 0, slot, u1, u2);
+            ni_records<NP, NL, EM, 1>(p, L, srad, cr, {g * cap + min(a, cap - 1)}, {there}, {cx - p.x[3 * (size_t)j]}, {cy - p.x[3 * (size_t)j + 1]}, {cz - p.x[3 * (size_t)j + 2]}, {j}, {slot});
         }
     }
     return nmax;
@@ -801,7 +970,7 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
         const double rm = (a < nl ? L.r[sbase + a] : 1e30) * ANNP_CFLENGTH;
         if (rm < p.rc_rad) {
             double sn, cs;
-            sincos_0_pi_s(ANNP_MY_PI / p.rc_rad * rm, sn, cs);
+            sincos_0_pi_s(p.por_rad * rm, sn, cs);
             const double fc = 0.5 * (cs + 1.0);
             const double e0 = exp_neg_s(-srad[0] * rm * rm);
 #pragma unroll
@@ -880,6 +1049,14 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
     }
 }
 
+// developer timing builds (tools/ni_stamps.py): -DANNP_NI_STAMPS writes s_memtime at a few points of a wave's life into the descriptor
+// row of the first atom of its run (the descriptor buffer is dead by then); no stamp is compiled into the library
+#ifdef ANNP_NI_STAMPS
+#define NI_STAMP(k) do { if (!p.fix && lane == 0) reinterpret_cast<unsigned long long *>(p.G + (size_t)run * NI_RUN * NI_GA * ANNP_GPAD)[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NI_STAMP(k) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------
 // GPAIRS: the in-range pairs of an atom are read from the list the descriptor pass left in memory (p.pairs) instead of
 // being found again by a pre-pass over all n (n - 1) / 2 candidates: 88 of the pass's 730 vector instructions per atom,
@@ -892,6 +1069,11 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     const int wave = uniform(threadIdx.x >> 6);
     const int run = uniform((p.fix ? (int)blockIdx.x : xcd_block()) * ANNP_WAVES_PER_BLOCK + wave);
     if (!p.fix && run * NI_RUN * NI_GA >= p.inum) return;
+    NI_STAMP(0);
+    // the first group's headers and list entries are asked for before anything else: the tables below are built while they fly
+    NiAhead ahead;
+    bool early = !p.fix;
+    if (early) ni_request(p, run * NI_RUN * NI_GA, run * NI_RUN * NI_GA, lane, ahead);
     const int nslots = p.fix ? min(*p.ovf_count, p.ovf_cap) : 0;   // fix-up launch: a small grid whose waves walk the queue
     const int nwaves = (int)gridDim.x * ANNP_WAVES_PER_BLOCK;
     const int nsf = p.npsf + p.ntsf;
@@ -900,26 +1082,13 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     NiTab tab = ni_tab(p.sym, p.isym, p.npsf, p.ntsf, nullptr);
     const double *srad = tab.rad;
     const NiConst kc = ni_tables_fill<NL, NE, NZ>(reinterpret_cast<double *>(lds_raw), p, tab, lane);
-    const double *T = kc.T;
     unsigned char *wbase = lds_raw + NI_TABLE_DOUBLES * 8 + (size_t)wave * ni_lds_per_wave(cap, true, nsf, GPAIRS);
     const NiLds L = ni_carve<true>(wbase, cap, cstride);
     for (int sl = lane; sl < NI_TSLOTS; sl += 64) { L.tkey[sl] = -1; L.tacc[3 * sl] = 0.0; L.tacc[3 * sl + 1] = 0.0; L.tacc[3 * sl + 2] = 0.0; }
-    // add a force to atom j's entry of the run's table; after NI_TPROBE occupied slots it goes straight to global memory
-    auto table_add = [&](int j, double fx, double fy, double fz) {
-        unsigned sl = ((unsigned)j * 0x9E3779B1u) >> 25;
-#pragma unroll 1
-        for (int probe = 0; probe < NI_TPROBE; probe++) {
-            const int old = atomicCAS(&L.tkey[sl], -1, j);
-            if (old == -1 || old == j) {
-                atomicAdd(&L.tacc[3 * sl], fx); atomicAdd(&L.tacc[3 * sl + 1], fy); atomicAdd(&L.tacc[3 * sl + 2], fz);
-                return;
-            }
-            sl = (sl + 1) & (NI_TSLOTS - 1);
-        }
-        atomicAdd(&p.f[3 * (size_t)j], fx); atomicAdd(&p.f[3 * (size_t)j + 1], fy); atomicAdd(&p.f[3 * (size_t)j + 2], fz);
-    };
-    NiAhead ahead;
-    bool requested = false;     // `ahead` holds the coming group (main launch, from the second group of the run on)
+    wave_lds_sync();
+    NI_STAMP(1);
+    int as0 = -1, as1 = -1, asc = -1;    // table slots of the coming group's neighbours / centres (ni_preload)
+    bool requested = false;     // `ahead` holds the coming group, and what ni_preload sent for it is on its way (main launch, from the second group of the run on)
 #pragma unroll 1
     for (int gk = 0;; gk++) {
     int ii0, row0;
@@ -940,30 +1109,27 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     int lane_q = lane;
     asm volatile("" : "+v"(lane_q));
     const int g = lane_q >> 4, l = lane_q & 15;
-    // this wave's coefficient rows: radial as they are, angular in visit order
-    for (int idx = lane_q; idx < NI_GA * nsf; idx += 64) {
-        const int gq = idx / nsf, k = idx % nsf;
-        double v = 0.0;
-        if (ii0 + gq < p.inum) v = p.coef[(size_t)(ii0 + gq) * ANNP_CPAD + (k < p.npsf ? k : p.npsf + tab.perm[k - p.npsf])];
-        L.coef[gq * cstride + k] = v;
-    }
     int nl, npg;
-    if (!requested) ni_request(p, ii0, row0, lane_q, ahead);
-    const int nmax = ni_stage_compact(p, ahead, row0, L, T, lane_q, nl, npg);
+    const int limit = p.fix ? cap : min(cap, p.skip_above);
+    if (!requested) { if (!early) ni_request(p, ii0, row0, lane_q, ahead); ni_preload(p, ahead, ii0, limit, cstride, L, lane_q, as0, as1, asc); }
+    early = false;
+    NI_STAMP(2 + 5 * gk);
+    const int nmax = ni_stage_compact<NP, NL, EM>(p, ahead, as0, as1, asc, row0, nsf, cstride, srad, L, lane_q, nl, npg);
+    NI_STAMP(3 + 5 * gk);
     // (only in the instantiation that reads its pairs from memory: the one with its own pre-pass has no register to spare, and it
     // is the fall-back and the fix-up kernel, not the steady state)
     requested = GPAIRS && !p.fix && gk + 1 < NI_RUN && ii0 + NI_GA < p.inum;
-    if (requested) ni_request(p, ii0 + NI_GA, ii0 + NI_GA, lane_q, ahead);       // consumed by the next trip of this loop
+    if (requested) ni_request(p, ii0 + NI_GA, ii0 + NI_GA, lane_q, ahead);       // consumed behind this group's pair loop (ni_preload)
     // more neighbours than these records hold: the group is in the queue (the descriptor pass's fix-up launch left its true
     // counts) and the force pass's own fix-up launch takes it; without a queue it is an error
-    if (nmax > (p.fix ? cap : min(cap, p.skip_above))) {
+    if (nmax > limit) {
         if (lane_q == 0 && (p.fix || !p.ovf_list)) atomicMax(p.errflag, nmax);
+        if (requested) ni_preload(p, ahead, ii0 + NI_GA, limit, cstride, L, lane_q, as0, as1, asc);
         wave_lds_sync();
         continue;
     }
     wave_lds_sync();
-    const double *cr = L.coef + g * cstride;        // radial weights of this lane's atom
-    const double *cw = cr + p.npsf;                 // angular, visit order
+    const double *cw = L.coef + g * cstride + p.npsf;       // angular weights of this lane's atom, visit order
     const int sbase = g * cap;
 
     const int npl = nl * (nl - 1) / 2;
@@ -1027,36 +1193,24 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     }
     if (!GPAIRS) wave_lds_sync();            // the list is rewritten by the next chunk
     }
+    // the coming group's positions, coefficient rows and table slots: requested here, they fly during this group's epilogue
+    // (into record arrays the epilogue does not read -- unless it tallies the virial: then it goes first)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    NI_STAMP(4 + 5 * gk);
+    if (!VIRIAL && requested) ni_preload(p, ahead, ii0 + NI_GA, limit, cstride, L, lane_q, as0, as1, asc);
+    NI_STAMP(5 + 5 * gk);
     double fi0 = 0.0, fi1 = 0.0, fi2 = 0.0;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
-    for (int a = l; a < nmax; a += NI_GL) {
+    // one neighbour's total (the radial part was there before the pair loop's sums: ni_record), handed to the table and to the centre
+    auto finish = [&](int a) {
         if (a < nl) {
             const int s = sbase + a;
-            double g0 = L.a0[s], g1 = L.a1[s], g2 = L.a2[s];
-            const double r = L.r[s], rm = r * ANNP_CFLENGTH;
-            const double d0 = L.dx[s], d1 = L.dy[s], d2 = L.dz[s];
-            if (rm < p.rc_rad) {                                     // ni:693-709
-                double sn, cs;
-                const double por = ANNP_MY_PI / p.rc_rad;
-                sincos_0_pi_s(por * rm, sn, cs);
-                const double fc = 0.5 * (cs + 1.0), dfc = -0.5 * por * sn;
-                double R = 0.0;
-                const double e0 = exp_neg_s(-srad[0] * rm * rm);
-#pragma unroll
-                for (int m = 0; m < NP; m++)
-                    if (m < p.npsf) {
-                        const double eta = srad[3 * m];
-                        const int km = NL > 0 ? NI_BYTE(EM, m & 3) : (int)((p.rad_em >> (8 * m)) & 255ull);
-                        const double em = km > 0 ? ni_powi(e0, km) : exp_neg_s(-eta * rm * rm);
-                        R = fma(cr[m], em * (-fc * 2.0 * eta * rm + dfc), R);
-                    }
-                const double sc = -R * L.rinv[s];                     // dr_dj = -xij/rij
-                g0 = fma(sc, d0, g0); g1 = fma(sc, d1, g1); g2 = fma(sc, d2, g2);
-            }
+            const double g0 = L.a0[s], g1 = L.a1[s], g2 = L.a2[s];
             const int j = L.j[s];
-            table_add(j, -g0 * ANNP_CFFORCE, -g1 * ANNP_CFFORCE, -g2 * ANNP_CFFORCE);       // ni:186-189
+            ni_table_add(L, p.f, L.sl[s], j, -g0 * ANNP_CFFORCE, -g1 * ANNP_CFFORCE, -g2 * ANNP_CFFORCE);       // ni:186-189
             fi0 += g0; fi1 += g1; fi2 += g2;
             if (VIRIAL) {       // the reference tallies the un-converted force (ni:190-198)
+                const double d0 = L.dx[s], d1 = L.dy[s], d2 = L.dz[s];
                 const double w0 = d0 * g0, w1 = d1 * g1, w2 = d2 * g2, w3 = d0 * g1, w4 = d0 * g2, w5 = d1 * g2;
                 v0 += w0; v1 += w1; v2 += w2; v3 += w3; v4 += w4; v5 += w5;
                 if (p.vatom) {
@@ -1066,12 +1220,13 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
                 }
             }
         }
-    }
+    };
+    for (int a = l; a < nmax; a += NI_GL) finish(a);
     // group sums (16 lanes) -> the centre atom
     const int i = L.ci[g];
     // (a group is a DPP row: four row shifts leave its sum in its last lane, no LDS traffic)
     fi0 = row16_sum_to_last(fi0); fi1 = row16_sum_to_last(fi1); fi2 = row16_sum_to_last(fi2);
-    if (l == NI_GL - 1 && i >= 0) table_add(i, fi0 * ANNP_CFFORCE, fi1 * ANNP_CFFORCE, fi2 * ANNP_CFFORCE);
+    if (l == NI_GL - 1 && i >= 0) ni_table_add(L, p.f, L.cs[g], i, fi0 * ANNP_CFFORCE, fi1 * ANNP_CFFORCE, fi2 * ANNP_CFFORCE);
     if (VIRIAL) {
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
@@ -1096,8 +1251,12 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
             }
         }
     }
+    if (VIRIAL && requested) { wave_lds_sync(); ni_preload(p, ahead, ii0 + NI_GA, limit, cstride, L, lane_q, as0, as1, asc); }
     wave_lds_sync();            // the next group of the run reuses the records
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    NI_STAMP(6 + 5 * gk);
     }
+    NI_STAMP(22);
     // flush the run's table: one global atomic per distinct atom and component, the three components of an atom from three
     // neighbouring lanes of one instruction -- float atomics are executed at the memory side, one request per 64-byte line an
     // instruction touches, and a lane per atom issuing x, then y, then z made three requests of what is one (or two) lines
@@ -1107,6 +1266,14 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
         const int j = L.tkey[sl];
         if (j >= 0) atomicAdd(&p.f[3 * (size_t)j + c], L.tacc[k]);
     }
+    NI_STAMP(23);
+#ifdef ANNP_NI_STAMPS
+    if (!p.fix && lane == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        reinterpret_cast<unsigned long long *>(p.G + (size_t)run * NI_RUN * NI_GA * ANNP_GPAD)[24] = hw;
+    }
+#endif
 }
 
 // product shape of the angular set, filled by annp_hip_init: nl*ne*nz == ntsf when it is a full product

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): where a wave of annp_ni_force spends its life.  Needs a library built with -DANNP_NI_STAMPS
+(make -C meng_zhang_amd/csrc nistamps): the kernel then writes s_memtime stamps into descriptor rows, read back here.
+   ANNP_HIP_LIBRARY=$PWD/meng_zhang_amd/libannp_hip_nistamps.so python tools/ni_stamps.py 40 40 80"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+    from annp_testlib import A_NI, NI_POT, fcc, perturb
+    from meng_zhang_amd import PairANNP
+    from meng_zhang_amd.domain import SlabDomain
+    from meng_zhang_amd.lib import load_library
+    dims = [int(v) for v in sys.argv[1:4]] or [40, 40, 80]
+    while len(dims) < 3:
+        dims.append(dims[-1])
+    x0, box = fcc(*dims, A_NI)
+    xg = perturb(x0, 12345, 0.05)
+    lib = load_library()
+    dev = torch.device("cuda", 0)
+    dom = SlabDomain.from_global(xg, box, (1, 1, 1), 8.5, dev)
+    pair = PairANNP(1, device=0)
+    pair.settings([])
+    pair.coeff(["*", "*", NI_POT, "Ni"])
+    pair.init_style()
+    h = pair.handle
+    st = torch.cuda.current_stream(dev).cuda_stream
+    pn, pf, pg, mx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    assert lib.annp_hip_neigh_build_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), 8.5, C.byref(pn), C.byref(pf), C.byref(pg), C.byref(mx), st) == 0
+    eng = torch.zeros(1, dtype=torch.float64, device=dev)
+    for _ in range(4):
+        dom.f.zero_()
+        assert lib.annp_hip_compute_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value, dom.f.data_ptr(), None, eng.data_ptr(), None, None, st) == 0
+    rows = np.zeros((dom.nlocal, 32))
+    assert lib.annp_hip_last_descriptors(h, rows.ctypes.data_as(C.POINTER(C.c_double)), dom.nlocal) == 0
+    t = rows.view(np.uint64)[::16]           # one row per wave: the first atom of its run of 16
+    t = t[(t[:, 23] > t[:, 0]) & (t[:, 21] > 0)]
+    ti = t.astype(np.int64)
+    names = [("start -> tables, force table cleared", 0, 1)]
+    for g in range(4):
+        b = 2 + 5 * g
+        prev = 1 if g == 0 else b - 1
+        names += [("g%d wait for what was fetched ahead (g0: fetch)" % g, prev, b), ("g%d records" % g, b, b + 1), ("g%d pair loop" % g, b + 1, b + 2),
+                  ("g%d preload issued, slots claimed" % g, b + 2, b + 3), ("g%d epilogue" % g, b + 3, b + 4)]
+    names += [("flush", 22, 23)]
+    print("waves %d; ticks per wave (mean / median / p90):" % len(t))
+    tot = {}
+    for nm, a, b in names:
+        d = (ti[:, b] - ti[:, a]).astype(np.float64)
+        print("  %-50s %9.0f %9.0f %9.0f" % (nm, d.mean(), np.median(d), np.percentile(d, 90)))
+        key = nm[3:] if nm[0] == "g" and nm[1].isdigit() else nm
+        tot[key] = tot.get(key, 0.0) + d.mean()
+    life = (ti[:, 23] - ti[:, 0]).astype(np.float64)
+    print("  %-50s %9.0f %9.0f %9.0f" % ("life", life.mean(), np.median(life), np.percentile(life, 90)))
+    print("by phase (mean ticks per wave, share of life):")
+    for k, v in tot.items():
+        print("  %-50s %9.0f  %.2f" % (k, v, v / life.mean()))
+    span = float(t[:, 23].max() - t[:, 0].min())
+    print("kernel span %.0f ticks; sum of lives / span / (1024 SIMDs) = %.2f waves per SIMD" % (span, life.sum() / span / 1024))
+
+
+if __name__ == "__main__":
+    main()
