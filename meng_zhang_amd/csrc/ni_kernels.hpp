@@ -423,25 +423,33 @@ __device__ __forceinline__ NiLds ni_carve(unsigned char *wbase, int cap, int cst
 
 // Filter the list rows of atoms ii0 .. ii0+3 into the records.  Returns the largest in-range count of the
 // four (uniform; > p.n_cap means the records overflowed and must not be used); nl = count of this lane's atom.
-template <bool FORCE>
-__device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L, const double *T, int lane, int &nl)
+// headers of a group: lane g < 4 fetches atom g (asked for before the kernel's tables are built, so that the two round trips overlap)
+struct NiHead { int hi, hjn; long long hbase; double hx, hy, hz; };
+__device__ __forceinline__ NiHead ni_stage_head(const NiArgs &p, int ii0, int lane)
 {
-    const int cap = p.n_cap;
-    // headers: lane g < 4 fetches atom g
-    int hi = -1, hjn = 0;
-    long long hbase = 0;
-    double hx = 0.0, hy = 0.0, hz = 0.0;
+    NiHead h;
+    h.hi = -1; h.hjn = 0; h.hbase = 0; h.hx = h.hy = h.hz = 0.0;
     if (lane < NI_GA) {
         const int ii = ii0 + lane;
         if (ii < p.inum) {
-            hi = p.ilist ? p.ilist[ii] : ii;
-            hjn = p.numneigh[hi];
-            if (p.type && !type_mapped(p.active, p.type[hi])) hjn = 0;      // centre of an unmapped type: nothing in range
-            hbase = p.first[hi];
-            hx = p.x[3 * (size_t)hi]; hy = p.x[3 * (size_t)hi + 1]; hz = p.x[3 * (size_t)hi + 2];
+            h.hi = p.ilist ? p.ilist[ii] : ii;
+            h.hjn = p.numneigh[h.hi];
+            if (p.type && !type_mapped(p.active, p.type[h.hi])) h.hjn = 0;      // centre of an unmapped type: nothing in range
+            h.hbase = p.first[h.hi];
+            h.hx = p.x[3 * (size_t)h.hi]; h.hy = p.x[3 * (size_t)h.hi + 1]; h.hz = p.x[3 * (size_t)h.hi + 2];
         }
-        L.ci[lane] = hi;
     }
+    return h;
+}
+
+template <bool FORCE>
+__device__ __forceinline__ int ni_stage(const NiArgs &p, const NiHead &head, const NiLds &L, int lane, int &nl)
+{
+    const int cap = p.n_cap;
+    const int hi = head.hi, hjn = head.hjn;
+    const long long hbase = head.hbase;
+    const double hx = head.hx, hy = head.hy, hz = head.hz;
+    if (lane < NI_GA) L.ci[lane] = hi;
     const double rcmax = fmax(p.rc_rad, p.rc_ang);
     const double rc2 = (rcmax / ANNP_CFLENGTH) * (rcmax / ANNP_CFLENGTH) * (1.0 + 1e-12);   // coarse filter in A^2
     const double pi_over_rc = p.por_ang;
@@ -573,24 +581,25 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, int ii0, const NiLds &L
     wave_lds_sync();
     // second sweep: the exact test of the reference (r * CFLENGTH < Rc, ni:693/729) and the per-neighbour terms.
     // Entries that fail it keep fc = 0 and r = huge, so every pair they enter is rejected by ni_pair.
-    for (int a = l; a < nmax; a += NI_GL) {
-        if (a < nl) {
-            const int s = g * cap + a;
-            const double rsq = L.r[s];
-            const double rinv = fast_rsqrt_ic(rsq);
-            const double r = rsq * rinv;
-            const double rm = r * ANNP_CFLENGTH;
-            double fc = 0.0, dfc = 0.0;
-            if (rm < p.rc_ang) {
-                double sn, cs;
-                sincos_0_pi_s(pi_over_rc * rm, sn, cs);
-                fc = 0.5 * (cs + 1.0);
-                dfc = -0.5 * pi_over_rc * sn;
-            }
-            L.r[s] = r; L.rinv[s] = rinv; L.fc[s] = fc; L.dfc[s] = dfc;
-            if (FORCE) { L.a0[s] = 0.0; L.a1[s] = 0.0; L.a2[s] = 0.0; }
+    // A lane's neighbours l and l + 16 side by side (shared coefficient loads, interleaved chains), the rest of a long row in a loop.
+    auto second = [&](int a0, int a1) {
+        const bool t0 = a0 < nl, t1 = a1 < nl;
+        const int s0 = g * cap + (t0 ? a0 : 0), s1 = g * cap + (t1 ? a1 : 0);
+        const double q0 = L.r[s0], q1 = L.r[s1];
+        const double i0 = fast_rsqrt_ic(q0), i1 = fast_rsqrt_ic(q1);
+        const double r0 = q0 * i0, r1 = q1 * i1;
+        const double m0 = r0 * ANNP_CFLENGTH, m1 = r1 * ANNP_CFLENGTH;
+        double sn0, cs0, sn1, cs1;
+        sincos_0_pi_s2(pi_over_rc * fmin(m0, p.rc_ang), pi_over_rc * fmin(m1, p.rc_ang), sn0, cs0, sn1, cs1);
+        const bool in0 = m0 < p.rc_ang, in1 = m1 < p.rc_ang;
+        if (t0) { L.r[s0] = r0; L.rinv[s0] = i0; L.fc[s0] = in0 ? 0.5 * (cs0 + 1.0) : 0.0; L.dfc[s0] = in0 ? (sn0 * -0.5) * pi_over_rc : 0.0; }
+        if (t1) { L.r[s1] = r1; L.rinv[s1] = i1; L.fc[s1] = in1 ? 0.5 * (cs1 + 1.0) : 0.0; L.dfc[s1] = in1 ? (sn1 * -0.5) * pi_over_rc : 0.0; }
+        if (FORCE) {
+            if (t0) { L.a0[s0] = 0.0; L.a1[s0] = 0.0; L.a2[s0] = 0.0; }
+            if (t1) { L.a0[s1] = 0.0; L.a1[s1] = 0.0; L.a2[s1] = 0.0; }
         }
-    }
+    };
+    for (int a = l; a < nmax; a += 2 * NI_GL) second(a, a + NI_GL);
     return nmax;
 }
 
@@ -879,22 +888,44 @@ __device__ __forceinline__ int ni_prepass(const NiLds &L, const NiConst &c, NiWa
     // test (ni_pair: the reference's r * CFLENGTH < Rc) then rejects, never the other way round
     const double cfl = c.K[NI_KM + 2], rc = c.K[NI_KM + 1], rc2a = c.K[NI_KM + 4];
     int cnt = 0;
-    for (int t = t0; t < t1; t++) {
-        const int pp = t * NI_GL + l;
-        int a, b;
-        ni_walk_next(walk, a, b);
-        const bool live = pp < npl;
-        const int sa = live ? sbase + a : NI_GA * cap, sb = live ? sbase + b : NI_GA * cap + 1;
-        const double g0 = L.dx[sb] - L.dx[sa], g1 = L.dy[sb] - L.dy[sa], g2 = L.dz[sb] - L.dz[sa];
-        const double gsq = g0 * g0 + g1 * g1 + g2 * g2;
-        const bool ok = live && (L.r[sa] * cfl < rc) && (L.r[sb] * cfl < rc) && (gsq < rc2a);
-        const unsigned long long m = __ballot(ok);
-        const unsigned m16 = (unsigned)(m >> (NI_GL * g)) & 0xffffu;
-        if (ok) L.pl[g * plist + cnt + __popc(m16 & ((1u << l) - 1u))] = (unsigned short)(a | (b << 8));
-        cnt += __popc(m16);
+    // two trips at a time: the sixteen record reads of both go out together, then the two tests (a trip by itself is a chain of
+    // LDS round trip -> a dozen dependent operations -> ballot -> write: ten of them in a row were a quarter of the descriptor pass)
+    for (int t = t0; t < t1; t += 2) {
+        int a[2], b[2], sa[2], sb[2];
+        bool live[2];
+        double ax[2], ay[2], az[2], ar[2], bx[2], by[2], bz[2], br[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int pp = (t + u) * NI_GL + l;
+            ni_walk_next(walk, a[u], b[u]);
+            live[u] = (t + u < t1) && pp < npl;
+            sa[u] = live[u] ? sbase + a[u] : NI_GA * cap; sb[u] = live[u] ? sbase + b[u] : NI_GA * cap + 1;
+            ax[u] = L.dx[sa[u]]; ay[u] = L.dy[sa[u]]; az[u] = L.dz[sa[u]]; ar[u] = L.r[sa[u]];
+            bx[u] = L.dx[sb[u]]; by[u] = L.dy[sb[u]]; bz[u] = L.dz[sb[u]]; br[u] = L.r[sb[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const double g0 = bx[u] - ax[u], g1 = by[u] - ay[u], g2 = bz[u] - az[u];
+            const double gsq = g0 * g0 + g1 * g1 + g2 * g2;
+            const bool ok = live[u] & (ar[u] * cfl < rc) & (br[u] * cfl < rc) & (gsq < rc2a);
+            const unsigned long long m = __ballot(ok);
+            const unsigned m16 = (unsigned)(m >> (NI_GL * g)) & 0xffffu;
+            if (ok) L.pl[g * plist + cnt + __popc(m16 & ((1u << l) - 1u))] = (unsigned short)(a[u] | (b[u] << 8));
+            cnt += __popc(m16);
+        }
     }
     return cnt;
 }
+
+// developer timing builds (tools/ni_stamps.py): -DANNP_NI_STAMPS writes s_memtime at a few points of a wave's life into the descriptor
+// row of the first atom of its run (the descriptor buffer is dead by then); no stamp is compiled into the library
+#ifdef ANNP_NI_STAMPS
+#define NI_STAMP(k) do { if (!p.fix && lane == 0) reinterpret_cast<unsigned long long *>(p.G + (size_t)run * NI_RUN * NI_GA * ANNP_GPAD)[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define NI_DSTAMP(k) do { dstamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NI_STAMP(k) do { } while (0)
+#define NI_DSTAMP(k) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------
 // FIX: the fix-up instantiation (its waves walk the queue: a loop around the body, bounded to 2 waves per SIMD so that what the
@@ -904,14 +935,20 @@ template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM, bool
 __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) void annp_ni_desc(NiArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+#ifdef ANNP_NI_STAMPS
+    unsigned long long dstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    NI_DSTAMP(0);
     const int lane0 = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
     const int nsf = p.npsf + p.ntsf;
     const int cap = p.n_cap;
+    // main launch: the group's headers are asked for first, the tables below are built while they fly
+    NiHead head;
+    if (!FIX) head = ni_stage_head(p, uniform((xcd_block() * ANNP_WAVES_PER_BLOCK + wave) * NI_GA), lane0);
     NiTab tab = ni_tab(p.sym, p.isym, p.npsf, p.ntsf, nullptr);
     const double *srad = tab.rad;
     const NiConst kc = ni_tables_fill<NL, NE, NZ>(reinterpret_cast<double *>(lds_raw), p, tab, lane0);
-    const double *T = kc.T;
     unsigned char *wbase = lds_raw + NI_TABLE_DOUBLES * 8 + (size_t)wave * ni_lds_per_wave(cap, false, nsf);
     const NiLds L = ni_carve<false>(wbase, cap, 0);
     double *scratch = reinterpret_cast<double *>(wbase);
@@ -935,7 +972,10 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
         wave_lds_sync();        // the records and the reduction scratch of the previous entry are dead
     }
     int nl;
-    const int nmax = ni_stage<false>(p, ii0, L, T, lane, nl);
+    NI_DSTAMP(1);
+    if (FIX) head = ni_stage_head(p, ii0, lane);
+    const int nmax = ni_stage<false>(p, head, L, lane, nl);
+    NI_DSTAMP(2);
     const int ncl = __shfl(nl, NI_GL * (lane & (NI_GA - 1)), 64);     // count of atom (lane & 3), for lanes 0..3
     // a group whose records overflowed is skipped by both passes: its count is left at 0 so that the force pass, which
     // runs without the host having looked at the error word, finds nothing to do for it (its list rows are not written)
@@ -965,23 +1005,34 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
     for (int m = 0; m < NP; m++) gr[m] = 0.0;
 #pragma unroll
     for (int m = 0; m < NT; m++) ga[m] = 0.0;      // indexed by visit position
-    // G2 (ni:686-711): lane l of the group owns neighbours l, l+16, ...
-    for (int a = l; a < nmax; a += NI_GL) {
-        const double rm = (a < nl ? L.r[sbase + a] : 1e30) * ANNP_CFLENGTH;
-        if (rm < p.rc_rad) {
-            double sn, cs;
-            sincos_0_pi_s(p.por_rad * rm, sn, cs);
-            const double fc = 0.5 * (cs + 1.0);
-            const double e0 = exp_neg_s(-srad[0] * rm * rm);
-#pragma unroll
-            for (int m = 0; m < NP; m++)
-                if (m < p.npsf) {
-                    // (the compiled-in shape has its radial etas in the ratios EM too: ni_is_shipped_shape)
-                    const int km = NL > 0 ? NI_BYTE(EM, m & 3) : (int)((p.rad_em >> (8 * m)) & 255ull);
-                    gr[m] += (km > 0 ? ni_powi(e0, km) : exp_neg_s(-srad[3 * m] * rm * rm)) * fc;
-                }
+    // G2 (ni:686-711): lane l of the group owns neighbours l, l+16, ... (two at a time; where the radial and the angular functions
+    // share their cutoff -- the shipped potential -- its function is the one the records already hold)
+    const bool same_rc = p.rc_rad == p.rc_ang;
+    for (int a = l; a < nmax; a += 2 * NI_GL) {
+        const bool t0 = a < nl, t1 = a + NI_GL < nl;
+        const int s0 = sbase + (t0 ? a : 0), s1 = sbase + (t1 ? a + NI_GL : 0);
+        const double m0 = fmin(L.r[s0] * ANNP_CFLENGTH, p.rc_rad), m1 = fmin(L.r[s1] * ANNP_CFLENGTH, p.rc_rad);
+        double f0, f1;
+        if (same_rc) { f0 = L.fc[s0]; f1 = L.fc[s1]; }
+        else {
+            double sn0, cs0, sn1, cs1;
+            sincos_0_pi_s2(p.por_rad * m0, p.por_rad * m1, sn0, cs0, sn1, cs1);
+            f0 = 0.5 * (cs0 + 1.0); f1 = 0.5 * (cs1 + 1.0);          // (0 at the cutoff itself)
         }
+        if (!(t0 && L.r[s0] * ANNP_CFLENGTH < p.rc_rad)) f0 = 0.0;          // ni:693: outside the cutoff nothing is added
+        if (!(t1 && L.r[s1] * ANNP_CFLENGTH < p.rc_rad)) f1 = 0.0;
+        double e0, e1;
+        exp_neg_s2(-srad[0] * m0 * m0, -srad[0] * m1 * m1, e0, e1);
+#pragma unroll
+        for (int m = 0; m < NP; m++)
+            if (m < p.npsf) {
+                // (the compiled-in shape has its radial etas in the ratios EM too: ni_is_shipped_shape)
+                const int km = NL > 0 ? NI_BYTE(EM, m & 3) : (int)((p.rad_em >> (8 * m)) & 255ull);
+                gr[m] += (km > 0 ? ni_powi(e0, km) : exp_neg_s(-srad[3 * m] * m0 * m0)) * f0;
+                gr[m] += (km > 0 ? ni_powi(e1, km) : exp_neg_s(-srad[3 * m] * m1 * m1)) * f1;
+            }
     }
+    NI_DSTAMP(3);
     // G4 (ni:713-767): the atom's pairs over its 16 lanes
     const int npl = nl * (nl - 1) / 2;
     const int trips = (nmax * (nmax - 1) / 2 + NI_GL - 1) / NI_GL;
@@ -991,6 +1042,7 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
     for (int t0 = 0; t0 < trips; t0 += CH) {
         const int cnt = ni_prepass(L, kc, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST);
         wave_lds_sync();
+        NI_DSTAMP(4);
         const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
                              max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
         for (int t2 = 0; t2 * NI_GL < cmax; t2++) {
@@ -1017,6 +1069,7 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
     }
     if (p.npair && l == 0 && ii0 + g < p.inum) p.npair[ii0 + g] = poff;
     wave_lds_sync();
+    NI_DSTAMP(5);
     // sum the 16 lane partials of every atom through LDS, NI_RED sums per round (records are dead now)
     constexpr int NS = NP + NT;
 #pragma unroll
@@ -1046,16 +1099,13 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
     }
     for (int idx = lane; idx < NI_GA * ANNP_GPAD; idx += 64)
         if (idx % ANNP_GPAD >= nsf && ii0 + idx / ANNP_GPAD < p.inum) p.G[(size_t)ii0 * ANNP_GPAD + idx] = 0.0;
+#ifdef ANNP_NI_STAMPS
+    NI_DSTAMP(6);
+    if (!FIX && nsf <= 28 && lane == 0 && ii0 + 1 < p.inum)       // (slots 28..31 of the first two atoms' rows: the network weighs them with zeros)
+        for (int k = 0; k < 7; k++) reinterpret_cast<unsigned long long *>(p.G + (size_t)(ii0 + k / 4) * ANNP_GPAD)[28 + k % 4] = dstamp[k];
+#endif
     }
 }
-
-// developer timing builds (tools/ni_stamps.py): -DANNP_NI_STAMPS writes s_memtime at a few points of a wave's life into the descriptor
-// row of the first atom of its run (the descriptor buffer is dead by then); no stamp is compiled into the library
-#ifdef ANNP_NI_STAMPS
-#define NI_STAMP(k) do { if (!p.fix && lane == 0) reinterpret_cast<unsigned long long *>(p.G + (size_t)run * NI_RUN * NI_GA * ANNP_GPAD)[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define NI_STAMP(k) do { } while (0)
-#endif
 
 // ---------------------------------------------------------------------------------
 // GPAIRS: the in-range pairs of an atom are read from the list the descriptor pass left in memory (p.pairs) instead of

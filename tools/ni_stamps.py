@@ -41,6 +41,19 @@ def main():
         assert lib.annp_hip_compute_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value, dom.f.data_ptr(), None, eng.data_ptr(), None, None, st) == 0
     rows = np.zeros((dom.nlocal, 32))
     assert lib.annp_hip_last_descriptors(h, rows.ctypes.data_as(C.POINTER(C.c_double)), dom.nlocal) == 0
+    if os.environ.get("NI_STAMPS_PASS", "force") == "desc":          # the descriptor pass: seven stamps in slots 28..31 of the rows of a group's first two atoms
+        u = rows.view(np.uint64)
+        n4 = (dom.nlocal // 4) * 4
+        d = np.concatenate([u[0:n4:4, 28:32], u[1:n4:4, 28:31]], axis=1).astype(np.int64)
+        d = d[(d[:, 6] > d[:, 0]) & (d[:, 0] > 0)]
+        nm = ["start -> tables", "stage (rows, positions, filter, records)", "list rows out, G2", "pre-pass of the pairs", "visit", "lane sums, rows out"]
+        life = (d[:, 6] - d[:, 0]).astype(np.float64)
+        print("waves %d; ticks per wave (mean / median / p90 / share of life):" % len(d))
+        for k, name in enumerate(nm):
+            v = (d[:, k + 1] - d[:, k]).astype(np.float64)
+            print("  %-45s %9.0f %9.0f %9.0f  %.2f" % (name, v.mean(), np.median(v), np.percentile(v, 90), v.mean() / life.mean()))
+        print("  %-45s %9.0f %9.0f %9.0f" % ("life", life.mean(), np.median(life), np.percentile(life, 90)))
+        return
     t = rows.view(np.uint64)[::16]           # one row per wave: the first atom of its run of 16
     t = t[(t[:, 23] > t[:, 0]) & (t[:, 21] > 0)]
     ti = t.astype(np.int64)
