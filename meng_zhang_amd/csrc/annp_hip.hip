@@ -152,6 +152,7 @@ struct annp_hip_handle {
     int *d_isym = nullptr;
     unsigned long long ni_rad_em = 0;   // NiArgs::rad_em
     NiShape ni_shape = {0, 0, 0};       // {lambda} x {eta} x {zeta} product shape of the angular set (0 = none)
+    double ni_lam[4] = {0, 0, 0, 0}, ni_eta[4] = {0, 0, 0, 0};   // its distinct lambda / eta values in visit order
     std::vector<double> sym_rad, sym_ang;
     // work buffers
     DevBuf<double> fscratch;            // forces of one evaluation by themselves, when the global virial is taken as sum x (x) f (annp_fdotr_add)
@@ -762,6 +763,8 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         a.type = types; a.active = h->active;
         a.rc_rad = h->sym_rad[2]; a.rc_ang = h->sym_ang[3];
         a.por_rad = ANNP_MY_PI / a.rc_rad; a.por_ang = ANNP_MY_PI / a.rc_ang;
+        a.rc2a = (a.rc_ang / ANNP_CFLENGTH) * (a.rc_ang / ANNP_CFLENGTH) * (1.0 + 1e-12);
+        for (int k = 0; k < 4; k++) { a.lam[k] = h->ni_lam[k]; a.eta[k] = h->ni_eta[k]; }
         a.rad_em = h->ni_rad_em;
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = vtab; a.vatom = d_vatom; a.ncount = h->ncount.p; a.errflag = h->d_flags;
         if (a.npsf > NI_MAXP || a.ntsf > NI_MAXT)
@@ -1263,6 +1266,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
                 prod = ang[4 * m + 1] == lams[l] && ang[4 * m] == etas[e] && ang[4 * m + 2] == zets[z];
             }
             h->ni_shape = prod ? NiShape{nl_, ne_, nz_, 0u, 0u} : NiShape{0, 0, 0, 0u, 0u};
+            for (int k = 0; k < 4; k++) { h->ni_lam[k] = k < nl_ ? lams[k] : 0.0; h->ni_eta[k] = k < ne_ ? etas[k] : 0.0; }   // visit order (kernel arguments)
             if (prod && nz_ <= 4)
                 for (int z = 0; z < nz_; z++) h->ni_shape.zp |= (unsigned)zint[z] << (8 * z);    // visit positions 0..nz-1: l = e = 0
         }

@@ -54,6 +54,7 @@ __host__ __device__ constexpr int ni_plist(bool force) { return ni_ch(force) * 1
 #endif
 constexpr int NI_RUN = NI_RUN_GROUPS;
 constexpr int NI_TSLOTS = 128;
+constexpr int NI_CAP_FIXED = 20;     // record capacity compiled into the steady-state instantiation of the force pass
 constexpr int NI_XSTAGE = 4096 + 128;   // bytes of the force pass's landing area for positions fetched ahead (ni_preload)
 #ifndef NI_TPROBE_N
 #define NI_TPROBE_N 8
@@ -61,6 +62,9 @@ constexpr int NI_XSTAGE = 4096 + 128;   // bytes of the force pass's landing are
 constexpr int NI_TPROBE = NI_TPROBE_N;
 #ifndef NI_WAVES_PER_SIMD
 #define NI_WAVES_PER_SIMD 4     // descriptor pass: 512 / 4 = 128 VGPRs
+#endif
+#ifndef NI_KEEP_RECORDS
+#define NI_KEEP_RECORDS 1
 #endif
 #ifndef NI_FORCE_WAVES_PER_SIMD
 #define NI_FORCE_WAVES_PER_SIMD 3
@@ -79,6 +83,9 @@ struct NiArgs {
     const double *sym;          // see "per-function tables" below
     const int *isym;
     double rc_rad, rc_ang;      // Bohr
+    double lam[4], eta[4];      // product shape (NiShape): the distinct lambda and eta values in visit order -- kernel arguments, i.e. scalar
+                                // registers: every use of one used to be a broadcast read of an LDS table, a quarter of the pair loops' LDS traffic
+    double rc2a;                // (rc_ang / CFLENGTH)^2 (1 + 1e-12): the pre-pass's bound on r_jk^2, in A^2
     double por_rad, por_ang;    // pi / rc_rad, pi / rc_ang, divided on the host (a wave-uniform double division is a dozen vector instructions and
                                 // a register pair that lives across the whole kernel)
     unsigned long long rad_em;  // byte m: eta_m / eta_0 of radial function m when that is a small integer (then
@@ -245,21 +252,18 @@ __device__ __forceinline__ void ni_visit_functions(const NiTab &t, int ntsf, dou
     }
 }
 
-// ---- constants of the pair loops, kept in LDS next to the math table ---------------------------
-// Same reason as the math table: a wave-uniform double that is live across the pair loop costs a register
-// pair (or two SGPRs, of which there are not enough either).  Every wave of a block writes the same values.
-//   K[KL + l]        lambda_l                          (product shape)
-//   K[KP + z]        2^(1-zeta_z)
-//   K[KD + 8 l + z]  2^(1-zeta_z) zeta_z lambda_l
-//   K[KE + e]        distinct eta values
-//   K[KM ..]         pi/Rc_ang, Rc_ang, CFLENGTH, 1/CFLENGTH, (Rc_ang / CFLENGTH)^2 (1 + 1e-12)
+// ---- constants of the pair loops ------------------------------------------------------------------
+// A wave-uniform double that lives across the pair loop wants a scalar register pair.  Rounds 2-4 kept such constants in an LDS table
+// next to a copy of the math table (annp_common.hpp) and read each where it was used: a 64-lane broadcast per use, ~20 of the ~75
+// values a trip of the force pass's pair loop moves through the CU's one LDS pipe -- which that loop loads as heavily as it loads the
+// vector pipe (round 5).  Now: lambda, eta and the cutoff are kernel arguments (NiArgs::lam, eta, rc_ang, por_ang: scalar registers,
+// re-read from the argument segment when they do not fit), CFLENGTH is a literal, and the factors 2^(1-zeta), zeta 2^(1-zeta) of the
+// product shape are applied with v_ldexp_f64 / a literal (the zetas are template arguments).  What is left in LDS is the generic
+// shape's copy of the sorted per-function table:
 //   S[...]           copy of the sorted per-function table + etas (generic shape)
-constexpr int NI_KL = 0, NI_KP = 4, NI_KD = 12, NI_KE = 44, NI_KM = 48, NI_KTAB = 56;
-constexpr int NI_TABLE_DOUBLES = ANNP_MTAB + NI_KTAB + 4 * NI_MAXT + NI_MAXE;
+constexpr int NI_TABLE_DOUBLES = 4 * NI_MAXT + NI_MAXE;
 
-struct NiConst {
-    const double *T, *K;
-};
+struct NiConst { };         // (nothing left: kept as the tag the visit functions take)
 
 // compile-time exponents of the product-shape kernels: byte z of ZP = zeta_z, byte e of EM = eta_e / eta_0
 #define NI_BYTE(packed, k) ((int)(((packed) >> (8 * (k))) & 255u))
@@ -267,38 +271,32 @@ struct NiConst {
 template <int NL, int NE, int NZ>
 __device__ __forceinline__ NiConst ni_tables_fill(double *lds, const NiArgs &p, NiTab &t, int lane)
 {
-    double *T = lds, *K = T + ANNP_MTAB, *S = K + NI_KTAB;
-    mtab_fill(T, lane);
-    if (lane < NI_KTAB) {
-        double v = 0.0;
-        if constexpr (NL > 0) {
-            if (lane < NI_KP) { if (lane < NL) v = t.sorted[4 * (lane * NE * NZ) + 1]; }
-            else if (lane < NI_KD) { const int z = lane - NI_KP; if (z < NZ) v = t.sorted[4 * z + 3]; }
-            else if (lane < NI_KE) {
-                const int l = (lane - NI_KD) >> 3, z = (lane - NI_KD) & 7;
-                if (l < NL && z < NZ) v = t.sorted[4 * z + 3] * t.sorted[4 * z + 2] * t.sorted[4 * (l * NE * NZ) + 1];
-            }
-        }
-        if (lane >= NI_KE && lane < NI_KM) { if (lane - NI_KE < t.ne) v = t.etas[lane - NI_KE]; }
-        if (lane == NI_KM) v = p.por_ang;
-        if (lane == NI_KM + 1) v = p.rc_ang;
-        if (lane == NI_KM + 2) v = ANNP_CFLENGTH;
-        if (lane == NI_KM + 3) v = 1.0 / ANNP_CFLENGTH;
-        if (lane == NI_KM + 4) v = (p.rc_ang / ANNP_CFLENGTH) * (p.rc_ang / ANNP_CFLENGTH) * (1.0 + 1e-12);
-        K[lane] = v;
+    if constexpr (NL == 0) {
+        double *S = lds;
+        for (int idx = lane; idx < 4 * p.ntsf + NI_MAXE; idx += 64) S[idx] = t.sorted[idx];
+        t.sorted = S; t.etas = S + 4 * p.ntsf;      // the generic visit reads the LDS copy
     }
-    for (int idx = lane; idx < 4 * p.ntsf + NI_MAXE; idx += 64) S[idx] = t.sorted[idx];
-    NiConst c;
-    c.T = T; c.K = K;
-    t.T = T; t.sorted = S; t.etas = S + 4 * p.ntsf;      // the generic visit reads the LDS copy
-    return c;
+    return NiConst{};
+}
+
+// 2^(1-zeta) x, and zeta 2^(1-zeta) x, for an integer zeta that is known once the visit is unrolled (a byte of the template argument ZP):
+// exact scalings (ni:748: term_coe = 2^(1-zeta)); a zeta that is a power of two goes into the exponent
+__device__ __forceinline__ double ni_pref(double x, int zeta) { return __builtin_ldexp(x, 1 - zeta); }
+__device__ __forceinline__ double ni_dpref(double x, int zeta)
+{
+    if ((zeta & (zeta - 1)) == 0) {
+        int k = 0;
+        for (int v = zeta; v > 1; v >>= 1) k++;
+        return __builtin_ldexp(x, 1 - zeta + k);
+    }
+    return __builtin_ldexp(x, 1 - zeta) * (double)zeta;
 }
 
 // exp(-eta_e r2sum) for the distinct etas: one exp, integer powers of it where eta_e is a multiple of eta_0
 template <int NE, unsigned EM>
-__device__ __forceinline__ void ni_exps(const NiConst &c, double r2sum, double (&E)[NE])
+__device__ __forceinline__ void ni_exps(const NiArgs &p, double r2sum, double (&E)[NE])
 {
-    E[0] = exp_neg_s(-c.K[NI_KE] * r2sum);
+    E[0] = exp_neg_s(-p.eta[0] * r2sum);
 #pragma unroll
     for (int e = 1; e < NE; e++) E[e] = ni_powi(E[0], NI_BYTE(EM, e));
 }
@@ -307,13 +305,13 @@ __device__ __forceinline__ void ni_exps(const NiConst &c, double r2sum, double (
 // visit position = (l * NE + e) * NZ + z as in the sorted order: per function one FMA, per (l,z) the power.
 //   ga[pos] += 2^(1-zeta) (1+lambda cos)^zeta exp(-eta r2sum) * tfc
 template <int NL, int NE, int NZ, unsigned ZP, unsigned EM, int NT>
-__device__ __forceinline__ void ni_desc_cart(const NiConst &c, double ct, double r2sum, double tfc, double (&ga)[NT])
+__device__ __forceinline__ void ni_desc_cart(const NiArgs &p, double ct, double r2sum, double tfc, double (&ga)[NT])
 {
     double E[NE];
-    ni_exps<NE, EM>(c, r2sum, E);
+    ni_exps<NE, EM>(p, r2sum, E);
 #pragma unroll
     for (int l = 0; l < NL; l++) {
-        const double u = fma(c.K[NI_KL + l], ct, 1.0);
+        const double u = fma(p.lam[l], ct, 1.0);
         const bool ok = u > 0.0;                          // ni:744-747
         const double U0 = ok ? tfc : 0.0;
         double U[5];
@@ -321,7 +319,7 @@ __device__ __forceinline__ void ni_desc_cart(const NiConst &c, double ct, double
         U[1] = U[0] * U[0]; U[2] = U[1] * U[1]; U[3] = U[2] * U[2]; U[4] = U[3] * U[3];
 #pragma unroll
         for (int z = 0; z < NZ; z++) {
-            const double pwt = c.K[NI_KP + z] * ni_ladder_pow(U, U0, NI_BYTE(ZP, z));
+            const double pwt = ni_pref(ni_ladder_pow(U, U0, NI_BYTE(ZP, z)), NI_BYTE(ZP, z));
 #pragma unroll
             for (int e = 0; e < NE; e++) ga[(l * NE + e) * NZ + z] = fma(pwt, E[e], ga[(l * NE + e) * NZ + z]);
         }
@@ -331,59 +329,62 @@ __device__ __forceinline__ void ni_desc_cart(const NiConst &c, double ct, double
 // Force-pass visit for the product shape.  The three sums the force needs factor over eta:
 //   A3 = sum c val      = sum_e E_e B_e,      B_e = sum_lz c_lez pw_lz     (pw = 2^(1-zeta) (1+lambda cos)^zeta)
 //   A2 = sum c eta val  = sum_e eta_e E_e B_e
-//   A1 = sum c dval     = sum_e E_e D_e,      D_e = sum_lz c_lez dw_lz     (dw = d pw / d cos)
+//   A1 = sum c dval     = sum_e E_e D_e,      D_e = sum_l lambda_l sum_z c_lez dw_lz     (lambda dw = d pw / d cos)
 // so the visit itself is a polynomial in (1 + lambda cos) with the atom's weights -- 6 FMAs per (l,z) --
 // and the exponentials are only needed afterwards.
 // cw: this atom's weights in visit order (LDS, read as a 16-lane broadcast).
 template <int NL, int NE, int NZ, unsigned ZP, unsigned EM>
-__device__ __forceinline__ void ni_force_cart(const NiConst &c, const double *cw, double ct, double r2sum,
+__device__ __forceinline__ void ni_force_cart(const NiArgs &p, const double *cw, double ct, double r2sum,
                                               double &A1, double &A2, double &A3)
 {
     double B[NE], D[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) { B[e] = 0.0; D[e] = 0.0; }
-    // Software-pipelined by hand: the weights and constants of step s+1 are read while step s computes, and a
+    // Software-pipelined by hand: the weights of step s+1 are read while step s computes, and a
     // scheduling fence closes each step.  Left alone the compiler issues all LDS reads of the visit (and of
     // the exponential after it) at the top and holds ~110 registers of operands.
-    double cc[NE], kp, kd;
+    double cc[NE];
     auto fetch = [&](int l, int z) {
 #pragma unroll
         for (int e = 0; e < NE; e++) cc[e] = cw[(l * NE + e) * NZ + z];
-        kp = c.K[NI_KP + z];
-        kd = c.K[NI_KD + 8 * l + z];
     };
     fetch(0, 0);
 #pragma unroll
     for (int l = 0; l < NL; l++) {
-        const double u = fma(c.K[NI_KL + l], ct, 1.0);
+        const double u = fma(p.lam[l], ct, 1.0);
         const bool ok = u > 0.0;
         const double U0 = ok ? 1.0 : 0.0;
         double U[5];
         U[0] = ok ? u : 0.0;
         U[1] = U[0] * U[0]; U[2] = U[1] * U[1]; U[3] = U[2] * U[2]; U[4] = U[3] * U[3];
+        double Dl[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) Dl[e] = 0.0;
 #pragma unroll
         for (int z = 0; z < NZ; z++) {
             double c0[NE];
 #pragma unroll
             for (int e = 0; e < NE; e++) c0[e] = cc[e];
-            const double pw = kp * ni_ladder_pow(U, U0, NI_BYTE(ZP, z));
-            const double dw = NI_BYTE(ZP, z) >= 1 ? kd * ni_ladder_pow(U, U0, NI_BYTE(ZP, z) - 1) : 0.0;
+            const double pw = ni_pref(ni_ladder_pow(U, U0, NI_BYTE(ZP, z)), NI_BYTE(ZP, z));
+            const double dw = NI_BYTE(ZP, z) >= 1 ? ni_dpref(ni_ladder_pow(U, U0, NI_BYTE(ZP, z) - 1), NI_BYTE(ZP, z)) : 0.0;
             if (z + 1 < NZ) fetch(l, z + 1);
             else if (l + 1 < NL) fetch(l + 1, 0);
 #pragma unroll
             for (int e = 0; e < NE; e++) {
                 B[e] = fma(c0[e], pw, B[e]);
-                D[e] = fma(c0[e], dw, D[e]);
+                Dl[e] = fma(c0[e], dw, Dl[e]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int e = 0; e < NE; e++) D[e] = fma(p.lam[l], Dl[e], D[e]);
     }
     double E[NE];
-    ni_exps<NE, EM>(c, r2sum, E);
+    ni_exps<NE, EM>(p, r2sum, E);
 #pragma unroll
     for (int e = 0; e < NE; e++) {
         A3 = fma(E[e], B[e], A3);
-        A2 = fma(c.K[NI_KE + e] * E[e], B[e], A2);
+        A2 = fma(p.eta[e] * E[e], B[e], A2);
         A1 = fma(E[e], D[e], A1);
     }
 }
@@ -787,10 +788,9 @@ __device__ __forceinline__ void ni_records(const NiArgs &p, const NiLds &L, cons
 // Force pass: rebuild the records from the compact lists the descriptor pass left (same entries, same order) and from what
 // ni_preload sent into LDS.
 template <int NP, int NL, unsigned EM>
-__device__ __forceinline__ int ni_stage_compact(const NiArgs &p, const NiAhead &q, int s0, int s1, int sc, int row0, int nsf, int cstride, const double *srad,
+__device__ __forceinline__ int ni_stage_compact(const NiArgs &p, const NiAhead &q, int s0, int s1, int sc, int row0, int cap, int nsf, int cstride, const double *srad,
                                                 const NiLds &L, int lane, int &nl, int &npairs)
 {
-    const int cap = p.n_cap;
     const int hi = q.hi, hn = q.hn, hp = q.hp;
     if (lane < NI_GA) { L.ci[lane] = hi; L.cs[lane] = sc; }
     const int g = lane >> 4, l = lane & 15;
@@ -840,11 +840,13 @@ __device__ __forceinline__ int ni_stage_compact(const NiArgs &p, const NiAhead &
 struct NiPairS {
     double ct, rjm, rkm, rgm, ig;   // ig = 1/r_jk (A^-1)
     double fcjk, dfcjk, tfc;
+    double xj[3], xk[3], ij, ik, fcj, fck;      // what the pair's records held (the force pass keeps them across the visit: since round 5 it has the registers,
+                                                // and its pair loop loads the LDS pipe as heavily as the vector pipe)
     bool ok;
 };
 
 // sa, sb: record slots (idle lanes pass the two dummy records: ok = false, everything finite)
-__device__ __forceinline__ NiPairS ni_pair(const NiLds &L, const NiConst &c, int sa, int sb)
+__device__ __forceinline__ NiPairS ni_pair(const NiLds &L, const NiArgs &p, int sa, int sb)
 {
     NiPairS q;
     const double rj = L.r[sa], rk = L.r[sb];
@@ -856,18 +858,21 @@ __device__ __forceinline__ NiPairS ni_pair(const NiLds &L, const NiConst &c, int
     const double gsq = g0 * g0 + g1 * g1 + g2 * g2;
     q.ig = fast_rsqrt_ic(gsq);
     q.ct = ((xj0 * ij) * (xk0 * ik) + (xj1 * ij) * (xk1 * ik)) + (xj2 * ij) * (xk2 * ik);
-    const double cfl = c.K[NI_KM + 2];
+    const double cfl = ANNP_CFLENGTH;
     q.rjm = rj * cfl; q.rkm = rk * cfl; q.rgm = (gsq * q.ig) * cfl;
-    const double rc = c.K[NI_KM + 1];
+    const double rc = p.rc_ang;
     q.ok = (q.rjm < rc) && (q.rkm < rc) && (q.rgm < rc);   // ni:729
     q.fcjk = 0.0; q.dfcjk = 0.0; q.tfc = 0.0;
+    q.xj[0] = xj0; q.xj[1] = xj1; q.xj[2] = xj2; q.xk[0] = xk0; q.xk[1] = xk1; q.xk[2] = xk2; q.ij = ij; q.ik = ik;
+    q.fcj = 0.0; q.fck = 0.0;
     if (q.ok) {
         double sn, cs;
-        const double por = c.K[NI_KM];
+        const double por = p.por_ang;
         sincos_0_pi_s(por * q.rgm, sn, cs);
         q.fcjk = 0.5 * (cs + 1.0);
         q.dfcjk = -0.5 * por * sn;
-        q.tfc = L.fc[sa] * L.fc[sb] * q.fcjk;
+        q.fcj = L.fc[sa]; q.fck = L.fc[sb];
+        q.tfc = q.fcj * q.fck * q.fcjk;
     }
     return q;
 }
@@ -881,12 +886,12 @@ __device__ __forceinline__ void ni_forget_lds() { asm volatile("" ::: "memory");
 // a dense list; the expensive part (cutoff function of r_jk, exponential, 24 functions) then runs over ceil(60/16)
 // = 4 trips instead of 10.  The visit applies the exact test again (ni_pair's `ok`).
 // Returns this lane's atom's count for the chunk (same value in the 16 lanes of a group).
-__device__ __forceinline__ int ni_prepass(const NiLds &L, const NiConst &c, NiWalk &walk, int g, int l, int sbase, int cap,
+__device__ __forceinline__ int ni_prepass(const NiLds &L, const NiArgs &p, NiWalk &walk, int g, int l, int sbase, int cap,
                                           int npl, int t0, int t1, const int plist)
 {
     // r_jk by its square against a bound a hair above the cutoff: the pre-pass may let a pair through that the visit's own
     // test (ni_pair: the reference's r * CFLENGTH < Rc) then rejects, never the other way round
-    const double cfl = c.K[NI_KM + 2], rc = c.K[NI_KM + 1], rc2a = c.K[NI_KM + 4];
+    const double cfl = ANNP_CFLENGTH, rc = p.rc_ang, rc2a = p.rc2a;
     int cnt = 0;
     // two trips at a time: the sixteen record reads of both go out together, then the two tests (a trip by itself is a chain of
     // LDS round trip -> a dozen dependent operations -> ballot -> write: ten of them in a row were a quarter of the descriptor pass)
@@ -1040,7 +1045,7 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
     constexpr int CH = ni_ch(false), PLIST = ni_plist(false);
     int poff = 0;               // pairs of this lane's atom written to p.pairs so far
     for (int t0 = 0; t0 < trips; t0 += CH) {
-        const int cnt = ni_prepass(L, kc, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST);
+        const int cnt = ni_prepass(L, p, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST);
         wave_lds_sync();
         NI_DSTAMP(4);
         const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
@@ -1049,11 +1054,11 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
             const int idx = t2 * NI_GL + l;
             const bool live = idx < cnt;
             const int v = live ? L.pl[g * PLIST + idx] : 0;
-            const NiPairS q = ni_pair(L, kc, live ? sbase + (v & 255) : NI_GA * cap, live ? sbase + (v >> 8) : NI_GA * cap + 1);
+            const NiPairS q = ni_pair(L, p, live ? sbase + (v & 255) : NI_GA * cap, live ? sbase + (v >> 8) : NI_GA * cap + 1);
             const double r2sum = q.rjm * q.rjm + q.rkm * q.rkm + q.rgm * q.rgm;
             const double tfc = q.tfc;                                   // idle lanes add zeros
             ni_forget_lds();                                            // (keeps the table reads inside the loop)
-            if constexpr (NL > 0) ni_desc_cart<NL, NE, NZ, ZP, EM, NT>(kc, q.ct, r2sum, tfc, ga);
+            if constexpr (NL > 0) ni_desc_cart<NL, NE, NZ, ZP, EM, NT>(p, q.ct, r2sum, tfc, ga);
             else
                 ni_visit_functions<NT, false>(tab, p.ntsf, q.ct, r2sum,
                                               [&](int pos, double val, double) { ga[pos] = fma(val, tfc, ga[pos]); });
@@ -1111,7 +1116,10 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
 // GPAIRS: the in-range pairs of an atom are read from the list the descriptor pass left in memory (p.pairs) instead of
 // being found again by a pre-pass over all n (n - 1) / 2 candidates: 88 of the pass's 730 vector instructions per atom,
 // a sixth of its LDS traffic and the 1 KB of LDS per wave that held the chunk's list.
-template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM, bool VIRIAL, bool GPAIRS>
+// CAP > 0: the record capacity is compiled in (p.n_cap equals it).  The ten record arrays of a wave then lie at constant offsets from
+// one base and a record access is `ds_read_b64 v, v offset:imm`; with the capacity in a register each array keeps its own base in a
+// scalar register -- more than there are: two dozen v_readlane of spilled ones and as many address additions per trip of the pair loop.
+template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM, bool VIRIAL, bool GPAIRS, int CAP = 0>
 __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(NiArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1127,7 +1135,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     const int nslots = p.fix ? min(*p.ovf_count, p.ovf_cap) : 0;   // fix-up launch: a small grid whose waves walk the queue
     const int nwaves = (int)gridDim.x * ANNP_WAVES_PER_BLOCK;
     const int nsf = p.npsf + p.ntsf;
-    const int cap = p.n_cap;
+    const int cap = CAP > 0 ? CAP : p.n_cap;
     const int cstride = ni_coef_stride(nsf);
     NiTab tab = ni_tab(p.sym, p.isym, p.npsf, p.ntsf, nullptr);
     const double *srad = tab.rad;
@@ -1164,7 +1172,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     if (!requested) { if (!early) ni_request(p, ii0, row0, lane_q, ahead); ni_preload(p, ahead, ii0, limit, cstride, L, lane_q, as0, as1, asc); }
     early = false;
     NI_STAMP(2 + 5 * gk);
-    const int nmax = ni_stage_compact<NP, NL, EM>(p, ahead, as0, as1, asc, row0, nsf, cstride, srad, L, lane_q, nl, npg);
+    const int nmax = ni_stage_compact<NP, NL, EM>(p, ahead, as0, as1, asc, row0, cap, nsf, cstride, srad, L, lane_q, nl, npg);
     NI_STAMP(3 + 5 * gk);
     // (only in the instantiation that reads its pairs from memory: the one with its own pre-pass has no register to spare, and it
     // is the fall-back and the fix-up kernel, not the steady state)
@@ -1191,7 +1199,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     for (int t0 = 0; t0 < (GPAIRS ? 1 : trips); t0 += CH) {
     int cnt;
     if (GPAIRS) cnt = npg;          // one "chunk": the whole list
-    else { cnt = ni_prepass(L, kc, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST); wave_lds_sync(); }
+    else { cnt = ni_prepass(L, p, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST); wave_lds_sync(); }
     const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
                          max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
     for (int t2 = 0; t2 * NI_GL < cmax; t2++) {
@@ -1201,7 +1209,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
         if (GPAIRS) { pv = pv_next; pv_next = (idx + NI_GL < cnt) ? gpl[idx + NI_GL] : 0; }
         else pv = lv ? L.pl[g * PLIST + idx] : 0;
         const int sa = lv ? sbase + (pv & 255) : NI_GA * cap, sb = lv ? sbase + (pv >> 8) : NI_GA * cap + 1;
-        const NiPairS q = ni_pair(L, kc, sa, sb);
+        const NiPairS q = ni_pair(L, p, sa, sb);
         const double r2sum = q.rjm * q.rjm + q.rkm * q.rkm + q.rgm * q.rgm;
         // everything below only matters for pairs inside the cutoffs; keeping the visit inside the branch also keeps
         // its LDS reads next to their use (hoisted out, they would all be live across the branch)
@@ -1209,7 +1217,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
             // A1 = sum c term1 CFLENGTH, A2 = sum c term2, A3 = sum c term3   (ni:752-754)
             double A1 = 0.0, A2 = 0.0, A3 = 0.0;
             ni_forget_lds();
-            if constexpr (NL > 0) ni_force_cart<NL, NE, NZ, ZP, EM>(kc, cw, q.ct, r2sum, A1, A2, A3);
+            if constexpr (NL > 0) ni_force_cart<NL, NE, NZ, ZP, EM>(p, cw, q.ct, r2sum, A1, A2, A3);
             else
                 ni_visit_functions<NT, true>(tab, p.ntsf, q.ct, r2sum, [&](int pos, double val, double dval) {
                     const double cc = cw[pos];
@@ -1218,14 +1226,20 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
                     A1 = fma(cc, dval, A1);
                 });
             ni_forget_lds();
-            A1 *= q.tfc * kc.K[NI_KM + 3];
+            A1 *= q.tfc * (1.0 / ANNP_CFLENGTH);
             A2 *= q.tfc;
             const double rx = p.compat ? q.rkm : q.rgm;       // ni:737-738 vs lal_annp.cu:409-414
+#if NI_KEEP_RECORDS
+            const double fcj = q.fcj, fck = q.fck, dfcj = L.dfc[sa], dfck = L.dfc[sb];
+            const double irj = q.ij, irk = q.ik;
+            const double xj[3] = {q.xj[0], q.xj[1], q.xj[2]}, xk[3] = {q.xk[0], q.xk[1], q.xk[2]};
+#else
             const double fcj = L.fc[sa], fck = L.fc[sb], dfcj = L.dfc[sa], dfck = L.dfc[sb];
-            const double t3j_a = fck * dfcj * q.fcjk, t3_g = fck * fcj * q.dfcjk;
-            const double t3k_a = fcj * dfck * q.fcjk;
             const double irj = L.rinv[sa], irk = L.rinv[sb];
             const double xj[3] = {L.dx[sa], L.dy[sa], L.dz[sa]}, xk[3] = {L.dx[sb], L.dy[sb], L.dz[sb]};
+#endif
+            const double t3j_a = fck * dfcj * q.fcjk, t3_g = fck * fcj * q.dfcjk;
+            const double t3k_a = fcj * dfck * q.fcjk;
             double fj[3], fk[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) {
@@ -1374,8 +1388,13 @@ inline void ni_launch_force_t(const NiArgs &a, NiShape sh, hipStream_t s)
     const size_t lds = ni_lds_block(a.n_cap, true, a.npsf + a.ntsf, GP);
     const int per_block = ANNP_WAVES_PER_BLOCK * NI_GA * NI_RUN;
     const int blocks = (a.inum + per_block - 1) / per_block;
-    if (ni_is_shipped_shape(a, sh)) hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, VIR, GP>), dim3(blocks), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((annp_ni_force<NI_GENERIC, VIR, GP>), dim3(blocks), dim3(256), lds, s, a);
+    if (ni_is_shipped_shape(a, sh)) {
+        if (GP && a.n_cap <= NI_CAP_FIXED) {        // the capacity compiled in (fcc Ni: 18 neighbours inside the cutoff; fewer bytes of LDS than this buy no further workgroup)
+            NiArgs c = a;
+            c.n_cap = NI_CAP_FIXED;
+            hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, VIR, GP, GP ? NI_CAP_FIXED : 0>), dim3(blocks), dim3(256), ni_lds_block(NI_CAP_FIXED, true, a.npsf + a.ntsf, GP), s, c);
+        } else hipLaunchKernelGGL((annp_ni_force<NI_SHIPPED, VIR, GP>), dim3(blocks), dim3(256), lds, s, a);
+    } else hipLaunchKernelGGL((annp_ni_force<NI_GENERIC, VIR, GP>), dim3(blocks), dim3(256), lds, s, a);
 }
 
 // the fix-up launches: a fixed small grid whose waves walk the queue (empty in the steady state: they exit at once)
@@ -1420,6 +1439,8 @@ inline hipError_t ni_set_lds_attributes()
     NI_ATTR(annp_ni_desc<NI_GENERIC, true>);
     NI_ATTR(annp_ni_force<NI_SHIPPED, true, true>);
     NI_ATTR(annp_ni_force<NI_SHIPPED, false, true>);
+    NI_ATTR(annp_ni_force<NI_SHIPPED, true, true, NI_CAP_FIXED>);
+    NI_ATTR(annp_ni_force<NI_SHIPPED, false, true, NI_CAP_FIXED>);
     NI_ATTR(annp_ni_force<NI_GENERIC, true, true>);
     NI_ATTR(annp_ni_force<NI_GENERIC, false, true>);
     NI_ATTR(annp_ni_force<NI_SHIPPED, true, false>);
