@@ -444,9 +444,8 @@ __device__ __forceinline__ NiHead ni_stage_head(const NiArgs &p, int ii0, int la
 }
 
 template <bool FORCE>
-__device__ __forceinline__ int ni_stage(const NiArgs &p, const NiHead &head, const NiLds &L, int lane, int &nl)
+__device__ __forceinline__ int ni_stage(const NiArgs &p, const NiHead &head, const NiLds &L, int cap, int lane, int &nl)
 {
-    const int cap = p.n_cap;
     const int hi = head.hi, hjn = head.hjn;
     const long long hbase = head.hbase;
     const double hx = head.hx, hy = head.hy, hz = head.hz;
@@ -595,6 +594,13 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, const NiHead &head, con
         const bool in0 = m0 < p.rc_ang, in1 = m1 < p.rc_ang;
         if (t0) { L.r[s0] = r0; L.rinv[s0] = i0; L.fc[s0] = in0 ? 0.5 * (cs0 + 1.0) : 0.0; L.dfc[s0] = in0 ? (sn0 * -0.5) * pi_over_rc : 0.0; }
         if (t1) { L.r[s1] = r1; L.rinv[s1] = i1; L.fc[s1] = in1 ? 0.5 * (cs1 + 1.0) : 0.0; L.dfc[s1] = in1 ? (sn1 * -0.5) * pi_over_rc : 0.0; }
+        // a neighbour outside the angular cutoff (a radial-only one, or one the coarse filter let through by a hair) is moved 10 000 A
+        // away for the pre-pass, which then needs no test of r_ij, r_ik: any pair with it fails the test of r_jk (two of them may pass it:
+        // ni_pair's exact test, on L.r, rejects the pair).  Nothing else reads dx of such a record.
+        if (!FORCE) {
+            if (t0 && !in0) L.dx[s0] = 1e4;
+            if (t1 && !in1) L.dx[s1] = 1e4;
+        }
         if (FORCE) {
             if (t0) { L.a0[s0] = 0.0; L.a1[s0] = 0.0; L.a2[s0] = 0.0; }
             if (t1) { L.a0[s1] = 0.0; L.a1[s1] = 0.0; L.a2[s1] = 0.0; }
@@ -886,6 +892,9 @@ __device__ __forceinline__ void ni_forget_lds() { asm volatile("" ::: "memory");
 // a dense list; the expensive part (cutoff function of r_jk, exponential, 24 functions) then runs over ceil(60/16)
 // = 4 trips instead of 10.  The visit applies the exact test again (ni_pair's `ok`).
 // Returns this lane's atom's count for the chunk (same value in the 16 lanes of a group).
+// RTEST: the records may hold neighbours outside the angular cutoff at their true place (the force pass's own records; the
+// descriptor pass's ni_stage moves them away instead)
+template <bool RTEST>
 __device__ __forceinline__ int ni_prepass(const NiLds &L, const NiArgs &p, NiWalk &walk, int g, int l, int sbase, int cap,
                                           int npl, int t0, int t1, const int plist)
 {
@@ -905,14 +914,14 @@ __device__ __forceinline__ int ni_prepass(const NiLds &L, const NiArgs &p, NiWal
             ni_walk_next(walk, a[u], b[u]);
             live[u] = (t + u < t1) && pp < npl;
             sa[u] = live[u] ? sbase + a[u] : NI_GA * cap; sb[u] = live[u] ? sbase + b[u] : NI_GA * cap + 1;
-            ax[u] = L.dx[sa[u]]; ay[u] = L.dy[sa[u]]; az[u] = L.dz[sa[u]]; ar[u] = L.r[sa[u]];
-            bx[u] = L.dx[sb[u]]; by[u] = L.dy[sb[u]]; bz[u] = L.dz[sb[u]]; br[u] = L.r[sb[u]];
+            ax[u] = L.dx[sa[u]]; ay[u] = L.dy[sa[u]]; az[u] = L.dz[sa[u]]; ar[u] = RTEST ? L.r[sa[u]] : 0.0;
+            bx[u] = L.dx[sb[u]]; by[u] = L.dy[sb[u]]; bz[u] = L.dz[sb[u]]; br[u] = RTEST ? L.r[sb[u]] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const double g0 = bx[u] - ax[u], g1 = by[u] - ay[u], g2 = bz[u] - az[u];
             const double gsq = g0 * g0 + g1 * g1 + g2 * g2;
-            const bool ok = live[u] & (ar[u] * cfl < rc) & (br[u] * cfl < rc) & (gsq < rc2a);
+            const bool ok = live[u] & (!RTEST || ((ar[u] * cfl < rc) & (br[u] * cfl < rc))) & (gsq < rc2a);
             const unsigned long long m = __ballot(ok);
             const unsigned m16 = (unsigned)(m >> (NI_GL * g)) & 0xffffu;
             if (ok) L.pl[g * plist + cnt + __popc(m16 & ((1u << l) - 1u))] = (unsigned short)(a[u] | (b[u] << 8));
@@ -935,7 +944,8 @@ __device__ __forceinline__ int ni_prepass(const NiLds &L, const NiArgs &p, NiWal
 // ---------------------------------------------------------------------------------
 // FIX: the fix-up instantiation (its waves walk the queue: a loop around the body, bounded to 2 waves per SIMD so that what the
 // loop keeps live does not spill; it runs on the few groups that outgrew their records, if any)
-template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM, bool FIX>
+// CAP > 0: the record capacity is compiled in (p.n_cap equals it), as in the force pass: record arrays at constant offsets
+template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM, bool FIX, int CAP = 0>
 // (the table-driven instantiation keeps NI_MAXP + NI_MAXT = 40 accumulators per lane: 128 VGPRs would spill 39 of them)
 __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) void annp_ni_desc(NiArgs p)
 {
@@ -947,7 +957,7 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
     const int lane0 = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
     const int nsf = p.npsf + p.ntsf;
-    const int cap = p.n_cap;
+    const int cap = CAP > 0 ? CAP : p.n_cap;
     // main launch: the group's headers are asked for first, the tables below are built while they fly
     NiHead head;
     if (!FIX) head = ni_stage_head(p, uniform((xcd_block() * ANNP_WAVES_PER_BLOCK + wave) * NI_GA), lane0);
@@ -979,7 +989,7 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
     int nl;
     NI_DSTAMP(1);
     if (FIX) head = ni_stage_head(p, ii0, lane);
-    const int nmax = ni_stage<false>(p, head, L, lane, nl);
+    const int nmax = ni_stage<false>(p, head, L, cap, lane, nl);
     NI_DSTAMP(2);
     const int ncl = __shfl(nl, NI_GL * (lane & (NI_GA - 1)), 64);     // count of atom (lane & 3), for lanes 0..3
     // a group whose records overflowed is skipped by both passes: its count is left at 0 so that the force pass, which
@@ -1045,7 +1055,7 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
     constexpr int CH = ni_ch(false), PLIST = ni_plist(false);
     int poff = 0;               // pairs of this lane's atom written to p.pairs so far
     for (int t0 = 0; t0 < trips; t0 += CH) {
-        const int cnt = ni_prepass(L, p, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST);
+        const int cnt = ni_prepass<false>(L, p, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST);
         wave_lds_sync();
         NI_DSTAMP(4);
         const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
@@ -1199,7 +1209,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     for (int t0 = 0; t0 < (GPAIRS ? 1 : trips); t0 += CH) {
     int cnt;
     if (GPAIRS) cnt = npg;          // one "chunk": the whole list
-    else { cnt = ni_prepass(L, p, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST); wave_lds_sync(); }
+    else { cnt = ni_prepass<true>(L, p, walk, g, l, sbase, cap, npl, t0, min(trips, t0 + CH), PLIST); wave_lds_sync(); }
     const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
                          max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
     for (int t2 = 0; t2 * NI_GL < cmax; t2++) {
@@ -1376,7 +1386,8 @@ inline int ni_launch_desc(const NiArgs &a, NiShape sh, hipStream_t s)
     if (a.npsf > NI_MAXP || a.ntsf > NI_MAXT) return -1;
     const int blocks = ni_blocks(a.inum);
     if (ni_is_shipped_shape(a, sh))
-        hipLaunchKernelGGL((annp_ni_desc<NI_SHIPPED, false>), dim3(blocks), dim3(256), lds, s, a);
+        if (a.n_cap == NI_CAP_FIXED) hipLaunchKernelGGL((annp_ni_desc<NI_SHIPPED, false, NI_CAP_FIXED>), dim3(blocks), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((annp_ni_desc<NI_SHIPPED, false>), dim3(blocks), dim3(256), lds, s, a);
     else
         hipLaunchKernelGGL((annp_ni_desc<NI_GENERIC, false>), dim3(blocks), dim3(256), lds, s, a);
     return 0;
@@ -1434,6 +1445,7 @@ inline hipError_t ni_set_lds_attributes()
     hipError_t e;
 #define NI_ATTR(...) if ((e = hipFuncSetAttribute((const void *)__VA_ARGS__, hipFuncAttributeMaxDynamicSharedMemorySize, full)) != hipSuccess) return e
     NI_ATTR(annp_ni_desc<NI_SHIPPED, false>);
+    NI_ATTR(annp_ni_desc<NI_SHIPPED, false, NI_CAP_FIXED>);
     NI_ATTR(annp_ni_desc<NI_GENERIC, false>);
     NI_ATTR(annp_ni_desc<NI_SHIPPED, true>);
     NI_ATTR(annp_ni_desc<NI_GENERIC, true>);
