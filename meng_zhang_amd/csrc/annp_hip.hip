@@ -1096,6 +1096,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     h->nsf = p->nsf; h->npsf = p->npsf; h->ntsf = p->ntsf; h->nl = nl; h->ni_compat = p->ni_compat;
     h->e_scale = p->e_scale; h->e_shift = p->e_shift; h->e_atom = p->e_atom; h->cut = p->cut;
     if (const char *e = std::getenv("ANNP_HIP_FULL_LIST")) h->full_list = std::atoi(e) != 0;
+    if (const char *e = std::getenv("ANNP_HIP_NEIGH_SYNC")) h->nb.lazy = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_NI_PAIRS")) h->ni_no_pairs = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_NI_FIXUP")) h->ni_no_fixup = std::atoi(e) == 0;
     if (const char *e = std::getenv("ANNP_HIP_FE_DESC")) h->fe_desc_pairs = std::strcmp(e, "pairs") == 0;
@@ -1420,6 +1421,10 @@ int annp_hip_sync(annp_hip_handle *h)
     if (!h) return ANNP_HIP_EARG;
     DEVICE_GUARD(h);
     HIP_TRY(h, hipDeviceSynchronize());
+    {   // a list build whose row maximum nobody has looked at yet (neigh_kernels.hpp: lazy builds)
+        std::string msg;
+        if (int rc = neigh_settle(h->nb, msg)) return fail(h, rc, "%s", msg.c_str());
+    }
     return poll_flags(h, true);
 }
 

@@ -26,6 +26,20 @@ struct NeighBuild {
     bool pitched = false;           // layout of the current list: rows `pitch_used` apart (else exact CSR)
     int pitch_used = 0;
     double mean_exact = 0.0;        // list entries per atom found by the last exact (two-pass) build
+    // Steady state without a host round trip (round 5): the bins of the last build that looked at the bounding box are reused
+    // (bin_of clamps: an atom beyond them lands in the outermost bin, whose 27-bin search still covers its neighbours) and the
+    // pitched build's row maximum is not waited for.  Both come back through pinned words and are looked at by the NEXT build:
+    // a box that outgrew the bins by more than half a bin recomputes them, a row that outgrew the pitch -- its count is clamped on
+    // the device, so nothing is indexed beyond a row -- is an error then (and the next build is an exact one).
+    bool lazy = true;               // ANNP_HIP_NEIGH_SYNC=1 turns it off
+    bool have_geom = false;
+    double geom_lo[3] = {0, 0, 0}, geom_cut = 0.0;
+    int geom_nb[3] = {0, 0, 0};
+    double *h_bbox = nullptr;       // pinned: lo[3], hi[3] of the last build
+    long long *h_max = nullptr;     // pinned: row maximum of the last pitched build
+    hipEvent_t ev_lazy = nullptr;   // both have arrived
+    bool pending = false;           // a lazy build's words have not been looked at yet
+    int pending_pitch = 0;
     // scratch
     int *binof = nullptr, *bincount = nullptr, *binstart = nullptr, *binfill = nullptr, *binitems = nullptr;
     long long *blocksum = nullptr;
@@ -42,7 +56,12 @@ inline void neigh_release(NeighBuild &nb)
 {
     void *ptrs[] = {nb.numneigh, nb.first, nb.neigh, nb.binof, nb.bincount, nb.binstart, nb.binfill, nb.binitems, nb.blocksum, nb.bbox, nb.dmax, nb.xs};
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (nb.h_bbox) (void)hipHostFree(nb.h_bbox);
+    if (nb.h_max) (void)hipHostFree(nb.h_max);
+    if (nb.ev_lazy) (void)hipEventDestroy(nb.ev_lazy);
+    const bool lazy = nb.lazy;
     nb = NeighBuild();
+    nb.lazy = lazy;
 }
 
 // max over an int array: one atomic per block (per-wave atomics on the one result word serialise: 4096 of them cost 40 us)
@@ -90,6 +109,13 @@ __global__ __launch_bounds__(64) void annp_bbox_final(const double *part, int np
         for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_xor(lo, off, 64)); hi = fmax(hi, __shfl_xor(hi, off, 64)); }
         if (lane == 0) { bbox[d] = lo; bbox[3 + d] = hi; }
     }
+}
+
+// a row count that outgrew the pitch is cut back to it (the entries beyond were not written: annp_neigh_tile<true>)
+__global__ void annp_clamp_int(int *v, int n, int hi)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && v[k] > hi) v[k] = hi;
 }
 
 struct BinGeom { double lo[3]; double inv; int nb[3]; };
@@ -338,6 +364,25 @@ inline int nb_alloc(T *&p, size_t &cap, size_t n, size_t &bytes, std::string &ms
     return 0;
 }
 
+// Look at what a lazy build left in its pinned words (no-op otherwise).  -7: a row had outgrown the pitch.
+inline int neigh_settle(NeighBuild &nb, std::string &msg)
+{
+    if (!nb.pending) return 0;
+    if (hipEventSynchronize(nb.ev_lazy) != hipSuccess) { msg = "neighbour build: hipEventSynchronize failed"; return -4; }     // (recorded a rebuild interval ago: no wait in practice)
+    nb.pending = false;
+    const int mx = (int)(nb.h_max[0] & 0xffffffffll);
+    nb.max_numneigh = std::min(mx, nb.pending_pitch);
+    nb.pitch = (mx + mx / 16 + 4 + 7) / 8 * 8;
+    if (mx > nb.pending_pitch) {
+        nb.pitch = 0;           // the next build is an exact one
+        nb.have_geom = false;
+        msg = "neighbour build: a list row grew from at most " + std::to_string(nb.pending_pitch) + " to " + std::to_string(mx) +
+              " entries between two rebuilds; the evaluations since the last rebuild missed the entries beyond the pitch (ANNP_HIP_NEIGH_SYNC=1 checks every build before it is used)";
+        return -7;
+    }
+    return 0;
+}
+
 inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, double cutneigh, hipStream_t s, std::string &msg)
 {
 #define NB_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { msg = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? -3 : -4; } } while (0)
@@ -350,18 +395,38 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     if (nb_alloc(nb.binof, nb.cap_binof, (size_t)nall, nb.bytes, msg)) return -3;
     if (nb_alloc(nb.binitems, nb.cap_binitems, (size_t)nall, nb.bytes, msg)) return -3;
     const int bparts = std::max(1, std::min(ANNP_BBOX_BLOCKS, (nall + 255) / 256));
+    if (!nb.h_bbox) {
+        NB_TRY(hipHostMalloc((void **)&nb.h_bbox, 6 * sizeof(double)));
+        NB_TRY(hipHostMalloc((void **)&nb.h_max, sizeof(long long)));
+        NB_TRY(hipEventCreateWithFlags(&nb.ev_lazy, hipEventDisableTiming));
+    }
+    // what the last lazy build left behind: its row maximum and its bounding box
+    bool reuse_geom = false;
+    if (int rc_ = neigh_settle(nb, msg)) return rc_;
+    if (nb.lazy && nb.have_geom && nb.geom_cut == cutneigh && nb.pitch > 0) {
+        reuse_geom = true;
+        for (int d = 0; d < 3; d++) {       // the box as of the last build: still within half a bin of the bins?
+            const double lo = nb.geom_lo[d], hi = lo + nb.geom_nb[d] * cutneigh;
+            if (nb.h_bbox[d] < lo - 0.5 * cutneigh || nb.h_bbox[3 + d] > hi + 0.5 * cutneigh || nb.h_bbox[3 + d] < hi - 1.5 * cutneigh) reuse_geom = false;
+        }
+    }
     hipLaunchKernelGGL(annp_bbox_partial, dim3(bparts), dim3(256), 0, s, d_x, nall, nb.bbox + 6);
     hipLaunchKernelGGL(annp_bbox_final, dim3(1), dim3(64), 0, s, nb.bbox + 6, bparts, nb.bbox);
-    double hb[6];
-    NB_TRY(hipMemcpyAsync(hb, nb.bbox, sizeof(hb), hipMemcpyDeviceToHost, s));
-    NB_TRY(hipStreamSynchronize(s));
+    NB_TRY(hipMemcpyAsync(nb.h_bbox, nb.bbox, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
     BinGeom g;
     long long nbins = 1;
-    for (int d = 0; d < 3; d++) {
-        g.lo[d] = hb[d];
-        g.nb[d] = (int)std::floor((hb[3 + d] - hb[d]) / cutneigh) + 1;
-        if (g.nb[d] < 1) g.nb[d] = 1;
-        nbins *= g.nb[d];
+    if (reuse_geom) {
+        for (int d = 0; d < 3; d++) { g.lo[d] = nb.geom_lo[d]; g.nb[d] = nb.geom_nb[d]; nbins *= g.nb[d]; }
+    } else {
+        NB_TRY(hipStreamSynchronize(s));
+        for (int d = 0; d < 3; d++) {
+            g.lo[d] = nb.h_bbox[d];
+            g.nb[d] = (int)std::floor((nb.h_bbox[3 + d] - nb.h_bbox[d]) / cutneigh) + 1;
+            if (g.nb[d] < 1) g.nb[d] = 1;
+            nbins *= g.nb[d];
+            nb.geom_lo[d] = g.lo[d]; nb.geom_nb[d] = g.nb[d];
+        }
+        nb.geom_cut = cutneigh; nb.have_geom = true;
     }
     g.inv = 1.0 / cutneigh;
     if (nbins > (1ll << 27)) { msg = "neighbour build: too many bins"; return -1; }
@@ -414,10 +479,18 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
         hipLaunchKernelGGL((annp_neigh_tile<true>), dim3((unsigned)nbins), dim3(256), tlds, s, d_x, nb.xs, nlocal, g, rc2, nb.binstart, nb.binitems,
                            nb.numneigh, (const long long *)nb.first, nb.neigh, nb.pitch);
         hipLaunchKernelGGL(annp_max_int, dim3(annp_max_int_blocks(nlocal)), dim3(256), 0, s, nb.numneigh, nlocal, nb.dmax);
-        long long h1[1];
-        NB_TRY(hipMemcpyAsync(h1, nb.dmax, sizeof(h1), hipMemcpyDeviceToHost, s));
+        NB_TRY(hipMemcpyAsync(nb.h_max, nb.dmax, sizeof(long long), hipMemcpyDeviceToHost, s));
+        if (reuse_geom) {       // steady state: nobody waits; the row maximum is looked at by the next build
+            hipLaunchKernelGGL(annp_clamp_int, dim3((nlocal + 255) / 256), dim3(256), 0, s, nb.numneigh, nlocal, nb.pitch);
+            NB_TRY(hipEventRecord(nb.ev_lazy, s));
+            NB_TRY(hipGetLastError());
+            nb.pending = true; nb.pending_pitch = nb.pitch;
+            nb.max_numneigh = nb.pitch;         // an upper bound, as far as the caller is concerned
+            nb.nlocal = nlocal; nb.nall = nall; nb.valid = true; nb.pitched = true; nb.pitch_used = nb.pitch;
+            return 0;
+        }
         NB_TRY(hipStreamSynchronize(s));
-        nb.max_numneigh = (int)(h1[0] & 0xffffffffll);
+        nb.max_numneigh = (int)(nb.h_max[0] & 0xffffffffll);
         const bool fits = nb.max_numneigh <= nb.pitch;
         const int used = nb.pitch;
         learn_pitch();
