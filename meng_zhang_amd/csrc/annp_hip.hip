@@ -1489,7 +1489,7 @@ int annp_hip_neigh_build_device(annp_hip_handle *h, int nlocal, int nall, const 
     DEVICE_GUARD(h);
     std::string msg;
     size_t before = h->nb.bytes;
-    int rc = neigh_build(h->nb, nlocal, nall, d_x, list_cutoff(h, cutneigh), (hipStream_t)stream, msg);
+    int rc = neigh_build(h->nb, nlocal, nall, d_x, list_cutoff(h, cutneigh), (hipStream_t)stream, msg, true);
     h->bytes += h->nb.bytes - before;
     if (rc) return fail(h, rc, "%s", msg.c_str());
     if (d_numneigh) *d_numneigh = h->nb.numneigh;

@@ -383,7 +383,9 @@ inline int neigh_settle(NeighBuild &nb, std::string &msg)
     return 0;
 }
 
-inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, double cutneigh, hipStream_t s, std::string &msg)
+// allow_lazy: the caller is a device-resident stepping loop (annp_hip_neigh_build_device); the host-pointer entries, which wait for their
+// results anyway and are handed any configuration at any time, check every build before it is used
+inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, double cutneigh, hipStream_t s, std::string &msg, bool allow_lazy = false)
 {
 #define NB_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { msg = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? -3 : -4; } } while (0)
     nb.valid = false;
@@ -403,7 +405,7 @@ inline int neigh_build(NeighBuild &nb, int nlocal, int nall, const double *d_x, 
     // what the last lazy build left behind: its row maximum and its bounding box
     bool reuse_geom = false;
     if (int rc_ = neigh_settle(nb, msg)) return rc_;
-    if (nb.lazy && nb.have_geom && nb.geom_cut == cutneigh && nb.pitch > 0) {
+    if (allow_lazy && nb.lazy && nb.have_geom && nb.geom_cut == cutneigh && nb.pitch > 0) {
         reuse_geom = true;
         for (int d = 0; d < 3; d++) {       // the box as of the last build: still within half a bin of the bins?
             const double lo = nb.geom_lo[d], hi = lo + nb.geom_nb[d] * cutneigh;
