@@ -634,6 +634,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         FeArgs a{};
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
         a.cutsq = h->cutsq; a.rc_list = std::sqrt(h->cutsq); a.rc_par = h->cut;
+        a.por_list = ANNP_MY_PI / a.rc_list; a.two_over_rcp = 2.0 / a.rc_par;
         a.type = types; a.active = h->active;
         a.G = h->G.p; a.coef = h->coef.p; a.f = d_f; a.virial = vtab; a.vatom = d_vatom; a.ncount = h->ncount.p;
         a.errflag = h->d_flags;
@@ -731,6 +732,7 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
         FeArgs a{};
         a.inum = inum; a.ilist = d_ilist; a.x = d_x; a.numneigh = d_numneigh; a.first = d_first; a.neigh = d_neigh;
         a.cutsq = h->cutsq; a.rc_list = h->cut; a.rc_par = h->cut;          // fc and the radial argument both use the file's cutoff (adp:105,130,588)
+        a.por_list = ANNP_MY_PI / a.rc_list; a.two_over_rcp = 2.0 / a.rc_par;
         a.G = h->G.p; a.ncount = h->ncount.p; a.errflag = h->d_flags;
         a.nmax_word = h->fw + 1;           // (annp_fe_desc_sh raises it itself; the pair-loop descriptor kernel does not)
         const bool desc_sh = !h->fe_desc_pairs && !h->fe_dense;

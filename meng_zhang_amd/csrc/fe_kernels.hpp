@@ -47,6 +47,8 @@ struct FeArgs {
     double cutsq;              // LAMMPS cutsq (cutmax^2)
     double rc_list;            // sqrt(cutsq), used in fc       (fe:150)
     double rc_par;             // params.cut, used in x = 2r/Rc-1 (fe:637,643)
+    double por_list, two_over_rcp;   // pi / rc_list and 2 / rc_par, divided on the host: a wave-uniform double division is two dozen vector instructions
+                               // per wave (a per cent of annp_fe_force_sh, whose four waves per group each paid it) and two register pairs for the whole kernel
     double *G;                 // [inum][ANNP_GPAD] raw sums (pass 1 out)
     const double *coef;        // [inum][ANNP_CPAD] (pass 2 in)
     double *f;                 // [nall][3] accumulated
@@ -190,8 +192,8 @@ __device__ __forceinline__ void fe_desc_atom(const FeArgs &p, const int ii, cons
     const int NZ = p.n_cap + fe_lcap(p.n_cap);                    // first null record
 
     const int i = p.ilist ? p.ilist[ii] : ii;
-    const double pi_over_rc = ANNP_MY_PI / p.rc_list;
-    const double two_over_rcp = 2.0 / p.rc_par;
+    const double pi_over_rc = p.por_list;
+    const double two_over_rcp = p.two_over_rcp;
 
     if (p.type && !type_mapped(p.active, p.type[i])) {      // centre of an unmapped type: no neighbours, no energy
         if (p.ncount && lane == 0) p.ncount[ii] = 0;
@@ -400,8 +402,8 @@ __device__ __forceinline__ void fe_force_atom(const FeArgs &p, const int ii, con
     double reg_rinv[2] = {0.0, 0.0}, reg_dfc[2] = {0.0, 0.0}, reg_rr[2] = {0.0, 0.0};   // AUXREG: rows lane, lane+64
 
     const int i = p.ilist ? p.ilist[ii] : ii;
-    const double pi_over_rc = ANNP_MY_PI / p.rc_list;
-    const double two_over_rcp = 2.0 / p.rc_par;
+    const double pi_over_rc = p.por_list;
+    const double two_over_rcp = p.two_over_rcp;
     const double *cf = p.coef + (size_t)ii * ANNP_CPAD;
 
     if (p.type && !type_mapped(p.active, p.type[i])) return;

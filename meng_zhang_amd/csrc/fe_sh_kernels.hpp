@@ -394,8 +394,8 @@ __global__ __launch_bounds__(256, 3) void annp_fe_desc_sh(FeArgs p)
     double2 *stA = reinterpret_cast<double2 *>(SZ + SH_GA * PL);  // behind the arrays: the staging rows of the register-resident entries, raw (dx,dy)[48], (dz,r^2)[48]
     double2 *stB = stA + SH_GL * SH_R;
     const int g = (lane >> 2) & 3, l = ((lane >> 4) << 2) | (lane & 3);      // atoms interleaved quad by quad (sh_row_reduce)
-    const double pi_over_rc = ANNP_MY_PI / p.rc_list;
-    const double two_over_rcp = 2.0 / p.rc_par;
+    const double pi_over_rc = p.por_list;
+    const double two_over_rcp = p.two_over_rcp;
 
     // ---- stage A: the four rows, raw (dx,dy | dz,r^2): in-cutoff entries 0..47 of a row through the staging rows into the
     //      registers of the atom's lanes, the others into the atom's LDS slots.  Lane ga < 4 fetches the header of atom ga.

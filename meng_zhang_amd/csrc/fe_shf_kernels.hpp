@@ -576,8 +576,8 @@ __global__ __launch_bounds__(64 * SHF_WAVES, ANNP_SHF_WPS) void annp_fe_force_sh
     // coefficient: they must be numbers)
     if (threadIdx.x < SHF_ZPAD / 8) reinterpret_cast<double *>(lds_raw + shf_lds_table() - SHF_ZPAD)[threadIdx.x] = 0.0;
     if (wq == 0 && lane < 4) reinterpret_cast<double *>(gbase + (size_t)SHF_GA * SHF_TBYTES)[lane] = 0.0;
-    const double pi_over_rc = ANNP_MY_PI / p.rc_list;
-    const double two_over_rcp = 2.0 / p.rc_par;
+    const double pi_over_rc = p.por_list;
+    const double two_over_rcp = p.two_over_rcp;
 
     // ---- this lane's atom.  Everything whose address follows from the list entry alone is requested at once: the count, the
     //      lane's two candidate neighbours, its moments of the wave's columns, and from the coefficient row the W_l of its table
