@@ -53,7 +53,11 @@ __host__ __device__ constexpr int ni_plist(bool force) { return ni_ch(force) * 1
 #define NI_RUN_GROUPS 4
 #endif
 constexpr int NI_RUN = NI_RUN_GROUPS;
-constexpr int NI_TSLOTS = 128;
+#ifndef NI_TSLOTS_N
+#define NI_TSLOTS_N 128
+#endif
+constexpr int NI_TSLOTS = NI_TSLOTS_N;          // a power of two
+constexpr int NI_TSHIFT = 32 - (NI_TSLOTS == 128 ? 7 : NI_TSLOTS == 64 ? 6 : NI_TSLOTS == 32 ? 5 : NI_TSLOTS == 256 ? 8 : 4);
 constexpr int NI_CAP_FIXED = 20;     // record capacity compiled into the steady-state instantiation of the force pass
 constexpr int NI_XSTAGE = 4096 + 128;   // bytes of the force pass's landing area for positions fetched ahead (ni_preload)
 #ifndef NI_TPROBE_N
@@ -651,7 +655,7 @@ __device__ __forceinline__ void ni_request(const NiArgs &p, int ii0, int row0, i
 // Up to three keys per lane are resolved together (want_k false: no key).
 __device__ __forceinline__ void ni_table_claim3(int *tkey, bool w0, int j0, bool w1, int j1, bool w2, int j2, int &r0, int &r1, int &r2)
 {
-    unsigned a0 = ((unsigned)j0 * 0x9E3779B1u) >> 25, a1 = ((unsigned)j1 * 0x9E3779B1u) >> 25, a2 = ((unsigned)j2 * 0x9E3779B1u) >> 25;
+    unsigned a0 = ((unsigned)j0 * 0x9E3779B1u) >> NI_TSHIFT, a1 = ((unsigned)j1 * 0x9E3779B1u) >> NI_TSHIFT, a2 = ((unsigned)j2 * 0x9E3779B1u) >> NI_TSHIFT;
     r0 = r1 = r2 = -1;
 #pragma unroll 1
     for (int probe = 0; probe < NI_TPROBE; probe++) {
