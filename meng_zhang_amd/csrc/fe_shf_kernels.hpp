@@ -144,7 +144,8 @@ struct ShfTable {
                 if (b >= 0 && v != 0.0) atomicAdd(&f[(size_t)b * (SHF_BATOMS * 3) + r], v);
             }
         }
-        if (tid == 64 * SHF_WAVES - 1 && spills && key[SHF_NBUCK]) atomicAdd(spills, key[SHF_NBUCK]);
+        // (the count saturates near 2^30: it feeds a notice, and an int that wrapped would silence it -- ADVICE r4)
+        if (tid == 64 * SHF_WAVES - 1 && spills && key[SHF_NBUCK] && __hip_atomic_load(spills, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (1 << 30)) atomicAdd(spills, key[SHF_NBUCK]);
     }
 };
 
