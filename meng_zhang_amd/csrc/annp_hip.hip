@@ -394,14 +394,15 @@ void digest_flags(annp_hip_handle *h)
         // random order lose ~100 per atom and the pass takes 2.3 times as long.  The caller is told from 40 per atom on -- a third
         // of a bcc-Fe neighbourhood: sorting its atoms in space then buys up to that factor.
         if (h->flags_sh) {
-            h->shf_scattered = h->h_flags[4] > 40 * (long long)h->flags_inum;
+            const long long lost = (long long)(unsigned)h->h_flags[4];        // (the device adds to an int: above 2^31 it reads negative)
+            h->shf_scattered = lost > 40 * (long long)h->flags_inum;
             if (h->shf_scattered != h->shf_scattered_said) {
                 h->shf_scattered_said = h->shf_scattered;
                 if (h->notice) {
                     if (h->shf_scattered)
                         std::fprintf(h->notice, "annp/hip: atoms are not ordered in space (%.1f force contributions per atom found no room in the force pass's "
                                      "table of eight-atom buckets): the force pass takes up to 2.3 times as long as with sorted atoms (atom_modify sort)\n",
-                                     (double)h->h_flags[4] / std::max(1, h->flags_inum));
+                                     (double)lost / std::max(1, h->flags_inum));
                     else
                         std::fprintf(h->notice, "annp/hip: atoms are ordered in space again\n");
                     std::fflush(h->notice);
