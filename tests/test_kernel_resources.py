@@ -27,7 +27,7 @@ def test_occupancies_quoted_in_design(kernels):
         assert hits, prefix
         return {(k["vgpr"], k["occupancy"]) for k in hits}
     shipped = "3, 24, 2, 3, 4, 268698113u, 328193u"
-    assert all(w == 4 and v <= 128 for v, w in occ("annp::annp_ni_desc<%s, false>" % shipped))
+    assert all(w == 4 and v <= 128 for v, w in occ("annp::annp_ni_desc<%s, false, " % shipped))      # record capacity compiled in (20) and at run time (0)
     assert all(w == 3 and v <= 168 for v, w in occ("annp::annp_ni_force<%s" % shipped))
     assert all(w >= 4 and v <= 128 for v, w in occ("annp::annp_fe_desc<9, 19>"))
     assert all(w == 3 and v <= 168 for v, w in occ("annp::annp_fe_desc_sh<9, 19>"))      # 13 KB of LDS per wave: 12 waves per CU either way
