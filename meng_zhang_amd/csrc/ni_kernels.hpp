@@ -267,20 +267,17 @@ __device__ __forceinline__ void ni_visit_functions(const NiTab &t, int ntsf, dou
 //   S[...]           copy of the sorted per-function table + etas (generic shape)
 constexpr int NI_TABLE_DOUBLES = 4 * NI_MAXT + NI_MAXE;
 
-struct NiConst { };         // (nothing left: kept as the tag the visit functions take)
-
 // compile-time exponents of the product-shape kernels: byte z of ZP = zeta_z, byte e of EM = eta_e / eta_0
 #define NI_BYTE(packed, k) ((int)(((packed) >> (8 * (k))) & 255u))
 
 template <int NL, int NE, int NZ>
-__device__ __forceinline__ NiConst ni_tables_fill(double *lds, const NiArgs &p, NiTab &t, int lane)
+__device__ __forceinline__ void ni_tables_fill(double *lds, const NiArgs &p, NiTab &t, int lane)
 {
     if constexpr (NL == 0) {
         double *S = lds;
         for (int idx = lane; idx < 4 * p.ntsf + NI_MAXE; idx += 64) S[idx] = t.sorted[idx];
         t.sorted = S; t.etas = S + 4 * p.ntsf;      // the generic visit reads the LDS copy
     }
-    return NiConst{};
 }
 
 // 2^(1-zeta) x, and zeta 2^(1-zeta) x, for an integer zeta that is known once the visit is unrolled (a byte of the template argument ZP):
@@ -967,7 +964,7 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
     if (!FIX) head = ni_stage_head(p, uniform((xcd_block() * ANNP_WAVES_PER_BLOCK + wave) * NI_GA), lane0);
     NiTab tab = ni_tab(p.sym, p.isym, p.npsf, p.ntsf, nullptr);
     const double *srad = tab.rad;
-    const NiConst kc = ni_tables_fill<NL, NE, NZ>(reinterpret_cast<double *>(lds_raw), p, tab, lane0);
+    ni_tables_fill<NL, NE, NZ>(reinterpret_cast<double *>(lds_raw), p, tab, lane0);
     unsigned char *wbase = lds_raw + NI_TABLE_DOUBLES * 8 + (size_t)wave * ni_lds_per_wave(cap, false, nsf);
     const NiLds L = ni_carve<false>(wbase, cap, 0);
     double *scratch = reinterpret_cast<double *>(wbase);
@@ -1153,7 +1150,7 @@ __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(Ni
     const int cstride = ni_coef_stride(nsf);
     NiTab tab = ni_tab(p.sym, p.isym, p.npsf, p.ntsf, nullptr);
     const double *srad = tab.rad;
-    const NiConst kc = ni_tables_fill<NL, NE, NZ>(reinterpret_cast<double *>(lds_raw), p, tab, lane);
+    ni_tables_fill<NL, NE, NZ>(reinterpret_cast<double *>(lds_raw), p, tab, lane);
     unsigned char *wbase = lds_raw + NI_TABLE_DOUBLES * 8 + (size_t)wave * ni_lds_per_wave(cap, true, nsf, GPAIRS);
     const NiLds L = ni_carve<true>(wbase, cap, cstride);
     for (int sl = lane; sl < NI_TSLOTS; sl += 64) { L.tkey[sl] = -1; L.tacc[3 * sl] = 0.0; L.tacc[3 * sl + 1] = 0.0; L.tacc[3 * sl + 2] = 0.0; }
