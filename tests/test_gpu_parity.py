@@ -381,6 +381,26 @@ def test_ni_random_clusters(ni_pot, seed, density, compat):
     assert np.allclose(r["virial"], o["virial"], rtol=1e-8, atol=1e-6 * scale)
 
 
+@pytest.mark.parametrize("natoms", [1, 2, 3, 5, 17, 63, 65])
+def test_ni_tiny_systems(ni_pot, natoms):
+    """fewer atoms than a wave's run of groups (16), than a group (4), than two: the force pass fetches a group ahead of the one it
+    works on (ni_preload) and clamps what it asks for to atoms that exist"""
+    x = _random_cluster(100 + natoms, 0.09, 12.0, 1.9)[:natoms]
+    assert x.shape[0] == natoms
+    s = System(x, np.array([0, 0, 0, 12.0, 12.0, 12.0]), periodic=(0, 0, 0), rc_list=6.5)
+    o = oracle_compute(ni_pot, s, KIND_NI_FIXED, FAST, want_virial=True)
+    p = make_pair(NI_POT, "Ni")
+    try:
+        for _ in range(2):          # the second evaluation runs with the capacity the first one learned
+            r = run(p, s, vflag=1)
+    finally:
+        p.close()
+    scale = max(1.0, np.abs(o["f"]).max())
+    assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6 * max(1.0, np.abs(o["eatom"]).max())
+    assert np.abs(r["f"] - o["f"]).max() < 1e-8 * scale
+    assert np.allclose(r["virial"], o["virial"], rtol=1e-8, atol=1e-6 * scale)
+
+
 def test_special_bits_in_neighbour_indices_are_masked(fe_pair, fe_pot):
     """LAMMPS stores special-bond flags in the top bits of a neighbour index; the pair style masks
     them with NEIGHMASK (fe_v2/src/pair_annp.cpp:136)."""
