@@ -1,6 +1,7 @@
 #!/bin/bash
 # Developer tool (GPU box): kernel timings of the Behler (Ni) passes, the default library first, then every library given
-# (developer builds of the same code, e.g. the timing builds -DNI_TIMING=n of ni_kernels.hpp -- their results are wrong on purpose).
+# (developer builds of the same code: -DNI_TSLOTS_N=64, -DNI_RUN_GROUPS=8, -DNI_KEEP_RECORDS=0 ...; the parity tests run on the default library only:
+# NI_SKIP_PARITY=1 skips them).
 #   bash tools/ni_session.sh <name> [library ...]
 set -o pipefail
 out=gpurun_out/$1; shift
