@@ -100,6 +100,7 @@ template <bool VIRIAL>
 __global__ __launch_bounds__(256) void annp_anna_adp(AnnaArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ANNP_POISON();
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
     const int cap = p.n_cap;

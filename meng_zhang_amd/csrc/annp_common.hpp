@@ -28,6 +28,30 @@ __device__ __forceinline__ void wave_lds_sync()
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Developer builds (`make poison`, never the shipped library): the first act of every kernel that uses LDS is to fill its
+// workgroup's whole allocation with a pattern, so that a read of LDS the workgroup never wrote meets the worst value instead
+// of whatever the previous dispatch on that CU left there.  LDS is not cleared between dispatches: a kernel whose result
+// depends on it passes or fails by the history of its CU (VERDICT r5 "What's weak" 1).  Two patterns, two libraries:
+//   ANNP_POISON_LDS=1  -1e300: survives fmin / fmax clamps, and its square is +Inf (the exp(-eta r^2) x 0 of round 5's Behler G2 loop);
+//   ANNP_POISON_LDS=2  all bits set: a quiet NaN as a double (and -1 as an int, which is what a force table's free keys look
+//                      like to the next kernel) -- catches every `x * 0` mask, whatever stands in front of it.
+// The size comes from the dispatch packet (hsa_kernel_dispatch_packet_t::group_segment_size, byte 24: static + dynamic LDS).
+#ifdef ANNP_POISON_LDS
+__device__ __forceinline__ void annp_poison_lds()
+{
+    typedef const __attribute__((address_space(4))) unsigned *packet_p;
+    const unsigned bytes = ((packet_p)__builtin_amdgcn_dispatch_ptr())[6];
+    typedef __attribute__((address_space(3))) double *lds_dp;
+    const unsigned nthreads = blockDim.x * blockDim.y * blockDim.z;
+    for (unsigned o = 8u * threadIdx.x; o + 8u <= bytes && o < 160u * 1024u; o += 8u * nthreads)
+        *(lds_dp)(uintptr_t)o = ANNP_POISON_LDS == 2 ? __builtin_bit_cast(double, ~0ull) : -1e300;
+    __syncthreads();
+}
+#define ANNP_POISON() annp::annp_poison_lds()
+#else
+#define ANNP_POISON() do { } while (0)
+#endif
+
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Give each XCD a
 // contiguous range of atoms instead, so the positions and list rows a spatial neighbourhood shares are
 // served by one L2.  Pure speed: any placement is correct.  Bijective for every grid size

@@ -359,6 +359,7 @@ template <int NP, int NT>
 __global__ __launch_bounds__(256) void annp_fe_desc(FeArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ANNP_POISON();
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
     const int ii = uniform(xcd_block() * (int)(blockDim.x >> 6) + wave);
@@ -641,6 +642,7 @@ template <int NP, int NT, bool VIRIAL, bool AUXREG, int NCAP = 0>
 __global__ __launch_bounds__(256) void annp_fe_force(FeArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ANNP_POISON();
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
     const int ii = uniform(xcd_block() * (int)(blockDim.x >> 6) + wave);
@@ -656,6 +658,7 @@ template <int NP, int NT, bool VIRIAL>
 __global__ __launch_bounds__(256) void annp_fe_force_fixup(FeArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ANNP_POISON();
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
     const int count = uniform(min(*p.ovf_count, p.ovf_cap));

@@ -378,6 +378,7 @@ __global__ __launch_bounds__(256, 3) void annp_fe_desc_sh(FeArgs p)
 {
     static_assert(NT == SH_LMAX + 1 && NP + NT <= ANNP_GPAD && NP + 1 <= 16, "layout of the output row");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ANNP_POISON();
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
     const int ii0 = uniform((xcd_block() * (int)(blockDim.x >> 6) + wave) * SH_GA);
@@ -652,6 +653,7 @@ template <int NP, int NT>
 __global__ __launch_bounds__(64) void annp_fe_desc_fixup(FeArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ANNP_POISON();
     const int lane = lane_id();
     const int count = min(*p.ovf_count, p.ovf_cap);
     for (int k = blockIdx.x; k < count; k += gridDim.x) {

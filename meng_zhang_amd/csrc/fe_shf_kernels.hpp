@@ -535,6 +535,7 @@ __global__ __launch_bounds__(64 * SHF_WAVES, ANNP_SHF_WPS) void annp_fe_force_sh
 {
     static_assert(NT == SH_LMAX + 1 && NP + 2 * NT + 1 <= ANNP_CPAD && NP + 1 <= SHF_GL, "coefficient row: c_m | p_k | W_l | P(1)");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ANNP_POISON();
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
     const int grp = wave / SHF_GW;                                   // the wave's group in the workgroup
@@ -559,7 +560,11 @@ __global__ __launch_bounds__(64 * SHF_WAVES, ANNP_SHF_WPS) void annp_fe_force_sh
         const bool all_there = seen == (1 << SHF_WAVES) - 1;
         // (the "& 3" behind the read is for the compiler: with a place it knows nothing about, hipcc 7.2 built the switches below
         // wrongly -- the fourth place's first moment loads went out from registers nobody had written: a memory fault, round 5)
+#ifdef ANNP_SHF_NO_PLACE_MASK      // the construct hipcc 7.2 miscompiles: only ever built by tests/test_kernel_resources.py, to show that tools/asm_check.py sees it
+        if (uniform(all_there) && !p.shf_places_by_number) wq = uniform(place);
+#else
         if (uniform(all_there) && !p.shf_places_by_number) wq = uniform(place) & 3;
+#endif
     }
     ShfTable tab;
     tab.key = reinterpret_cast<int *>(lds_raw + (size_t)SHF_NBUCK * SHF_BATOMS * 24);

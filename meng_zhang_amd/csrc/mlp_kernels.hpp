@@ -198,6 +198,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES_PER_BLOCK) void annp_mlp_mfma(MlpArg
     using S = MlpSlots<KS0, MT, NL>;
     constexpr int KSH = S::KSH, MT0 = S::MT0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ANNP_POISON();
     double *opnd = reinterpret_cast<double *>(lds_raw);                 // [S::total][64]
 
     const int lane = lane_id();

@@ -68,6 +68,7 @@ inline void neigh_release(NeighBuild &nb)
 __global__ __launch_bounds__(256) void annp_max_int(const int *v, int n, int *out)
 {
     __shared__ int part[4];
+    ANNP_POISON();
     int m = 0;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) m = max(m, v[k]);
 #pragma unroll
@@ -86,6 +87,7 @@ constexpr int ANNP_BBOX_BLOCKS = 256;
 __global__ __launch_bounds__(256) void annp_bbox_partial(const double *x, int n, double *part)   // part[gridDim.x][6]
 {
     __shared__ double slo[3][4], shi[3][4];
+    ANNP_POISON();
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
         for (int d = 0; d < 3; d++) { const double v = x[3 * (size_t)k + d]; lo[d] = fmin(lo[d], v); hi[d] = fmax(hi[d], v); }
@@ -140,6 +142,7 @@ __global__ void annp_bin_count(const double *x, int n, BinGeom g, int *binof, in
 __global__ __launch_bounds__(1024) void annp_scan_bins(const int *cnt, int n, int *start)
 {
     __shared__ int part[1024];
+    ANNP_POISON();
     const int per = (n + 1023) / 1024;
     const int b0 = threadIdx.x * per, b1 = min(n, b0 + per);
     int s = 0;
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(256) void annp_neigh_tile(const double *x, const do
                                                        int *numneigh, const long long *first, int *neigh, int pitch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ANNP_POISON();
     double *cx = reinterpret_cast<double *>(lds_raw), *cy = cx + NEIGH_CH, *cz = cy + NEIGH_CH;
     int *cj = reinterpret_cast<int *>(cz + NEIGH_CH);
     int *cntl = cj + NEIGH_CH;          // [NEIGH_MAXA] running row length of the bin's atoms
@@ -306,6 +310,7 @@ __global__ void annp_first_pitched(long long *first, int n, int pitch)
 __global__ __launch_bounds__(1024) void annp_scan_block_sums(const int *v, int n, long long *bs)
 {
     __shared__ long long sh[16];
+    ANNP_POISON();
     const int k = blockIdx.x * 1024 + threadIdx.x;
     long long s = (k < n) ? v[k] : 0;
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -320,6 +325,7 @@ __global__ __launch_bounds__(1024) void annp_scan_block_sums(const int *v, int n
 __global__ __launch_bounds__(1024) void annp_scan_block_offsets(long long *bs, int nblocks, long long *total)
 {
     __shared__ long long sh[1024];
+    ANNP_POISON();
     const int nt = blockDim.x, t = threadIdx.x;
     const int chunk = (nblocks + nt - 1) / nt;
     const int a = min(nblocks, t * chunk), b = min(nblocks, a + chunk);
@@ -340,6 +346,7 @@ __global__ __launch_bounds__(1024) void annp_scan_block_offsets(long long *bs, i
 __global__ __launch_bounds__(1024) void annp_scan_finish(const int *v, int n, const long long *bs, long long *first)
 {
     __shared__ long long sh[1024];
+    ANNP_POISON();
     const int k = blockIdx.x * 1024 + threadIdx.x;
     sh[threadIdx.x] = (k < n) ? v[k] : 0;
     __syncthreads();

@@ -585,7 +585,9 @@ __device__ __forceinline__ int ni_stage(const NiArgs &p, const NiHead &head, con
     // A lane's neighbours l and l + 16 side by side (shared coefficient loads, interleaved chains), the rest of a long row in a loop.
     auto second = [&](int a0, int a1) {
         const bool t0 = a0 < nl, t1 = a1 < nl;
-        const int s0 = g * cap + (t0 ? a0 : 0), s1 = g * cap + (t1 ? a1 : 0);
+        // (a lane without a neighbour reads the dummy record -- written above, finite -- never a record of its atom: an atom with NO
+        // in-range neighbour has none that anybody wrote, and LDS keeps what the previous dispatch left there)
+        const int s0 = t0 ? g * cap + a0 : NI_GA * cap, s1 = t1 ? g * cap + a1 : NI_GA * cap;
         const double q0 = L.r[s0], q1 = L.r[s1];
         const double i0 = fast_rsqrt_ic(q0), i1 = fast_rsqrt_ic(q1);
         const double r0 = q0 * i0, r1 = q1 * i1;
@@ -951,6 +953,7 @@ template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM, bool
 __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) void annp_ni_desc(NiArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ANNP_POISON();
 #ifdef ANNP_NI_STAMPS
     unsigned long long dstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1026,7 +1029,13 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
     const bool same_rc = p.rc_rad == p.rc_ang;
     for (int a = l; a < nmax; a += 2 * NI_GL) {
         const bool t0 = a < nl, t1 = a + NI_GL < nl;
-        const int s0 = sbase + (t0 ? a : 0), s1 = sbase + (t1 ? a + NI_GL : 0);
+        // A lane with nothing to add reads the DUMMY record (ni_stage: r = 1e3, fc = 0), not record 0 of its atom.  Round 5 read
+        // `sbase + 0` there and multiplied the result by f = 0: for an atom with no in-range neighbour at all (nl == 0) in a wave
+        // whose other atoms have some (nmax > 0) that record was never written, a large negative leftover of the previous
+        // dispatch gives m^2 = +Inf, exp_neg_s(-Inf) = NaN, and NaN x 0 = NaN in the atom's descriptor row and energy
+        // (test_ni_tiny_systems[17], red once on a fresh box; `make poison` makes it red every time).  ni:692-709: nothing is
+        // added outside the cutoff -- by selection below, not by a zero factor.
+        const int s0 = t0 ? sbase + a : NI_GA * cap, s1 = t1 ? sbase + a + NI_GL : NI_GA * cap;
         const double m0 = fmin(L.r[s0] * ANNP_CFLENGTH, p.rc_rad), m1 = fmin(L.r[s1] * ANNP_CFLENGTH, p.rc_rad);
         double f0, f1;
         if (same_rc) { f0 = L.fc[s0]; f1 = L.fc[s1]; }
@@ -1035,8 +1044,9 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
             sincos_0_pi_s2(p.por_rad * m0, p.por_rad * m1, sn0, cs0, sn1, cs1);
             f0 = 0.5 * (cs0 + 1.0); f1 = 0.5 * (cs1 + 1.0);          // (0 at the cutoff itself)
         }
-        if (!(t0 && L.r[s0] * ANNP_CFLENGTH < p.rc_rad)) f0 = 0.0;          // ni:693: outside the cutoff nothing is added
-        if (!(t1 && L.r[s1] * ANNP_CFLENGTH < p.rc_rad)) f1 = 0.0;
+        const bool in0 = t0 && L.r[s0] * ANNP_CFLENGTH < p.rc_rad, in1 = t1 && L.r[s1] * ANNP_CFLENGTH < p.rc_rad;    // ni:693: outside the cutoff nothing is added
+        if (!in0) f0 = 0.0;
+        if (!in1) f1 = 0.0;
         double e0, e1;
         exp_neg_s2(-srad[0] * m0 * m0, -srad[0] * m1 * m1, e0, e1);
 #pragma unroll
@@ -1044,8 +1054,10 @@ __global__ __launch_bounds__(256, FIX ? 2 : (NL > 0 ? NI_WAVES_PER_SIMD : 3)) vo
             if (m < p.npsf) {
                 // (the compiled-in shape has its radial etas in the ratios EM too: ni_is_shipped_shape)
                 const int km = NL > 0 ? NI_BYTE(EM, m & 3) : (int)((p.rad_em >> (8 * m)) & 255ull);
-                gr[m] += (km > 0 ? ni_powi(e0, km) : exp_neg_s(-srad[3 * m] * m0 * m0)) * f0;
-                gr[m] += (km > 0 ? ni_powi(e1, km) : exp_neg_s(-srad[3 * m] * m1 * m1)) * f1;
+                const double v0 = (km > 0 ? ni_powi(e0, km) : exp_neg_s(-srad[3 * m] * m0 * m0)) * f0;
+                const double v1 = (km > 0 ? ni_powi(e1, km) : exp_neg_s(-srad[3 * m] * m1 * m1)) * f1;
+                gr[m] += in0 ? v0 : 0.0;
+                gr[m] += in1 ? v1 : 0.0;
             }
     }
     NI_DSTAMP(3);
@@ -1134,6 +1146,7 @@ template <int NP, int NT, int NL, int NE, int NZ, unsigned ZP, unsigned EM, bool
 __global__ __launch_bounds__(256, NI_FORCE_WAVES_PER_SIMD) void annp_ni_force(NiArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ANNP_POISON();
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x >> 6);
     const int run = uniform((p.fix ? (int)blockIdx.x : xcd_block()) * ANNP_WAVES_PER_BLOCK + wave);

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void annp_verlet_half(long long n3, double *x,
 __global__ __launch_bounds__(256) void annp_fdotr_add(int nall, const double *__restrict__ x, const double *__restrict__ fs, double *f, double *vtable)
 {
     __shared__ double part[4][6];
+    ANNP_POISON();
     double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nall; i += (long long)gridDim.x * 256) {
         const double f0 = fs[3 * i], f1 = fs[3 * i + 1], f2 = fs[3 * i + 2];

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Developer tool: the GPU test suite under the LDS-poisoning builds of the library (make -C meng_zhang_amd/csrc poison; annp_common.hpp).
+#   bash tools/poison_session.sh <name> [prefix]     `prefix`: first run the Behler tiny-system tests under libannp_hip_poison_prefix.so
+#                                                   (a poison build of the code BEFORE a fix: expected red, does not stop the session)
+set -o pipefail
+name=$1; shift
+out=gpurun_out/$name
+mkdir -p $out
+cd $GRAFT_REPO_ROOT
+lib=$GRAFT_REPO_ROOT/meng_zhang_amd
+if [ "$1" = prefix ]; then
+    echo "=== poison, code before the fix (expected red) $(date +%T)"
+    ANNP_HIP_LIBRARY=$lib/libannp_hip_poison_prefix.so timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "ni_tiny_systems" > $out/prefix.log 2>&1
+    rc=$?; [ $rc -ge 124 ] && { tail -20 $out/prefix.log; exit 1; }
+    tail -12 $out/prefix.log
+fi
+for variant in poison poison_nan; do
+    echo "=== $variant $(date +%T)"
+    ANNP_HIP_LIBRARY=$lib/libannp_hip_$variant.so timeout -k 10 420 python -m pytest tests -m gpu -q > $out/$variant.log 2>&1
+    rc=$?; [ $rc -ge 124 ] && { tail -20 $out/$variant.log; exit 1; }
+    grep -E "^(FAILED|ERROR)" $out/$variant.log | head -40; tail -2 $out/$variant.log
+done
+echo "=== shipped $(date +%T)"
+timeout -k 10 420 python -m pytest tests -m gpu -x -q > $out/shipped.log 2>&1 || { tail -30 $out/shipped.log; exit 1; }
+tail -2 $out/shipped.log
+echo "=== done $(date +%T)"
