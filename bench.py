@@ -399,6 +399,9 @@ def secondary_ni(args, dev, local_rank):
     return out
 
 
+FE_ST_LOG_VOLUME = 1773495.9        # A^3: what LAMMPS printed for fe_st.dat under `boundary m p m` (the reference's log, thermo "Volume", step 0)
+
+
 def secondary_fe_st(args, dev, local_rank):
     """The reference's own published deck as a short extra leg: fe_st.dat, 152 880 Fe atoms, `boundary m p m`
     (free surfaces in x and z, ragged neighbour counts, atoms in the data file's id order), the global virial tallied every step
@@ -418,7 +421,9 @@ def secondary_fe_st(args, dev, local_rank):
            "value": leg.natoms * steps / dt, "unit": "atom-steps/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
            "kernel_ms": {"descriptor": float(ms4[0]), "network": float(ms4[1]), "force": float(ms4[2]), "evaluation": float(ms4[3]), "samples": ns},
            "neighbors_in_cutoff_mean": float(n.mean()), "neighbors_in_cutoff_max": int(n.max()), "list_neighbors_max": int(leg.mx.value),
-           "energy_last_step_eV": e, "pressure_virial_last_step_bar": float(vir[:3].sum() / (3 * 1773495.9) * 1.6021765e6),
+           "energy_last_step_eV": e, "pressure_virial_last_step_bar": float(vir[:3].sum() / (3 * FE_ST_LOG_VOLUME) * 1.6021765e6),
+           "pressure_volume_A3": FE_ST_LOG_VOLUME, "pressure_volume_source": "thermo column Volume at step 0 of the reference's log_relaxing_new.lammps for this deck "
+           "(boundary m p m: LAMMPS' shrink-wrapped box, not derivable from the data file's 1773141.3 A^3 alone)",
            "eval_path": int(leg.lib.annp_hip_eval_path(leg.h)),
            "reference_published": {"value": 85.4e3, "unit": "atom-steps/s", "n_gpus": 2, "precision": "mixed (reference GPU build)",
                                    "run": "fix npt, 1000 steps", "source": "performance test.zip log_relaxing_new.lammps:1168-1176 (BASELINE.md)",

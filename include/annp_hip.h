@@ -168,9 +168,12 @@ int annp_hip_compute_device(annp_hip_handle *handle, int inum, int nall,
  * stays valid until the next build or annp_hip_clear.
  * From the second rebuild of a handle on the call does not wait for the device: the bins of the last build that
  * looked at its bounding box are used again, rows lie a fixed pitch apart, *max_numneigh is that pitch (an upper bound of the
- * longest row) and the longest row itself is looked at by the NEXT build or annp_hip_sync.  A row that grew beyond the pitch in
+ * longest row -- NOT the longest row, as it is after a build that waits) and the longest row itself is looked at, without waiting,
+ * by the evaluations on the list (annp_hip_compute_device: the first one that finds the word landed, i.e. a step or two after the
+ * build), at the latest by the NEXT build or annp_hip_sync.  A row that grew beyond the pitch in
  * between (more than 6 % + 4 entries from one rebuild to the next) was cut on the device -- nothing is indexed beyond a row -- and
- * is reported then as ANNP_HIP_ENEIGHCAP; the build after that is an exact one.  ANNP_HIP_NEIGH_SYNC=1 in the environment at init
+ * is reported then as ANNP_HIP_ENEIGHCAP (the evaluations enqueued before that missed the entries beyond the pitch); the build after
+ * that is an exact one.  ANNP_HIP_NEIGH_SYNC=1 in the environment at init
  * makes every build wait and check before it returns, as the builds inside annp_hip_compute_n always do. */
 int annp_hip_neigh_build_device(annp_hip_handle *handle, int nlocal, int nall, const double *d_x,
                                 double cutneigh,

@@ -35,12 +35,13 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 //   ANNP_POISON_LDS=1  -1e300: survives fmin / fmax clamps, and its square is +Inf (the exp(-eta r^2) x 0 of round 5's Behler G2 loop);
 //   ANNP_POISON_LDS=2  all bits set: a quiet NaN as a double (and -1 as an int, which is what a force table's free keys look
 //                      like to the next kernel) -- catches every `x * 0` mask, whatever stands in front of it.
-// The size comes from the dispatch packet (hsa_kernel_dispatch_packet_t::group_segment_size, byte 24: static + dynamic LDS).
+// The size comes from the dispatch packet (hsa_kernel_dispatch_packet_t::group_segment_size, byte 28: static + dynamic LDS);
+// annp_hip_poison_selftest (annp_hip.hip, these builds only) checks that the fill really covers the allocation.
 #ifdef ANNP_POISON_LDS
 __device__ __forceinline__ void annp_poison_lds()
 {
     typedef const __attribute__((address_space(4))) unsigned *packet_p;
-    const unsigned bytes = ((packet_p)__builtin_amdgcn_dispatch_ptr())[6];
+    const unsigned bytes = ((packet_p)__builtin_amdgcn_dispatch_ptr())[7];         // header, setup, workgroup_size[3], reserved (12 B) | grid_size[3] | private_segment_size | group_segment_size
     typedef __attribute__((address_space(3))) double *lds_dp;
     const unsigned nthreads = blockDim.x * blockDim.y * blockDim.z;
     for (unsigned o = 8u * threadIdx.x; o + 8u <= bytes && o < 160u * 1024u; o += 8u * nthreads)

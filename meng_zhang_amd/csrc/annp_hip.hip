@@ -132,12 +132,13 @@ struct annp_hip_handle {
     FILE *notice = nullptr;             // annp_hip_set_notice: where a change of kernel path is announced (once per change)
     bool fe_dense_said = false;
     int sh_cap_used = 0;                // state slots the last annp_fe_desc_sh launch had (= atoms with moments have at most that many neighbours)
-    bool fe_dense = false;              // most atoms have more neighbours than the moment kernels take (128): the pair-loop kernels for all
+    bool fe_dense = false;              // most atoms have more neighbours than the moment kernels take (SH_CAP_MAX = 160): the pair-loop kernels for all
     bool fe_last_sh = false;            // the last Chebyshev evaluation ran the moment kernels
     bool flags_sh = false; int flags_inum = 0;      // ... and the evaluation the pending flag words belong to (several can be in flight)
     bool shf_scattered = false, shf_scattered_said = false;       // the caller's atoms are in no spatial order (annp_fe_force_sh's force table)
     int fe_last_inum = 0;
     int sh_wpb = 0;                     // waves per workgroup of annp_fe_desc_sh (ANNP_HIP_SH_WPB; 0 = chosen per launch)
+    bool sh_park = false;               // ANNP_HIP_SH_TAIL=park: the descriptor pass parks its totals in the moment row at every capacity (round 4b's kernel; developer A/B switch)
     int flagact[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // up to max(MLP_MAXL, ANNA_MAXL) weight layers
     static_assert(MLP_MAXL <= 8 && ANNA_MAXL <= 8, "flagact holds 8 layers");
     double e_scale = 0, e_shift = 0, e_atom = 0, cut = 0, cutsq = 0;
@@ -252,7 +253,12 @@ int ensure(annp_hip_handle *h, DevBuf<T> &b, size_t n, bool zeroed = false)
     size_t want = n + n / 8 + 64;
     if (b.p) { h->bytes -= b.cap * sizeof(T); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
     HIP_TRY(h, hipMalloc((void **)&b.p, want * sizeof(T)));
-    if (zeroed) HIP_TRY(h, hipMemset(b.p, 0, want * sizeof(T)));       // (only when the buffer grows)
+    if (zeroed) {       // (only when the buffer grows)
+        // the work streams do not synchronise with the null stream (hipStreamNonBlocking): the zeros are in place before anything of the
+        // evaluation is enqueued, whatever hipMemset itself waits for
+        HIP_TRY(h, hipMemset(b.p, 0, want * sizeof(T)));
+        HIP_TRY(h, hipStreamSynchronize(nullptr));
+    }
     b.cap = want;
     h->bytes += want * sizeof(T);
     return 0;
@@ -543,7 +549,12 @@ int launch_fe_desc(annp_hip_handle *h, FeArgs a, int inum, int cap_list, int max
         }
     }
     const int groups = (inum + SH_GA - 1) / SH_GA;
-    hipLaunchKernelGGL((annp_fe_desc_sh<FE_NP, FE_NT>), dim3((groups + wpb - 1) / wpb), dim3(64 * wpb), sh_lds_per_wave(cap) * wpb, s, a);
+    // up to 112 neighbours per atom (bcc Fe inside 6.5 A) the monomial totals change basis group by group out of LDS (round 6); above that,
+    // where the neighbours' state leaves no room for a group, they are parked in the moment row (ANNP_HIP_SH_TAIL=park forces that: A/B runs)
+    if (cap <= SHG_CAP_MAX && !h->sh_park)
+        hipLaunchKernelGGL((annp_fe_desc_sh<FE_NP, FE_NT, true>), dim3((groups + wpb - 1) / wpb), dim3(64 * wpb), sh_lds_per_wave(cap) * wpb, s, a);
+    else
+        hipLaunchKernelGGL((annp_fe_desc_sh<FE_NP, FE_NT, false>), dim3((groups + wpb - 1) / wpb), dim3(64 * wpb), sh_lds_per_wave(cap) * wpb, s, a);
     HIP_TRY(h, hipGetLastError());
     if (fix) {
         FeArgs b = a;
@@ -561,6 +572,14 @@ int launch_fe_desc(annp_hip_handle *h, FeArgs a, int inum, int cap_list, int max
 // the sticky word and the current evaluation's words into the host mirror, in the layout digest_flags reads
 int copy_flags(annp_hip_handle *h, hipStream_t st)
 {
+    // One writer of the host mirror at a time: the synchronous sizing paths copy in the caller's stream while the copy of the
+    // evaluation before may still be on its way on the side stream -- landing late it would overwrite the words the host is about
+    // to read.  It is waited for and digested first (an error it carries is reported by the next look at the handle, as ever).
+    if (st != h->stream_flags && h->flags_pending) {
+        HIP_TRY(h, hipEventSynchronize(h->ev_flags));
+        h->flags_pending = false;
+        digest_flags(h);
+    }
     HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipMemcpyAsync(h->h_flags + 1, h->fw + 1, (ANNP_NFLAGS - 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     return 0;
@@ -572,6 +591,13 @@ int compute_device_impl(annp_hip_handle *h, int inum, int nall, const double *d_
 {
     int rc;
     if ((rc = poll_flags(h, false))) return rc;      // an error of an earlier evaluation, reported once
+    // A list build whose row maximum nobody has looked at yet (neigh_kernels.hpp: builds behind annp_hip_neigh_build_device do not wait
+    // for it): looked at here as soon as the word has landed -- by the first or second evaluation on that list, never blocking -- so a
+    // row that outgrew the pitch is reported a step late, not a rebuild interval late
+    if (h->nb.pending && hipEventQuery(h->nb.ev_lazy) == hipSuccess) {
+        std::string msg;
+        if (int rs = neigh_settle(h->nb, msg)) return fail(h, rs, "%s", msg.c_str());
+    }
     if (inum <= 0) return 0;
     // The global virial without per-atom virials (every step of an NPT run): the evaluation's forces go to a scratch array, and one
     // streaming kernel behind the passes adds them onto the caller's f and sums x (x) f over owned atoms and ghosts -- the reference's
@@ -1107,6 +1133,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (const char *e = std::getenv("ANNP_HIP_VIRIAL")) h->virial_tally = std::strcmp(e, "tally") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SHF_PLACES")) h->shf_places_by_number = std::strcmp(e, "number") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SH_WPB")) h->sh_wpb = std::min(4, std::max(0, std::atoi(e)));
+    if (const char *e = std::getenv("ANNP_HIP_SH_TAIL")) h->sh_park = std::strcmp(e, "park") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SH_CAP")) h->sh_cap = std::min((int)SH_CAP_MAX, std::max((int)SH_CAP_MIN, round_up(std::atoi(e), 16)));
     h->cutsq = cutsq_all;
     h->nelem = ne; h->multi = multi; h->active = active;
@@ -1321,7 +1348,8 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     {
         const int full = 160 * 1024;
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
-        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc_sh<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc_sh<FE_NP, FE_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
+        INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc_sh<FE_NP, FE_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_desc_fixup<FE_NP, FE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh<FE_NP, FE_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
         INIT_TRY(hipFuncSetAttribute((const void *)annp_fe_force_sh<FE_NP, FE_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, full));
@@ -1418,6 +1446,30 @@ int annp_hip_last_descriptors(annp_hip_handle *h, double *rows, int inum)
     HIP_TRY(h, hipMemcpy(rows, h->G.p, sizeof(double) * ANNP_GPAD * (size_t)inum, hipMemcpyDeviceToHost));
     return 0;
 }
+
+#ifdef ANNP_POISON_LDS
+// developer builds only (make poison): does the fill of annp_common.hpp's ANNP_POISON() cover the workgroup's allocation?  A kernel with
+// `bytes` of dynamic LDS poisons, then copies its first and last words and one in the middle out.  Returns 0 when all three hold the pattern.
+__global__ void annp_poison_probe(unsigned long long *out, int bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ANNP_POISON();
+    const unsigned long long *w = reinterpret_cast<const unsigned long long *>(lds_raw);
+    if (threadIdx.x == 0) { out[0] = w[0]; out[1] = w[bytes / 16]; out[2] = w[bytes / 8 - 1]; }
+}
+extern "C" int annp_hip_poison_selftest(int bytes)
+{
+    unsigned long long *d = nullptr, hres[3] = {0, 0, 0};
+    if (hipMalloc((void **)&d, sizeof(hres)) != hipSuccess) return -1;
+    (void)hipFuncSetAttribute((const void *)annp_poison_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(annp_poison_probe, dim3(4), dim3(256), (size_t)bytes, nullptr, d, bytes);
+    if (hipMemcpy(hres, d, sizeof(hres), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(d); return -2; }
+    (void)hipFree(d);
+    const double pat = ANNP_POISON_LDS == 2 ? __builtin_bit_cast(double, ~0ull) : -1e300;
+    const unsigned long long want = __builtin_bit_cast(unsigned long long, pat);
+    return (hres[0] == want && hres[1] == want && hres[2] == want) ? 0 : 1;
+}
+#endif
 
 int annp_hip_sync(annp_hip_handle *h)
 {

@@ -29,7 +29,7 @@
 //            entries change basis, A_(m+k,m) = sum_j M_kj Mom_jm (sh_legendre): kappa |A|^2 into pw_l, kappa A into the moment
 //            row for the force pass.
 //   final    lane n of an atom: G_{9+n} from the 19 pw_l (q from constant memory), the radial sums, one 32-double row out.
-// An atom with more in-cutoff neighbours than the launch has state for (n_cap, at most 128) is queued for
+// An atom with more in-cutoff neighbours than the launch has state for (n_cap, at most SH_CAP_MAX = 160) is queued for
 // annp_fe_desc_fixup (the pair-loop kernel with room for a whole list row) instead.
 #pragma once
 #include <type_traits>
@@ -41,7 +41,8 @@ namespace annp {
 
 constexpr int SH_GA = 4;          // atoms per wave
 constexpr int SH_GL = 16;         // lanes per atom
-constexpr int SH_CAP_MAX = 128;   // state slots per atom the launch may ask for
+constexpr int SH_CAP_MAX = 160;   // state slots per atom the launch may ask for (round 6: 128 before -- a bcc cell compressed by 7 % has 136 neighbours inside
+                                  // 6.5 A and fell to the pair-loop kernels at half the speed; at 160 the pass keeps two workgroups per CU)
 static_assert(SH_LMAX == FE_NT - 1, "tables are generated for T_0..T_18");
 
 __constant__ double annp_sh_q[(SH_LMAX + 1) * (SH_LMAX + 1)] = ANNP_SH_Q_INIT;
@@ -53,6 +54,15 @@ __constant__ unsigned short annp_shd_info[SHD_NROUND * 16] = ANNP_SHD_INFO_INIT;
 __constant__ double annp_shd_kappa[SHD_NROUND * 16] = ANNP_SHD_KAPPA_INIT;
 __constant__ double annp_shd_coef[SHD_TFIRST[SHD_NROUND] * 16] = ANNP_SHD_COEF_INIT;
 __host__ __device__ constexpr int sh_apos(int m, int k) { return 2 * (shf_toff(m) + SH_LMAX - m - k); }
+// round 6, the GROUPED instantiation (launches with room for at most SHG_CAP_MAX neighbours per atom): the monomial totals of a group of
+// columns wait in LDS, not in the moment row (sh_tables.hpp: SHG_*)
+__constant__ unsigned short annp_shg_info[SHG_NROUND * 16] = ANNP_SHG_INFO_INIT;
+__constant__ double annp_shg_kappa[SHG_NROUND * 16] = ANNP_SHG_KAPPA_INIT;
+__constant__ double annp_shg_coef[SHG_TFIRST[SHG_NROUND] * 16] = ANNP_SHG_COEF_INIT;
+__host__ __device__ constexpr int shg_group_of(int m) { return m <= SHG_COLS[0][1] ? 0 : m <= SHG_COLS[1][1] ? 1 : 2; }
+__host__ __device__ constexpr int shg_group_of_round(int r) { return r < SHG_RFIRST[1] ? 0 : r < SHG_RFIRST[2] ? 1 : 2; }
+constexpr int SHG_CAP_MAX = 112;        // bcc Fe inside 6.5 A
+constexpr int SHG_PAD = 20;             // entries of zeros behind the last atom's: a lane reads up to 2 (T - 1) = 18 positions beyond its own with zero coefficients
 
 constexpr int SH_R = 5;           // neighbours per lane whose state stays in registers (ShRegs)
 constexpr int SH_CAP_MIN = SH_GL * SH_R + 16;
@@ -74,6 +84,12 @@ __host__ __device__ constexpr size_t sh_lds_per_wave(int n_cap)
     return a > b ? a : b;
 }
 static_assert(3 * 4 * sh_lds_per_wave(112) <= 160 * 1024, "bcc Fe (112 neighbours in 6.5 A): three workgroups of four waves per CU");
+// GROUPED: the group buffer -- four atoms' entries of the current group, SHG_NENT[g] (cosine, sine) pairs each, back to back, and SHG_PAD
+// pairs of zeros -- lies behind the neighbour arrays at their largest (SHG_CAP_MAX), where the staging rows of stage A were, and in front of pw
+constexpr int SHG_BUF_OFF = (int)sh_lds_arrays(SHG_CAP_MAX);
+constexpr int SHG_BUF_BYTES = (SH_GA * (SHG_NENT[0] > SHG_NENT[1] ? (SHG_NENT[0] > SHG_NENT[2] ? SHG_NENT[0] : SHG_NENT[2]) : (SHG_NENT[1] > SHG_NENT[2] ? SHG_NENT[1] : SHG_NENT[2])) + SHG_PAD) * 16;
+static_assert(SHG_BUF_OFF + SHG_BUF_BYTES + SH_PWB <= (int)sh_lds_per_wave(SHG_CAP_MAX), "the group buffer fits between the neighbour arrays and pw");
+static_assert(SHG_BUF_OFF >= (int)sh_lds_arrays(SH_CAP_MIN), "... at every capacity the grouped kernel is launched with");
 static_assert(SH_GL * SH_R * 32 >= SH_PWB, "pw and the radial totals live where the staging rows were");
 
 // ---- sums over the 16 lanes of an atom ------------------------------------------------------------------------------
@@ -159,6 +175,8 @@ struct ShLane {
     unsigned arow;         // ... and the byte offset of this lane's atom's row from it (a lane without an atom: 0, and alive = false)
     bool alive;
     unsigned a_mom;        // LDS byte address of the atom's monomial moments (sh_legendre)
+    unsigned a_grp;        // GROUPED: LDS byte address of the wave's group buffer ...
+    unsigned g16;          // ... and 16 x this lane's atom's number in the wave: its entries of group q begin at a_grp + g16 * SHG_NENT[q]
     int iters;             // LDS-resident neighbours per lane to walk (uniform, may be 0)
     int l16;               // the lane's number among the 16 of its atom
     int jrev;              // which of a batch's 16 totals this lane ends up with: wave lane bits 5,4,1,0 -> bits 0,1,2,3
@@ -171,7 +189,7 @@ struct ShRegs { double z[SH_R], ex[SH_R], ey[SH_R], pc[SH_R], ps[SH_R]; };
 // batch B of column M: sums 16B .. 16B+R-1 of the column (cosine j = 0..K-1, then sine j = 0..K-1) added up over the atom's
 // lanes; the lane that ends up with a total parks it in the atom's moment row in HBM -- the registers are needed for the next
 // column, and LDS is full of neighbours until the last one is done (sh_fetch_totals brings the row back in one go).
-template <int M, int B>
+template <int M, int B, bool GROUPED>
 __device__ __forceinline__ void sh_batch(const ShLane &w, const double *ac, const double *as)
 {
     constexpr int K = SH_LMAX + 1 - M;
@@ -189,6 +207,17 @@ __device__ __forceinline__ void sh_batch(const ShLane &w, const double *ac, cons
     const int j = w.jrev & (RP - 1);
     const int vv = 16 * B + j;
     const int jj = vv < K ? vv : vv - K;
+    if constexpr (GROUPED) {
+        // into the group buffer: every atom of the wave, existing or not (an atom without neighbours has zero totals; its entries are
+        // what the atom before it reads beyond its own with zero coefficients: they must be numbers)
+        if ((w.jrev & (16 - RP)) == 0 && j < R) {
+            constexpr int Q = shg_group_of(M);
+            typedef __attribute__((address_space(3))) double *l1p;
+            const unsigned at = w.a_grp + w.g16 * (unsigned)SHG_NENT[Q] + 8u * (unsigned)(sh_apos(M, 0) - 2 * SHG_GBASE[Q] + (vv < K ? 0 : 1)) - 16u * (unsigned)jj;
+            *(l1p)(uintptr_t)at = t;
+            if (M == 0) *(l1p)(uintptr_t)(at + 8u) = 0.0;
+        }
+    } else
     if ((w.jrev & (16 - RP)) == 0 && j < R && w.alive) {       // one lane per total
         // (one uniform base and a 32-bit offset per lane: the 32 batches would otherwise keep a 64-bit address each)
         const unsigned off = w.arow + 8u * (unsigned)(sh_apos(M, 0) + (vv < K ? 0 : 1)) - 16u * (unsigned)jj;
@@ -197,7 +226,7 @@ __device__ __forceinline__ void sh_batch(const ShLane &w, const double *ac, cons
     }
 }
 
-template <int M>
+template <int M, bool GROUPED>
 __device__ __forceinline__ void sh_column(const ShLane &w, ShRegs &st)
 {
     constexpr int K = SH_LMAX + 1 - M;
@@ -279,20 +308,26 @@ __device__ __forceinline__ void sh_column(const ShLane &w, ShRegs &st)
             left -= 2;
         }
     }
-    sh_batch<M, 0>(w, ac, as);
-    if (NB > 1) sh_batch<M, (NB > 1 ? 1 : 0)>(w, ac, as);
-    if (NB > 2) sh_batch<M, (NB > 2 ? 2 : 0)>(w, ac, as);
+    sh_batch<M, 0, GROUPED>(w, ac, as);
+    if (NB > 1) sh_batch<M, (NB > 1 ? 1 : 0), GROUPED>(w, ac, as);
+    if (NB > 2) sh_batch<M, (NB > 2 ? 2 : 0), GROUPED>(w, ac, as);
 }
-template <int M>
+template <int Q> __device__ __forceinline__ void shg_tail(const ShLane &w);
+template <int M, bool GROUPED>
 struct ShColumns {
     static __device__ __forceinline__ void run(const ShLane &w, ShRegs &st)
     {
-        sh_column<M>(w, st);
-        ShColumns<M + 1>::run(w, st);
+        sh_column<M, GROUPED>(w, st);
+        if constexpr (GROUPED) {
+            // the group's last column is summed: its entries change basis now, out of the group buffer (the reads of the next group's
+            // first batch come after the tail's in the wave's LDS queue: no fence between the groups is needed beyond the compiler's)
+            if constexpr (M == SHG_COLS[shg_group_of(M)][1]) { wave_lds_sync(); shg_tail<shg_group_of(M)>(w); wave_lds_sync(); }
+        }
+        ShColumns<M + 1, GROUPED>::run(w, st);
     }
 };
-template <>
-struct ShColumns<SH_LMAX + 1> {
+template <bool GROUPED>
+struct ShColumns<SH_LMAX + 1, GROUPED> {
     static __device__ __forceinline__ void run(const ShLane &, ShRegs &) {}
 };
 
@@ -359,6 +394,65 @@ __device__ __forceinline__ void sh_legendre(const ShLane &w)
     ShTail<0>::run(w, first);
 }
 
+// ---- GROUPED: the same, group by group, out of the group buffer (round 6).  Entry (m, k) of group Q reads the powers k, k-2, .. of its
+// own column at a_grp + g16 SHG_NENT[Q] + 16 (local position + 2t) and writes kappa A to the atom's moment row -- the only time the row
+// is touched: no totals parked there, nothing fetched back (8-10 GB of memory traffic per 1 M-atom launch down to the 3 GB the force
+// pass needs).  The rounds of a group follow one another as in ShTail, the next round's coefficients in flight.
+template <int R>
+struct ShgOps {
+    static constexpr int T = SHG_TRIPS[R];
+    static constexpr int Q = shg_group_of_round(R);
+    double c[T];
+    int info;
+    double kap;
+    __device__ __forceinline__ void load(const ShLane &w)
+    {
+        const unsigned lo = (unsigned)w.l16;
+        info = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(annp_shg_info + R * 16) + 2u * lo);
+        kap = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(annp_shg_kappa + R * 16) + 8u * lo);
+#pragma unroll
+        for (int t = 0; t < T; t++)
+            c[t] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(annp_shg_coef + (SHG_TFIRST[R] + t) * 16) + 8u * lo);
+        asm volatile("" ::: "memory");
+    }
+    __device__ __forceinline__ void finish(const ShLane &w)
+    {
+        typedef __attribute__((address_space(3))) shf_v2d *l2p;
+        const unsigned mo = w.a_grp + w.g16 * (unsigned)SHG_NENT[Q] + 16u * (unsigned)(info & 255);
+        shf_v2d mv[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) mv[t] = *(l2p)(uintptr_t)(mo + 32u * t);
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int t = T - 1; t >= 0; t--) { a0 = fma(c[t], mv[t].x, a0); a1 = fma(c[t], mv[t].y, a1); }       // (small powers first)
+        if ((info & 0x8000) && w.alive) {
+            atomicAdd(w.pwg + ((info >> 8) & 31), kap * fma(a0, a0, a1 * a1));
+            *reinterpret_cast<double2 *>(reinterpret_cast<char *>(w.Abase) + (w.arow + 16u * (unsigned)((info & 255) + SHG_GBASE[Q]))) = make_double2(kap * a0, kap * a1);
+        }
+    }
+};
+template <int R, int REND>
+struct ShgRounds {
+    static __device__ __forceinline__ void run(const ShLane &w, ShgOps<R> &cur)
+    {
+        if constexpr (R + 1 < REND) {
+            ShgOps<R + 1> nxt;
+            nxt.load(w);
+            cur.finish(w);
+            ShgRounds<R + 1, REND>::run(w, nxt);
+        } else {
+            cur.finish(w);
+        }
+    }
+};
+template <int Q>
+__device__ __forceinline__ void shg_tail(const ShLane &w)
+{
+    ShgOps<SHG_RFIRST[Q]> first;
+    first.load(w);
+    ShgRounds<SHG_RFIRST[Q], SHG_RFIRST[Q + 1]>::run(w, first);
+}
+
 // fe_geometry with the sincos coefficients from scalar registers (annp_common.hpp)
 __device__ __forceinline__ FeNbr sh_geometry(double2 R0, double2 R1, double pi_over_rc)
 {
@@ -373,7 +467,9 @@ __device__ __forceinline__ FeNbr sh_geometry(double2 R0, double2 R1, double pi_o
     return g;
 }
 
-template <int NP, int NT>
+// GROUPED (round 6): for launches with room for at most SHG_CAP_MAX neighbours per atom -- the steady state of bcc Fe -- the change of
+// basis runs group by group out of LDS (shg_tail); the other instantiation parks the totals in the moment row (any capacity up to SH_CAP_MAX)
+template <int NP, int NT, bool GROUPED>
 __global__ __launch_bounds__(256, 3) void annp_fe_desc_sh(FeArgs p)
 {
     static_assert(NT == SH_LMAX + 1 && NP + NT <= ANNP_GPAD && NP + 1 <= 16, "layout of the output row");
@@ -578,6 +674,16 @@ __global__ __launch_bounds__(256, 3) void annp_fe_desc_sh(FeArgs p)
     w.arow = dead ? 0u : (unsigned)(g * SH_MPAD * 8);
     w.l16 = l;
     w.a_mom = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)wbase + (unsigned)(g * SHF_NE * 16);
+    w.a_grp = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)wbase + (unsigned)SHG_BUF_OFF;
+    w.g16 = 16u * (unsigned)g;
+    if constexpr (GROUPED) {
+        // zeros behind the four atoms' entries of the smallest group up to the end of the buffer: every group's pad (what a larger group
+        // writes there later are numbers too).  The staging rows this overwrites are done with (settle ended on a barrier).
+        constexpr int Z0 = SH_GA * (SHG_NENT[0] < SHG_NENT[1] ? (SHG_NENT[0] < SHG_NENT[2] ? SHG_NENT[0] : SHG_NENT[2]) : (SHG_NENT[1] < SHG_NENT[2] ? SHG_NENT[1] : SHG_NENT[2])) * 2;
+        double *gb = reinterpret_cast<double *>(wbase + SHG_BUF_OFF);
+#pragma unroll
+        for (int k = Z0 + lane; k < SHG_BUF_BYTES / 8; k += 64) gb[k] = 0.0;
+    }
     w.jrev = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 1) & 1) << 2) | ((lane & 1) << 3);
     w.bit1 = (lane & 2) != 0; w.bit0 = (lane & 1) != 0;
     {
@@ -589,7 +695,8 @@ __global__ __launch_bounds__(256, 3) void annp_fe_desc_sh(FeArgs p)
     // ---- the monomial moments, column by column, parked in the atoms' moment rows; then, the neighbour arrays being done with,
     //      back into LDS in one go (whole rows: 12 loads per lane, one trip through the cache) and from there into the moments of
     //      the Pm^(m)_k: pw_l, and the moment row again, for the force pass
-    ShColumns<0>::run(w, st);
+    ShColumns<0, GROUPED>::run(w, st);
+    if constexpr (!GROUPED) {
     // (the wave reads back what its own lanes stored: rows are whole 128-byte lines nobody else touches, and the stores are
     // complete before the first load is issued)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -624,6 +731,7 @@ __global__ __launch_bounds__(256, 3) void annp_fe_desc_sh(FeArgs p)
     }
     wave_lds_sync();
     sh_legendre(w);
+    }
     wave_lds_sync();
 
     // ---- output row: slots l and l + 16 of the atom's 32

@@ -47,7 +47,10 @@ constexpr int SHF_BATOMS = 8;                      // atoms per bucket: 8 x 24 B
 constexpr int SHF_TPROBE = 8;                      // occupied buckets tried before a contribution goes straight to global memory
 constexpr int SHF_TBYTES = SHF_NE * 16;            // an atom's coefficient table: 190 x (b^c, b^s)
 static_assert((SHF_TBYTES / 4) % 64 >= 4 && (SHF_TBYTES / 4) % 64 <= 60, "two atoms' entries of one read must not share banks");
-static_assert(SHF_GW * SHF_CC * SHF_GL == SH_CAP_MAX, "the waves of a group cover the neighbour slots of an atom");
+constexpr int SHF_SLOTS = SHF_GW * SHF_CC * SHF_GL;     // 128 neighbour slots per atom in the waves' registers; the slots above (a denser system: up to
+                                                        // SH_CAP_MAX = 160) are an extra turn of one neighbour per lane for the waves at places 0, 1, ..
+constexpr int SHF_XWAVES = (SH_CAP_MAX - SHF_SLOTS) / SHF_GL;
+static_assert(SH_CAP_MAX >= SHF_SLOTS && (SH_CAP_MAX - SHF_SLOTS) % SHF_GL == 0 && SHF_XWAVES <= SHF_GW, "the waves of a group cover the neighbour slots of an atom");
 
 __constant__ unsigned char annp_shf_l[SHF_NE + 2] = ANNP_SHF_L_INIT;
 __constant__ double annp_shf_conv[SHF_CONV_NREC * 16] = ANNP_SHF_CONV_INIT;
@@ -685,6 +688,24 @@ __global__ __launch_bounds__(64 * SHF_WAVES, ANNP_SHF_WPS) void annp_fe_force_sh
         for (int u = 0; u < SHF_CC; u++) has_nbr[u] = a0 + SHF_GL * u < at.n;
         if (cc == 1) shf_turn<NP, 1, VIRIAL>(p, at, has_nbr, jn, dx, dy, dz, crl, pi_over_rc, two_over_rcp, tb, tab, fi, vs);
         else shf_turn<NP, 2, VIRIAL>(p, at, has_nbr, jn, dx, dy, dz, crl, pi_over_rc, two_over_rcp, tb, tab, fi, vs);
+        // more than 128 neighbours (a compressed cell; never bcc Fe at its own density): slots 128 + 16 wq + l, one more turn of one
+        // neighbour per lane for the waves at places 0 .. SHF_XWAVES-1 -- a turn with its loads exposed, for the systems that need it,
+        // instead of the pair-loop kernels for everybody (round 6: the cliff at 128 neighbours moved to 160)
+        if (nmax > SHF_SLOTS && wq < SHF_XWAVES) {
+            const int a2 = SHF_SLOTS + SHF_GL * wq + l;
+            bool has2[SHF_CC];
+            int jn2[SHF_CC];
+            double dx2[SHF_CC], dy2[SHF_CC], dz2[SHF_CC];
+#pragma unroll
+            for (int u = 0; u < SHF_CC; u++) { has2[u] = false; jn2[u] = at.i; dx2[u] = dy2[u] = dz2[u] = 0.0; }
+            has2[0] = a2 < at.n;
+            if (has2[0]) jn2[0] = p.nbrs[iic * SH_CAP_MAX + a2];
+#ifdef ANNP_SHF_CHECK
+            if ((unsigned)jn2[0] >= (unsigned)p.chk_nall) { atomicMax(p.errflag, 2000000 + (blockIdx.x & 0xffff)); jn2[0] = 0; }
+#endif
+            dx2[0] = at.xi - p.x[3 * (size_t)jn2[0]]; dy2[0] = at.yi - p.x[3 * (size_t)jn2[0] + 1]; dz2[0] = at.zi - p.x[3 * (size_t)jn2[0] + 2];
+            shf_turn<NP, 1, VIRIAL>(p, at, has2, jn2, dx2, dy2, dz2, crl, pi_over_rc, two_over_rcp, tb, tab, fi, vs);
+        }
         SHF_STAMP(5);
         // ---- the centre's share: sums over the atom's 16 lanes end up in the row's last lane
 #pragma unroll

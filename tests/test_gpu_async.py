@@ -24,14 +24,19 @@ def eval_info(pair):
 
 def test_fe_denser_configuration_takes_the_fixup_launch(fe_pot):
     """Second configuration 8 % denser than the first: ~135 in-cutoff neighbours against state sized for the previous
-    maximum.  Every atom is queued by the moment kernels and evaluated by the pair-loop fix-up launches; the call after that
-    -- most atoms went through the queue -- runs the pair-loop kernels for all atoms with the adapted capacity; back in the
-    first configuration the moment kernels return.  Forces equal the oracle's each time."""
+    maximum (112).  Every atom is queued by the moment kernels and evaluated by the pair-loop fix-up launches; the call after that
+    runs the moment kernels again, with room for 144 (round 6: they take up to 160 neighbours per atom, the force pass's waves an
+    extra turn for the slots above 128; up to round 5 the cliff stood at 128).  A third configuration, 15 % denser (168 neighbours),
+    is beyond them: most atoms went through the queue, so the next call runs the pair-loop kernels for all atoms with the adapted
+    capacity -- half the speed, said once on the notice stream; back in the first configuration the moment kernels return.
+    Forces equal the oracle's each time."""
     x, box = bcc(8, 8, 8, A_FE)
     s1 = System(perturb(x, 78, 0.05), box)
     s2 = System(perturb(x, 78, 0.05) * 0.92, box * 0.92)
+    s3 = System(perturb(x, 78, 0.05) * 0.85, box * 0.85)
     o1 = oracle_compute(fe_pot, s1, KIND_FE, FAST)
     o2 = oracle_compute(fe_pot, s2, KIND_FE, FAST)
+    o3 = oracle_compute(fe_pot, s3, KIND_FE, FAST)
     p = make_pair(FE_POT, "Fe")
     import ctypes as C
     import tempfile
@@ -44,39 +49,48 @@ def test_fe_denser_configuration_takes_the_fixup_launch(fe_pot):
     note = tempfile.NamedTemporaryFile(suffix=".log", delete=False)
     note.close()
     fh = libc.fopen(note.name.encode(), b"w")
+
+    def same(r, o):
+        assert np.abs(r["f_all"] - o["f_all"]).max() < 1e-9 * max(1.0, np.abs(o["f"]).max())
+        assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6
+        p.eatom[:] = 0.0
     try:
         assert lib.annp_hip_set_notice(p.handle, fh) == 0           # what annp_gpu_init does with LAMMPS' screen
-        r = run(p, s1)                                # first evaluation: room for 128 neighbours per atom
-        assert np.abs(r["f"] - o1["f"]).max() < 1e-9
+        r = run(p, s1)                                # first evaluation: room for 160 neighbours per atom
         mx1, nfix, cap, cap_next = eval_info(p)
-        assert nfix == 0 and cap == 128 and mx1 <= 126 and cap_next == (mx1 + 15) // 16 * 16
+        assert nfix == 0 and cap == 160 and mx1 <= 126 and cap_next == (mx1 + 15) // 16 * 16
         assert lib.annp_hip_eval_path(p.handle) == 0                # the moment kernels
-        p.eatom[:] = 0.0
+        same(r, o1)
         r = run(p, s2)                                # state still sized for s1
         mx2, nfix, cap, cap_next2 = eval_info(p)
-        assert cap == cap_next and mx2 > 128 and nfix > s2.nlocal // 2 and cap_next2 >= mx2
-        assert lib.annp_hip_eval_path(p.handle) == 1                # the 2x cliff is visible: pair by pair from the next evaluation on ...
-        assert np.abs(r["f_all"] - o2["f_all"]).max() < 1e-9 * max(1.0, np.abs(o2["f"]).max())
-        assert np.abs(r["eatom"] - o2["eatom"]).max() < 1e-6
-        p.eatom[:] = 0.0
-        r = run(p, s2)                                # pair-loop kernels, adapted
+        assert cap == cap_next and 128 < mx2 <= 160 and nfix > s2.nlocal // 2 and cap_next2 == (mx2 + 15) // 16 * 16
+        assert lib.annp_hip_eval_path(p.handle) == 0                # ... and no cliff: the moment kernels take this density
+        same(r, o2)
+        r = run(p, s2)                                # moment kernels with room for 144: slots above 128 are the force pass's extra turn
         _, nfix, cap, _ = eval_info(p)
-        assert nfix == 0 and cap == cap_next2
-        assert np.abs(r["f_all"] - o2["f_all"]).max() < 1e-9 * max(1.0, np.abs(o2["f"]).max())
-        p.eatom[:] = 0.0
+        assert nfix == 0 and cap == cap_next2 and lib.annp_hip_eval_path(p.handle) == 0
+        same(r, o2)
+        r = run(p, s3)                                # 168 neighbours: beyond the moment kernels, everything through the queue
+        mx3, nfix, cap, cap_next3 = eval_info(p)
+        assert cap == cap_next2 and mx3 > 160 and nfix > s3.nlocal // 2 and cap_next3 >= mx3
+        assert lib.annp_hip_eval_path(p.handle) == 1                # the 2x cliff is visible: pair by pair from the next evaluation on ...
+        same(r, o3)
+        r = run(p, s3)                                # pair-loop kernels, adapted
+        _, nfix, cap, _ = eval_info(p)
+        assert nfix == 0 and cap == cap_next3
+        same(r, o3)
         r = run(p, s1)                                # and back: capacity above need is fine, then the moment kernels again
-        assert np.abs(r["f"] - o1["f"]).max() < 1e-9
         assert eval_info(p)[3] == cap_next
-        p.eatom[:] = 0.0
+        same(r, o1)
         r = run(p, s1)
-        assert np.abs(r["f"] - o1["f"]).max() < 1e-9
         assert eval_info(p)[1:3] == [0, cap_next]
         assert lib.annp_hip_eval_path(p.handle) == 0
+        same(r, o1)
         lib.annp_hip_set_notice(p.handle, None)
         libc.fclose(fh)
         fh = None
         said = open(note.name).read().splitlines()                  # ... and was said, once each way
-        assert len(said) == 2 and "pair by pair" in said[0] and "more than the 128" in said[0] and "back to the moment kernels" in said[1]
+        assert len(said) == 2 and "pair by pair" in said[0] and "more than the 160" in said[0] and "back to the moment kernels" in said[1]
     finally:
         if fh:
             lib.annp_hip_set_notice(p.handle, None)
@@ -103,7 +117,11 @@ def test_fe_mixed_density_only_some_atoms_overflow(fe_pot):
         p.eatom[:] = 0.0
         got = run(p, s2)
         mx, nfix, cap, _ = eval_info(p)
-        assert cap in (112, 128) and mx > 128 and 20 < nfix < 400        # (the moment kernels queue every atom above their state)
+        assert cap == 112 and 128 < mx <= 160 and 20 < nfix < 400        # (the moment kernels queue every atom above their state)
+        p.eatom[:] = 0.0
+        got2 = run(p, s2)                             # the next evaluation has room for all of them: nothing in the queue
+        assert eval_info(p)[1:3] == [0, (mx + 15) // 16 * 16]
+        assert np.abs(got2["f_all"] - o2["f_all"]).max() < 1e-9 * max(1.0, np.abs(o2["f"]).max())
         assert np.abs(got["f_all"] - o2["f_all"]).max() < 1e-9 * max(1.0, np.abs(o2["f"]).max())
         assert np.abs(got["eatom"] - o2["eatom"]).max() < 1e-6
     finally:

@@ -131,7 +131,7 @@ def test_virtual_ranks_on_one_device(fe_pot, world):
         assert np.abs(f - o["f"]).max() < 1e-9 * max(1.0, np.abs(o["f"]).max())
 
 
-def _builds(x_lattice, xs, box0):
+def _builds(x_lattice, xs, box0, settle_first=False):
     """rebuild the device list for every configuration in xs (displacements of x_lattice, from which the images are planned) on one
     handle, evaluate after the last; returns forces, energy, the builds' return codes and what they reported as the longest row"""
     import torch
@@ -161,9 +161,14 @@ def _builds(x_lattice, xs, box0):
     if rcs[-1] == 0:
         eng = torch.zeros(1, dtype=torch.float64, device=dev)
         dom.f.zero_()
-        assert lib.annp_hip_compute_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value, dom.f.data_ptr(),
-                                           None, eng.data_ptr(), None, None, stream) == 0
+        if settle_first:
+            torch.cuda.synchronize(dev)          # the build's row maximum has landed in its pinned word: the evaluation below looks at it
+        out["rc_compute"] = lib.annp_hip_compute_device(h, dom.nlocal, dom.nall, dom.x.data_ptr(), None, None, pn, pf, pg, mx.value, dom.f.data_ptr(),
+                                                        None, eng.data_ptr(), None, None, stream)
+        out["message"] = lib.annp_hip_last_error(h)
         out["rc_sync"] = lib.annp_hip_sync(h)
+        if out["rc_sync"]:
+            out["message"] = lib.annp_hip_last_error(h)
         dom.reverse()
         out.update(f=dom.f[: dom.nlocal].cpu().numpy(), energy=float(eng.item()))
     pair.close()
@@ -176,7 +181,7 @@ def test_list_rebuilds_without_a_host_round_trip_equal_checked_ones(fe_pot, monk
     x0, box = bcc(12, 12, 12, A_FE)
     xs = [perturb(x0, 11 + k, 0.03 + 0.01 * k) for k in range(4)]
     lazy = _builds(x0, xs, box)
-    assert lazy["rcs"] == [0, 0, 0, 0] and lazy["rc_sync"] == 0
+    assert lazy["rcs"] == [0, 0, 0, 0] and lazy["rc_compute"] == 0 and lazy["rc_sync"] == 0
     monkeypatch.setenv("ANNP_HIP_NEIGH_SYNC", "1")
     checked = _builds(x0, xs, box)
     assert checked["rcs"] == [0, 0, 0, 0]
@@ -199,6 +204,11 @@ def test_a_row_that_outgrows_its_pitch_between_rebuilds_is_reported():
     r = _builds(x0, [x0, perturb(x0, 5, 0.02), dense, x0], box)
     assert r["rcs"][:3] == [0, 0, 0] and r["rcs"][3] == -7, r
     assert b"between two rebuilds" in r["message"] or "between two rebuilds" in str(r["message"])
-    # ... and annp_hip_sync says so too when no further build comes
+    # ... and when no further build comes: the first evaluation on the list that finds the word landed (the error used to
+    # wait for the next rebuild), or annp_hip_sync behind it
     r = _builds(x0, [x0, perturb(x0, 5, 0.02), dense], box)
-    assert r["rcs"] == [0, 0, 0] and r["rc_sync"] == -7
+    assert r["rcs"] == [0, 0, 0] and (r["rc_compute"], r["rc_sync"]) in ((-7, 0), (0, -7)), r
+    # the word has landed for certain: the evaluation itself reports it and nothing is left for the sync
+    r = _builds(x0, [x0, perturb(x0, 5, 0.02), dense], box, settle_first=True)
+    assert r["rcs"] == [0, 0, 0] and r["rc_compute"] == -7 and r["rc_sync"] == 0, r
+    assert "between two rebuilds" in str(r["message"])

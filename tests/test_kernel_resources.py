@@ -30,7 +30,7 @@ def test_occupancies_quoted_in_design(kernels):
     assert all(w == 4 and v <= 128 for v, w in occ("annp::annp_ni_desc<%s, false, " % shipped))      # record capacity compiled in (20) and at run time (0)
     assert all(w == 3 and v <= 168 for v, w in occ("annp::annp_ni_force<%s" % shipped))
     assert all(w >= 4 and v <= 128 for v, w in occ("annp::annp_fe_desc<9, 19>"))
-    assert all(w == 3 and v <= 168 for v, w in occ("annp::annp_fe_desc_sh<9, 19>"))      # 13 KB of LDS per wave: 12 waves per CU either way
+    assert all(w == 3 and v <= 168 for v, w in occ("annp::annp_fe_desc_sh<9, 19, "))      # 13 KB of LDS per wave: 12 waves per CU either way
     assert all(w == 4 and v <= 128 for v, w in occ("annp::annp_fe_force_sh<9, 19"))      # two 8-wave workgroups per CU
     assert all(w >= 5 for v, w in occ("annp::annp_fe_force<9, 19, false, true, 128>"))
     assert all(w >= 4 for v, w in occ("annp::annp_mlp_mfma<7, 2, 3>"))      # 8 waves per workgroup: at least 2 workgroups of registers

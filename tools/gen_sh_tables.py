@@ -139,6 +139,45 @@ def tail_tables():
     return info, kap, coef, trips
 
 
+# ---- the same change of basis in three groups of columns, each through LDS as soon as its columns are summed (round 6) ----------
+# annp_fe_desc_sh<.., GROUPED>: the monomial totals of a group of columns wait in LDS (there is room for a third of them beside the
+# neighbours' state up to 112 neighbours per atom) instead of the atom's moment row in HBM; after the group's last column its entries
+# change basis -- rounds of sixteen as above, per group -- and only kappa A goes to memory, once.  Columns are summed m = 0, 1, ..:
+# the groups are runs of m, cut so that each fills its rounds (54 + 58 + 78 entries in 4 + 4 + 5 rounds: 13, one more than ungrouped).
+SHG_GROUPS = [tuple(range(0, 3)), tuple(range(3, 7)), tuple(range(7, L + 1))]
+
+
+def group_schedule():
+    """[(columns, rounds, trips)] per group: tail_schedule restricted to the group's columns"""
+    out = []
+    for cols in SHG_GROUPS:
+        ent = sorted(((m, k) for m in cols for k in range(L + 1 - m)), key=lambda e: (-e[1], e[0]))
+        rounds = [ent[i:i + 16] for i in range(0, len(ent), 16)]
+        trips = [r[0][1] // 2 + 1 for r in rounds]
+        out.append((cols, [r + [None] * (16 - len(r)) for r in rounds], trips))
+    return out
+
+
+def group_tables():
+    """As tail_tables, rounds of all groups one after the other; positions are LOCAL to the group's LDS buffer (entry (m, k) of a group
+    whose highest column is mh sits at shf_toff(m) + L - m - k - shf_toff(mh)); a lane without an entry reads the group's last position
+    with zero coefficients.  Returns (info, kappa, coef, trips, first round of every group, base position of every group, entries per group)."""
+    polys = {m: pm_monomials(m) for m in range(L + 1)}
+    info, kap, coef, trips_all, rfirst, gbase, nent = [], [], [], [], [0], [], []
+    for cols, rounds, trips in group_schedule():
+        base = shf_toff(max(cols))
+        n = sum(L + 1 - m for m in cols)
+        gbase.append(base); nent.append(n)
+        for r, T in zip(rounds, trips):
+            info.append([(shf_toff(e[0]) + L - e[0] - e[1] - base) | ((e[0] + e[1]) << 8) | (1 << 15) if e else n - 1 for e in r])
+            kap.append([kappa(e[0] + e[1], e[0]) if e else Fr(0) for e in r])
+            for t in range(T):
+                coef.append([polys[e[0]][e[1]][e[1] - 2 * t] if e and e[1] - 2 * t >= 0 else Fr(0) for e in r])
+            trips_all.append(T)
+        rfirst.append(len(trips_all))
+    return info, kap, coef, trips_all, rfirst, gbase, nent
+
+
 def sqrt_to_double(x):
     getcontext().prec = 80
     return float((Decimal(x.numerator) / Decimal(x.denominator)).sqrt())
@@ -171,6 +210,20 @@ def render():
               "#define ANNP_SHD_INFO_INIT { " + ", ".join(str(v) for row in tail_tables()[0] for v in row) + " }",
               "#define ANNP_SHD_KAPPA_INIT { \\"] + ["    " + ", ".join(float(v).hex() for v in row) + ", \\" for row in tail_tables()[1]] + ["}",
               "#define ANNP_SHD_COEF_INIT { \\"] + ["    " + ", ".join(float(v).hex() for v in row) + ", \\" for row in tail_tables()[2]] + ["}", "",
+              "// the same in three groups of columns through LDS (round 6; group_schedule / group_tables of the generator): SHG_COLS[g] = columns of",
+              "// group g as [first, last], SHG_RFIRST[g] = its first round, SHG_GBASE[g] = position of its first entry in the moment row, SHG_NENT[g]",
+              "// = its entries per atom; positions in ANNP_SHG_INFO_INIT are local to the group (row position - SHG_GBASE[g])",
+              "constexpr int SHG_NGROUP = %d;" % len(SHG_GROUPS),
+              "constexpr int SHG_COLS[SHG_NGROUP][2] = {" + ", ".join("{%d, %d}" % (min(c), max(c)) for c in SHG_GROUPS) + "};",
+              "constexpr int SHG_NROUND = %d;" % len(group_tables()[3]),
+              "constexpr int SHG_RFIRST[SHG_NGROUP + 1] = {" + ", ".join(str(v) for v in group_tables()[4]) + "};",
+              "constexpr int SHG_GBASE[SHG_NGROUP] = {" + ", ".join(str(v) for v in group_tables()[5]) + "};",
+              "constexpr int SHG_NENT[SHG_NGROUP] = {" + ", ".join(str(v) for v in group_tables()[6]) + "};",
+              "constexpr int SHG_TRIPS[SHG_NROUND] = {" + ", ".join(str(t) for t in group_tables()[3]) + "};",
+              "constexpr int SHG_TFIRST[SHG_NROUND + 1] = {" + ", ".join(str(sum(group_tables()[3][:r])) for r in range(len(group_tables()[3]) + 1)) + "};",
+              "#define ANNP_SHG_INFO_INIT { " + ", ".join(str(v) for row in group_tables()[0] for v in row) + " }",
+              "#define ANNP_SHG_KAPPA_INIT { \\"] + ["    " + ", ".join(float(v).hex() for v in row) + ", \\" for row in group_tables()[1]] + ["}",
+              "#define ANNP_SHG_COEF_INIT { \\"] + ["    " + ", ".join(float(v).hex() for v in row) + ", \\" for row in group_tables()[2]] + ["}", "",
               "// q[n][l]: T_n((z+1)/2) = sum_{l<=n} q[n][l] P_l(z)",
               "#define ANNP_SH_Q_INIT { \\"]
     for n in range(L + 1):

@@ -8,6 +8,16 @@ out=gpurun_out/$name
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
 lib=$GRAFT_REPO_ROOT/meng_zhang_amd
+# the fill must cover the allocation, or the runs below say nothing: a probe kernel with 1 KB, 13 KB and 64 KB of dynamic LDS
+for variant in poison poison_nan; do
+    python - <<PY || { echo "poison self-test failed for $variant"; exit 1; }
+import ctypes, sys
+lib = ctypes.CDLL("$lib/libannp_hip_$variant.so")
+rcs = [lib.annp_hip_poison_selftest(n) for n in (1024, 13312, 65536)]
+print("self-test $variant:", rcs)
+sys.exit(0 if rcs == [0, 0, 0] else 1)
+PY
+done
 if [ "$1" = prefix ]; then
     echo "=== poison, code before the fix (expected red) $(date +%T)"
     ANNP_HIP_LIBRARY=$lib/libannp_hip_poison_prefix.so timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "ni_tiny_systems" > $out/prefix.log 2>&1
