@@ -125,7 +125,8 @@ struct annp_hip_handle {
     bool ni_primed = false;             // ... has been sized from a completed evaluation (else the next one sizes it synchronously)
     int fe_cap = 0;                     // Chebyshev force pass: record capacity for the next evaluation (0 = not sized yet)
     int cap_last = 0;                   // capacity the last force pass ran with
-    int sh_cap = SH_CAP_MAX;            // Chebyshev descriptor pass (annp_fe_desc_sh): state slots per atom for the next evaluation
+    int sh_cap = 128;                   // Chebyshev descriptor pass (annp_fe_desc_sh): state slots per atom for the next evaluation.  The first one gets 128, not
+                                        // SH_CAP_MAX: up to there the pass keeps three workgroups per CU (160: two), and whoever has more goes through the fix-up launch once
     bool fe_desc_pairs = false;         // ANNP_HIP_FE_DESC=pairs: the pair-loop descriptor kernel (annp_fe_desc) for every atom
     bool fe_force_pairs = false;        // ANNP_HIP_FE_FORCE=pairs: the pair-loop force kernel (annp_fe_force) for every atom
     int shf_places_by_number = 0;       // ANNP_HIP_SHF_PLACES=number: the one-slot wave of a group is its fourth wave, wherever it sits (developer A/B switch)
@@ -138,7 +139,7 @@ struct annp_hip_handle {
     bool shf_scattered = false, shf_scattered_said = false;       // the caller's atoms are in no spatial order (annp_fe_force_sh's force table)
     int fe_last_inum = 0;
     int sh_wpb = 0;                     // waves per workgroup of annp_fe_desc_sh (ANNP_HIP_SH_WPB; 0 = chosen per launch)
-    bool sh_park = false;               // ANNP_HIP_SH_TAIL=park: the descriptor pass parks its totals in the moment row at every capacity (round 4b's kernel; developer A/B switch)
+    bool sh_group = false;              // ANNP_HIP_SH_TAIL=group: the descriptor pass changes basis group by group out of LDS where it can (round 6, measured 2 % slower; developer A/B switch)
     int flagact[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // up to max(MLP_MAXL, ANNA_MAXL) weight layers
     static_assert(MLP_MAXL <= 8 && ANNA_MAXL <= 8, "flagact holds 8 layers");
     double e_scale = 0, e_shift = 0, e_atom = 0, cut = 0, cutsq = 0;
@@ -549,9 +550,12 @@ int launch_fe_desc(annp_hip_handle *h, FeArgs a, int inum, int cap_list, int max
         }
     }
     const int groups = (inum + SH_GA - 1) / SH_GA;
-    // up to 112 neighbours per atom (bcc Fe inside 6.5 A) the monomial totals change basis group by group out of LDS (round 6); above that,
-    // where the neighbours' state leaves no room for a group, they are parked in the moment row (ANNP_HIP_SH_TAIL=park forces that: A/B runs)
-    if (cap <= SHG_CAP_MAX && !h->sh_park)
+    // The monomial totals are parked in the moment row and changed of basis at the end (round 4b).  ANNP_HIP_SH_TAIL=group (developer A/B
+    // switch) selects round 6's variant for launches with room for at most 112 neighbours per atom: the change of basis group by group
+    // out of LDS, nothing parked -- 3 GB less memory traffic per 1 M-atom launch and 2 % SLOWER (4.84-4.86 against 4.72-4.77 ms on one box,
+    // alternating: gpurun_out/r6_ab2), as round 4's five-group version was: the pass does not wait for that traffic, and three tails in
+    // the middle of the columns cost more than one at the end.
+    if (cap <= SHG_CAP_MAX && h->sh_group)
         hipLaunchKernelGGL((annp_fe_desc_sh<FE_NP, FE_NT, true>), dim3((groups + wpb - 1) / wpb), dim3(64 * wpb), sh_lds_per_wave(cap) * wpb, s, a);
     else
         hipLaunchKernelGGL((annp_fe_desc_sh<FE_NP, FE_NT, false>), dim3((groups + wpb - 1) / wpb), dim3(64 * wpb), sh_lds_per_wave(cap) * wpb, s, a);
@@ -1133,7 +1137,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (const char *e = std::getenv("ANNP_HIP_VIRIAL")) h->virial_tally = std::strcmp(e, "tally") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SHF_PLACES")) h->shf_places_by_number = std::strcmp(e, "number") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SH_WPB")) h->sh_wpb = std::min(4, std::max(0, std::atoi(e)));
-    if (const char *e = std::getenv("ANNP_HIP_SH_TAIL")) h->sh_park = std::strcmp(e, "park") == 0;
+    if (const char *e = std::getenv("ANNP_HIP_SH_TAIL")) h->sh_group = std::strcmp(e, "group") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SH_CAP")) h->sh_cap = std::min((int)SH_CAP_MAX, std::max((int)SH_CAP_MIN, round_up(std::atoi(e), 16)));
     h->cutsq = cutsq_all;
     h->nelem = ne; h->multi = multi; h->active = active;

@@ -96,6 +96,9 @@ struct ShfTable {
 #endif
         const int b = j >> 3;
         unsigned h = ((unsigned)b * 0x9E3779B1u) >> (32 - SHF_BBITS);
+#ifdef ANNP_SHF_NOPROBE     // developer timing build (wrong forces): the bucket the hash names, whoever holds it -- what a probe costs
+        { double *a = acc + (h * SHF_BATOMS + (j & 7)) * 3; key[h] = b; atomicAdd(a, fx); atomicAdd(a + 1, fy); atomicAdd(a + 2, fz); return; }
+#endif
 #pragma unroll 1
         for (int probe = 0; probe < SHF_TPROBE; probe++) {
             // most contributions find their bucket taken by an earlier one: a plain read settles those, the compare-and-swap

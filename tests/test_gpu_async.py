@@ -56,9 +56,9 @@ def test_fe_denser_configuration_takes_the_fixup_launch(fe_pot):
         p.eatom[:] = 0.0
     try:
         assert lib.annp_hip_set_notice(p.handle, fh) == 0           # what annp_gpu_init does with LAMMPS' screen
-        r = run(p, s1)                                # first evaluation: room for 160 neighbours per atom
+        r = run(p, s1)                                # first evaluation: room for 128 neighbours per atom
         mx1, nfix, cap, cap_next = eval_info(p)
-        assert nfix == 0 and cap == 160 and mx1 <= 126 and cap_next == (mx1 + 15) // 16 * 16
+        assert nfix == 0 and cap == 128 and mx1 <= 126 and cap_next == (mx1 + 15) // 16 * 16
         assert lib.annp_hip_eval_path(p.handle) == 0                # the moment kernels
         same(r, o1)
         r = run(p, s2)                                # state still sized for s1

@@ -3,7 +3,7 @@
 # tools/kbench.py under each of the given environments in turn, `rounds` times over.
 #   bash tools/ab_session.sh <name> <rounds> "<kbench args>" "<env A>" "<env B>" ...       an environment: VAR=value words, or "-" for none;
 #   LIB=<file> in an environment selects meng_zhang_amd/<file> as ANNP_HIP_LIBRARY
-#   TESTS="tests/test_gpu_fe_desc_sh.py ..." in the caller's environment: run first (under every environment), stop if red
+#   TESTS="tests/test_gpu_fe_desc_sh.py ..." in the caller's environment: run first (under the first TESTS_ENVS environments, default all), stop if red
 set -o pipefail
 name=$1; rounds=$2; kargs=$3; shift 3
 out=gpurun_out/$name
@@ -13,6 +13,7 @@ expand() { local e=""; for w in $1; do case $w in -) ;; LIB=*) e="$e ANNP_HIP_LI
 if [ -n "$TESTS" ]; then
     k=0
     for env in "$@"; do
+        [ $k -ge ${TESTS_ENVS:-99} ] && break
         echo "=== tests under [$env] $(date +%T)"
         env $(expand "$env") timeout -k 10 600 python -m pytest $TESTS -m gpu -x -q > $out/tests_$k.log 2>&1 || { tail -30 $out/tests_$k.log; exit 1; }
         tail -1 $out/tests_$k.log
