@@ -208,6 +208,11 @@ struct annp_hip_handle {
     int *pin_num = nullptr;
     size_t pin_hdr_cap = 0;             // atoms
     static constexpr int kListBufs = 3;
+    static constexpr int kListParts = 8;        // runs of chunks a host list is evaluated in while it is uploaded (annp_hip_compute, ago == 0)
+    hipEvent_t ev_part[kListParts] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int list_parts = 4;                         // ANNP_HIP_LIST_PARTS (1 = upload first, evaluate afterwards: rounds 1-5)
+    int list_pipe_min = 1 << 16;                // ... for lists of at least that many atoms (ANNP_HIP_LIST_PIPE_MIN)
+    size_t list_chunk = kListChunk;             // ints per chunk of the upload (ANNP_HIP_LIST_CHUNK: smaller chunks let a test cut a small list into runs)
     static constexpr size_t kListChunk = (size_t)8 << 20;      // ints per staging buffer (32 MB)
     int *pin_list[kListBufs] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_list[kListBufs] = {nullptr, nullptr, nullptr};
@@ -1028,6 +1033,7 @@ void annp_hip_clear(annp_hip_handle *h)
         if (h->pin_list[b]) (void)hipHostFree(h->pin_list[b]);
         if (h->ev_list[b]) (void)hipEventDestroy(h->ev_list[b]);
     }
+    for (hipEvent_t e : h->ev_part) if (e) (void)hipEventDestroy(e);
     delete h->pool;
     if (h->h_scalars) (void)hipHostFree(h->h_scalars);
     for (hipEvent_t e : h->evring) if (e) (void)hipEventDestroy(e);
@@ -1137,6 +1143,9 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (const char *e = std::getenv("ANNP_HIP_VIRIAL")) h->virial_tally = std::strcmp(e, "tally") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SHF_PLACES")) h->shf_places_by_number = std::strcmp(e, "number") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SH_WPB")) h->sh_wpb = std::min(4, std::max(0, std::atoi(e)));
+    if (const char *e = std::getenv("ANNP_HIP_LIST_PARTS")) h->list_parts = std::max(1, std::min((int)annp_hip_handle::kListParts, std::atoi(e)));
+    if (const char *e = std::getenv("ANNP_HIP_LIST_PIPE_MIN")) h->list_pipe_min = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("ANNP_HIP_LIST_CHUNK")) h->list_chunk = std::max<size_t>(1024, std::min<size_t>(annp_hip_handle::kListChunk, (size_t)std::atoll(e)));
     if (const char *e = std::getenv("ANNP_HIP_SH_TAIL")) h->sh_group = std::strcmp(e, "group") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SH_CAP")) h->sh_cap = std::min((int)SH_CAP_MAX, std::max((int)SH_CAP_MIN, round_up(std::atoi(e), 16)));
     h->cutsq = cutsq_all;
@@ -2070,8 +2079,12 @@ static int host_evaluate(annp_hip_handle *h, int inum, int nall, const int *host
 // 230 M entries at 1 M atoms: the rows are packed into pinned staging buffers of 32 MB by a few host threads and each
 // buffer goes out with its own asynchronous copy, so packing chunk c + 1 overlaps the transfer of chunk c; the
 // headers take the same road.  (A single-threaded pack into pageable memory and one blocking copy cost 250 ms.)
+// `parts` > 1 with a hook: the list is cut into that many runs of whole chunks, and when the copies of a run are enqueued (on `s`) the hook
+// is called with the run's range of list slots [ii0, ii1) and an event recorded behind its last copy -- the caller starts the evaluation
+// of those atoms on another stream while the host packs the next run (annp_hip_compute, round 6).
+typedef std::function<int(int, int, hipEvent_t)> ListPartHook;
 static int upload_host_list(annp_hip_handle *h, int inum, int nall, const int *ilist, const int *numj,
-                            const int *const *firstneigh, hipStream_t s)
+                            const int *const *firstneigh, hipStream_t s, int parts = 1, const ListPartHook &hook = ListPartHook())
 {
     int rc;
     if ((size_t)nall + 1 > h->pin_hdr_cap) {
@@ -2096,20 +2109,24 @@ static int upload_host_list(annp_hip_handle *h, int inum, int nall, const int *i
         tot += numj[i];
         mx = std::max(mx, numj[i]);
     }
-    if (mx > (int)annp_hip_handle::kListChunk) return fail(h, ANNP_HIP_ENEIGHCAP, "a list row has %d entries", mx);
+    if (mx > (int)h->list_chunk) return fail(h, ANNP_HIP_ENEIGHCAP, "a list row has %d entries", mx);
     if ((rc = ensure(h, h->first, (size_t)nall + 1)) || (rc = ensure(h, h->numneigh, (size_t)nall)) ||
         (rc = ensure(h, h->neigh, (size_t)std::max<long long>(tot, 1))) || (rc = ensure(h, h->ilist, (size_t)std::max(inum, 1))))
         return rc;
     HIP_TRY(h, hipMemcpyAsync(h->first.p, h->pin_first, sizeof(long long) * ((size_t)nall + 1), hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(h->numneigh.p, h->pin_num, sizeof(int) * (size_t)nall, hipMemcpyHostToDevice, s));
     if (inum > 0) HIP_TRY(h, hipMemcpyAsync(h->ilist.p, ilist, sizeof(int) * (size_t)inum, hipMemcpyHostToDevice, s));
+    h->list_max = mx;           // (the hook evaluates before this function returns)
     // rows, chunk by chunk (whole rows per chunk)
     int ii0 = 0, chunk = 0;
+    const long long part_fill = parts > 1 ? (tot + parts - 1) / parts : tot + 1;      // entries per run of chunks, about
+    long long part_done = 0;
+    int part_ii0 = 0, part_k = 0;
     while (ii0 < inum) {
         const long long base = h->pin_first[ilist[ii0]];
         int ii1 = ii0;
         long long fill = 0;
-        while (ii1 < inum && fill + numj[ilist[ii1]] <= (long long)annp_hip_handle::kListChunk) fill += numj[ilist[ii1++]];
+        while (ii1 < inum && fill + numj[ilist[ii1]] <= (long long)h->list_chunk) fill += numj[ilist[ii1++]];
         const int b = chunk % annp_hip_handle::kListBufs;
         if (chunk >= annp_hip_handle::kListBufs) HIP_TRY(h, hipEventSynchronize(h->ev_list[b]));      // its previous copy has left
         int *dst = h->pin_list[b];
@@ -2125,11 +2142,71 @@ static int upload_host_list(annp_hip_handle *h, int inum, int nall, const int *i
         HIP_TRY(h, hipEventRecord(h->ev_list[b], s));
         ii0 = ii1;
         chunk++;
+        part_done += fill;
+        if (hook && (ii0 >= inum || part_done >= part_fill)) {      // a run is on its way: its atoms can be evaluated behind this event
+            if (!h->ev_part[part_k % annp_hip_handle::kListParts]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_part[part_k % annp_hip_handle::kListParts], hipEventDisableTiming));
+            hipEvent_t ev = h->ev_part[part_k % annp_hip_handle::kListParts];
+            HIP_TRY(h, hipEventRecord(ev, s));
+            if ((rc = hook(part_ii0, ii0, ev))) { (void)hipStreamSynchronize(s); return rc; }
+            part_ii0 = ii0; part_done = 0; part_k++;
+        }
     }
     HIP_TRY(h, hipStreamSynchronize(s));     // ilist and the staging buffers are the caller's / reused
     h->list_max = mx;
     h->list_valid = true;
     return 0;
+}
+
+// annp_hip_compute with a list to upload (ago == 0: LAMMPS rebuilt its list; `package gpu ... neigh no`, the mode of the reference's own
+// deck): 0.92 GB of rows for 1 M atoms take 25 ms to pack and send, and rounds 1-5 started the 10 ms evaluation when the last byte had
+// landed.  The passes work atom by atom, so the list goes out in a few runs of chunks on the second stream and the evaluation of a
+// run's atoms is enqueued on the first as soon as the run's copies are -- behind an event, while the host packs the next run: all but
+// the last run's evaluation hides behind the upload.  Forces, energy and virial accumulate over the runs as they do over two calls.
+static int host_evaluate_uploading(annp_hip_handle *h, int inum, int nall, const int *host_type, const int *ilist, const int *numj,
+                                   const int *const *firstneigh, int eflag, int vflag, int eatom_flag,
+                                   double *f, double *eng_vdwl, double *eatom, double *virial, double *vatom)
+{
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = ensure_pool(h))) return rc;
+    if ((rc = ensure(h, h->f, (size_t)nall * 3)) || (rc = ensure(h, h->eatom, (size_t)nall))) return rc;
+    if (vatom && (rc = ensure(h, h->vatom, (size_t)nall * 6))) return rc;
+    const int *d_type = nullptr;
+    if (h->multi) {
+        if (!host_type) return fail(h, ANNP_HIP_EARG, "this potential distinguishes atom types: host_type is required");
+        for (int k = 0; k < nall; k++)
+            if (host_type[k] < 1 || host_type[k] > h->ntypes)
+                return fail(h, ANNP_HIP_EARG, "type[%d] = %d is outside 1..%d", k, host_type[k], h->ntypes);
+        if ((rc = ensure(h, h->type, (size_t)nall))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->type.p, host_type, sizeof(int) * (size_t)nall, hipMemcpyHostToDevice, s));
+        d_type = h->type.p;
+    }
+    const bool want_eatom = eflag && eatom_flag && eatom;
+    const size_t nf = (size_t)nall * 3;
+    const bool f_on_device = nall > 0 && host_register(h, h->reg_f, f, nf * sizeof(double));
+    if (f_on_device) {          // (ahead of the list on the second stream: the first run's force pass waits for it)
+        HIP_TRY(h, hipMemcpyAsync(h->f.p, f, nf * sizeof(double), hipMemcpyHostToDevice, h->stream2));
+        HIP_TRY(h, hipEventRecord(h->ev_f_up, h->stream2));
+        h->pre_force_wait = h->ev_f_up;
+    } else {
+        HIP_TRY(h, hipMemsetAsync(h->f.p, 0, sizeof(double) * nf, s));
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), s));
+    if (want_eatom) HIP_TRY(h, hipMemsetAsync(h->eatom.p, 0, sizeof(double) * (size_t)nall, s));
+    if (vatom) HIP_TRY(h, hipMemsetAsync(h->vatom.p, 0, sizeof(double) * (size_t)nall * 6, s));
+    h->list_valid = false;
+    rc = upload_host_list(h, inum, nall, ilist, numj, firstneigh, h->stream2, h->list_parts, [&](int a, int b, hipEvent_t ev) -> int {
+        HIP_TRY(h, hipStreamWaitEvent(s, ev, 0));
+        return compute_device_impl(h, b - a, nall, h->x.p, d_type, h->ilist.p + a, h->numneigh.p, h->first.p, h->neigh.p, h->list_max,
+                                   h->f.p, want_eatom ? h->eatom.p : nullptr, h->d_scalars, (vflag && virial) ? h->d_scalars + 1 : nullptr,
+                                   vatom ? h->vatom.p : nullptr, s);
+    });
+    if (h->pre_force_wait) {        // no run got as far as its force pass: the upload of f still has to land before anything else happens to it
+        (void)hipStreamWaitEvent(s, h->pre_force_wait, 0);
+        h->pre_force_wait = nullptr;
+    }
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    return host_finish(h, inum, nall, eflag, vflag, eatom_flag, f_on_device, f, eng_vdwl, eatom, virial, vatom);
 }
 
 int annp_hip_compute(annp_hip_handle *h, int ago, int inum, int nall, int nghost,
@@ -2148,6 +2225,12 @@ int annp_hip_compute(annp_hip_handle *h, int ago, int inum, int nall, int nghost
     int rc;
     // neighbour list: re-packed to CSR and uploaded when LAMMPS rebuilt it (ago == 0)
     if (ago == 0 || !h->list_valid) {
+        // a list of some size, and nothing that would make the evaluation start over (a Behler handle sizes its first evaluation by trying)
+        if (h->list_parts > 1 && inum >= h->list_pipe_min && !(h->descriptor == ANNP_HIP_DESC_BEHLER && !h->ni_primed)) {
+            if ((rc = upload_x(h, host_x, nall, s))) return rc;
+            return host_evaluate_uploading(h, inum, nall, host_type, ilist, numj, firstneigh, eflag, vflag, eatom_flag, f, eng_vdwl, eatom, virial,
+                                           want_vatom ? vatom : nullptr);
+        }
         if ((rc = upload_host_list(h, inum, nall, ilist, numj, firstneigh, s))) return rc;
     }
     if ((rc = upload_x(h, host_x, nall, s))) return rc;

@@ -180,3 +180,52 @@ def test_types_out_of_range_are_refused(tmp_path):
     with pytest.raises(RuntimeError, match="outside 1..2"):
         p.compute(eflag=1, vflag=0)
     p.close()
+
+
+@pytest.mark.parametrize("register", ["1", "0"])
+@pytest.mark.parametrize("kind", ["fe", "fe_vatom", "ni"])
+def test_host_list_evaluated_while_it_is_uploaded(fe_pot, ni_pot, kind, register):
+    """annp_hip_compute with ago == 0 (round 6): the list goes out in runs of chunks and the atoms of a run are evaluated behind the run's
+    copies, while the next run is packed.  Small chunks (ANNP_HIP_LIST_CHUNK) and no size threshold (ANNP_HIP_LIST_PIPE_MIN) cut a
+    1 458-atom list into five runs: same energies, forces, virial and per-atom quantities as one upload and one evaluation
+    (ANNP_HIP_LIST_PARTS=1, the route of rounds 1-5) and as the oracle; f accumulates on top of the caller's values either way."""
+    if kind == "ni":
+        x, box = fcc(7, 7, 7, A_NI)
+        s = System(perturb(x, 5, 0.05), box, rc_list=6.5)
+        o = oracle_compute(ni_pot, s, KIND_NI_FIXED, FAST, want_virial=True)
+        pot, el = NI_POT, "Ni"
+    else:
+        x, box = bcc(9, 9, 9, A_FE)
+        s = System(perturb(x, 7, 0.05), box)
+        o = oracle_compute(fe_pot, s, KIND_FE, FAST, want_virial=True)
+        pot, el = FE_POT, "Fe"
+    want_vatom = kind != "fe"
+    chunk = int(s.numneigh[: s.nlocal].sum()) // 19 + 1          # (19 chunks in 5 runs)
+    res = []
+    for parts in ("5", "1"):
+        p = make_pair(pot, el, env={"ANNP_HIP_REGISTER": register, "ANNP_HIP_LIST_PARTS": parts, "ANNP_HIP_LIST_PIPE_MIN": "1",
+                                    "ANNP_HIP_LIST_CHUNK": str(max(1024, chunk))})
+        attach(p, s)
+        base = np.random.default_rng(3).normal(0, 1, p.atom.f.shape)
+        out = []
+        for call in range(2):       # both with ago == 0: the second on a handle that has adapted its capacities
+            p.ago = 0
+            p.atom.f[:] = base
+            p.eatom = None
+            p.vatom = None
+            e = p.compute(eflag=1, vflag=1, eflag_atom=True, vflag_atom=want_vatom)
+            out.append((e, p.atom.f - base, p.eatom[: s.nlocal].copy(), np.array(p.virial, dtype=float).copy(),
+                        p.vatom.copy() if want_vatom else None))
+        p.close()
+        res.append(out)
+    scale = max(1.0, np.abs(o["f"]).max())
+    for out in res:
+        for e, f, ea, vir, va in out:
+            assert abs(e - o["energy"]) < 1e-9 * max(1.0, abs(o["energy"]))
+            assert np.abs(f - o["f_all"]).max() < 1e-9 * scale
+            assert np.abs(ea - o["eatom"]).max() < 1e-9 * max(1.0, np.abs(o["eatom"]).max())
+            assert np.allclose(vir, o["virial"], rtol=1e-9, atol=1e-6 * scale)
+    for a, b in zip(res[0], res[1]):                              # in runs == in one go, to the order of the force sums
+        assert np.abs(a[1] - b[1]).max() < 1e-10 * scale
+        if want_vatom:
+            assert np.abs(a[4] - b[4]).max() < 1e-9 * max(1.0, np.abs(b[4]).max())
