@@ -312,11 +312,109 @@ __device__ __forceinline__ void sh_column(const ShLane &w, ShRegs &st)
     if (NB > 1) sh_batch<M, (NB > 1 ? 1 : 0), GROUPED>(w, ac, as);
     if (NB > 2) sh_batch<M, (NB > 2 ? 2 : 0), GROUPED>(w, ac, as);
 }
+// Columns M and M + 1 together (round 6): the powers of z are the same for both -- one multiply serves four multiply-adds instead of two --
+// and a neighbour's running power fc (x+iy)^m is advanced twice in a row, the first result used on the way.  Twice the accumulators,
+// 4 K - 2 of them, which is why only the columns from SH_PAIR_FROM on are paired: from m = 10 (34 accumulators; the single column m = 1
+// has 36) the kernel keeps its 168 registers without scratch, from m = 8 the compiler spills 6 registers, from m = 4 45.  Measured on one
+// box, alternating (profiles/r06_kernel_experiments.txt): no pairs 4.746-4.755 ms per 1 M atoms, from m = 12 4.680-4.693, from m = 10
+// 4.654-4.667, from m = 8 (with its spills) 4.657-4.674.  Sixteen double-precision multiplies per neighbour fewer (2.6 % of what the
+// columns execute) for 1.9 % of the pass -- where 95 fewer shuffle / select instructions per atom bought nothing: the pass answers to its
+// double-precision work, not to its instruction count.  The long columns would need their powers cut into bands to fit.
+#ifndef ANNP_SH_PAIR_FROM
+#define ANNP_SH_PAIR_FROM 10          // (99: no column is paired)
+#endif
+constexpr int SH_PAIR_FROM = ANNP_SH_PAIR_FROM;
+template <int M>
+__device__ __forceinline__ void sh_column2(const ShLane &w, ShRegs &st)
+{
+    static_assert(M >= 1 && M + 1 <= SH_LMAX, "both columns have sine parts");
+    constexpr int K = SH_LMAX + 1 - M, K1 = K - 1;            // entries of column M, of column M + 1
+    double ac[K], as[K], bc[K1], bs[K1];
+    // one neighbour: z^j times (cx, cy) = fc (x+iy)^M into column M, times (dx, dy) = fc (x+iy)^(M+1) into column M + 1
+    auto neighbour = [&](auto first, double z, const double cx, const double cy, const double dx, const double dy) {
+        constexpr bool FIRST = decltype(first)::value;
+        asm volatile("" : "+v"(z));          // (as in sh_column: the powers are made again per column pair, not kept across all of them)
+        ac[0] = FIRST ? cx : ac[0] + cx; as[0] = FIRST ? cy : as[0] + cy;
+        bc[0] = FIRST ? dx : bc[0] + dx; bs[0] = FIRST ? dy : bs[0] + dy;
+        double P = z;
+#pragma unroll
+        for (int k = 1; k < K; k++) {
+            if (k >= 2) P *= z;
+            ac[k] = FIRST ? P * cx : fma(P, cx, ac[k]);
+            as[k] = FIRST ? P * cy : fma(P, cy, as[k]);
+            if (k < K1) {
+                bc[k] = FIRST ? P * dx : fma(P, dx, bc[k]);
+                bs[k] = FIRST ? P * dy : fma(P, dy, bs[k]);
+            }
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < SH_R; r++) {
+        const double cx = st.pc[r], cy = st.ps[r];
+        const double dx = fma(cx, st.ex[r], -(cy * st.ey[r])), dy = fma(cx, st.ey[r], cy * st.ex[r]);       // fc (x+iy)^(M+1)
+        if (r == 0) neighbour(std::true_type{}, st.z[r], cx, cy, dx, dy);
+        else neighbour(std::false_type{}, st.z[r], cx, cy, dx, dy);
+        if (M + 1 < SH_LMAX) {      // fc (x+iy)^(M+2)
+            st.pc[r] = fma(dx, st.ex[r], -(dy * st.ey[r]));
+            st.ps[r] = fma(dx, st.ey[r], dy * st.ex[r]);
+        }
+    }
+    int left = uniform(w.iters);
+    if (left > 0) {
+        // the LDS-resident neighbours, as in sh_column (two per trip, an odd one first, the next one's z and power requested a neighbour ahead)
+        typedef __attribute__((address_space(3))) shf_v2d *l2p;
+        typedef __attribute__((address_space(3))) double *l1p;
+        unsigned qa = w.a_sa, qc = w.a_sc, qz = w.a_sz;
+        auto one = [&](const double z, const shf_v2d C, const shf_v2d A, const unsigned at) {
+            shf_v2d D;
+            D.x = fma(C.x, A.x, -(C.y * A.y)); D.y = fma(C.x, A.y, C.y * A.x);
+            neighbour(std::false_type{}, z, C.x, C.y, D.x, D.y);
+            if (M + 1 < SH_LMAX) {
+                shf_v2d E;
+                E.x = fma(D.x, A.x, -(D.y * A.y)); E.y = fma(D.x, A.y, D.y * A.x);
+                *(l2p)(uintptr_t)at = E;
+            }
+        };
+        shf_v2d C0 = *(l2p)(uintptr_t)qc;
+        double z0 = *(l1p)(uintptr_t)qz;
+        if (left & 1) {
+            const shf_v2d A0 = *(l2p)(uintptr_t)qa;
+            const shf_v2d Cn = *(l2p)(uintptr_t)(qc + 16u * SH_GL);
+            const double zn = *(l1p)(uintptr_t)(qz + 8u * SH_GL);
+            one(z0, C0, A0, qc);
+            qa += 16u * SH_GL; qc += 16u * SH_GL; qz += 8u * SH_GL;
+            C0 = Cn; z0 = zn;
+            left--;
+        }
+        while (left > 0) {
+            const shf_v2d A0 = *(l2p)(uintptr_t)qa;
+            const shf_v2d C1 = *(l2p)(uintptr_t)(qc + 16u * SH_GL);
+            const double z1 = *(l1p)(uintptr_t)(qz + 8u * SH_GL);
+            one(z0, C0, A0, qc);
+            const shf_v2d A1 = *(l2p)(uintptr_t)(qa + 16u * SH_GL);
+            C0 = *(l2p)(uintptr_t)(qc + 32u * SH_GL);
+            z0 = *(l1p)(uintptr_t)(qz + 16u * SH_GL);
+            one(z1, C1, A1, qc + 16u * SH_GL);
+            qa += 32u * SH_GL; qc += 32u * SH_GL; qz += 16u * SH_GL;
+            left -= 2;
+        }
+    }
+    constexpr int NBA = (2 * K + 15) / 16, NBB = (2 * K1 + 15) / 16;
+    sh_batch<M, 0, false>(w, ac, as);
+    if (NBA > 1) sh_batch<M, (NBA > 1 ? 1 : 0), false>(w, ac, as);
+    sh_batch<M + 1, 0, false>(w, bc, bs);
+    if (NBB > 1) sh_batch<M + 1, (NBB > 1 ? 1 : 0), false>(w, bc, bs);
+}
 template <int Q> __device__ __forceinline__ void shg_tail(const ShLane &w);
 template <int M, bool GROUPED>
 struct ShColumns {
     static __device__ __forceinline__ void run(const ShLane &w, ShRegs &st)
     {
+        if constexpr (!GROUPED && M >= SH_PAIR_FROM && M + 1 <= SH_LMAX) {
+            sh_column2<M>(w, st);
+            ShColumns<M + 2, GROUPED>::run(w, st);
+            return;
+        }
         sh_column<M, GROUPED>(w, st);
         if constexpr (GROUPED) {
             // the group's last column is summed: its entries change basis now, out of the group buffer (the reads of the next group's
@@ -328,6 +426,10 @@ struct ShColumns {
 };
 template <bool GROUPED>
 struct ShColumns<SH_LMAX + 1, GROUPED> {
+    static __device__ __forceinline__ void run(const ShLane &, ShRegs &) {}
+};
+template <bool GROUPED>
+struct ShColumns<SH_LMAX + 2, GROUPED> {
     static __device__ __forceinline__ void run(const ShLane &, ShRegs &) {}
 };
 
