@@ -323,28 +323,84 @@ __device__ __forceinline__ void sh_column(const ShLane &w, ShRegs &st)
 #ifndef ANNP_SH_PAIR_FROM
 #define ANNP_SH_PAIR_FROM 10          // (99: no column is paired)
 #endif
-constexpr int SH_PAIR_FROM = ANNP_SH_PAIR_FROM;
-template <int M>
-__device__ __forceinline__ void sh_column2(const ShLane &w, ShRegs &st)
+#ifndef ANNP_SH_BAND_FROM
+#define ANNP_SH_BAND_FROM 99          // pairs (m, m+1), m = BAND_FROM, BAND_FROM + 2, .. < PAIR_FROM - 1 go in two bands of powers (99: none)
+#endif
+constexpr int SH_PAIR_FROM = ANNP_SH_PAIR_FROM, SH_BAND_FROM = ANNP_SH_BAND_FROM;
+// z^J with the fewest multiplies a square-and-multiply chain gives (J is small and known at compile time)
+template <int J>
+__device__ __forceinline__ double sh_zpow(const double z)
+{
+    if constexpr (J == 0) return 1.0;
+    else if constexpr (J == 1) return z;
+    else if constexpr (J % 2 == 0) { const double h = sh_zpow<J / 2>(z); return h * h; }
+    else return sh_zpow<J - 1>(z) * z;
+}
+// The totals of one sweep over the neighbours -- the powers [J0, J1) of columns M and M + 1: cosine and sine of column M, then of column
+// M + 1 -- summed over the atom's lanes sixteen at a time and parked in the moment row (as sh_batch does for a whole column).
+template <int M, int J0, int J1, int B>
+__device__ __forceinline__ void sh_batch_band(const ShLane &w, const double *ac, const double *as, const double *bc, const double *bs)
+{
+    constexpr int K = SH_LMAX + 1 - M, K1 = K - 1;
+    constexpr int NA = (J1 < K ? J1 : K) - J0, NBB = (J1 < K1 ? J1 : K1) - J0;     // powers of column M, of column M + 1 in this band
+    constexpr int S1 = NA, S2 = 2 * NA, S3 = 2 * NA + NBB, NV = 2 * NA + 2 * NBB;
+    constexpr int R = NV - 16 * B < 16 ? NV - 16 * B : 16;
+    constexpr int RP = sh_pow2_at_least(R);
+    static_assert(NA >= 1 && NBB >= 1 && R >= 1, "a band has powers of both columns");
+    double v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int vv = 16 * B + j;
+        double x = 0.0;
+        if (j < R) {
+            if (vv < S1) x = ac[vv < S1 ? vv : 0];
+            else if (vv < S2) x = as[(vv - S1 >= 0 && vv - S1 < NA) ? vv - S1 : 0];
+            else if (vv < S3) x = bc[(vv - S2 >= 0 && vv - S2 < NBB) ? vv - S2 : 0];
+            else x = bs[(vv - S3 >= 0 && vv - S3 < NBB) ? vv - S3 : 0];
+        }
+        v[j] = x;
+    }
+    const double t = sh_row_reduce<RP>(v, w.bit1, w.bit0);
+    const int j = w.jrev & (RP - 1);
+    const int vv = 16 * B + j;
+    if ((w.jrev & (16 - RP)) == 0 && j < R && w.alive) {       // one lane per total
+        const bool second = vv >= S2;                          // column M + 1
+        const int q = second ? vv - S2 : vv, n = second ? NBB : NA;
+        const bool sine = q >= n;
+        const int jj = J0 + (sine ? q - n : q);                // the power
+        const unsigned pos = second ? (unsigned)sh_apos(M + 1, 0) : (unsigned)sh_apos(M, 0);
+        const unsigned off = w.arow + 8u * (pos + (sine ? 1u : 0u)) - 16u * (unsigned)jj;
+        *reinterpret_cast<double *>(reinterpret_cast<char *>(w.Abase) + off) = t;
+    }
+}
+// The powers [J0, J1) of columns M and M + 1 in one sweep over the neighbours.  LAST: the sweep that also advances the neighbours' running
+// power fc (x+iy)^m by two (an earlier band of the same pair leaves it alone and makes fc (x+iy)^(M+1) again in the next sweep).
+template <int M, int J0, int J1, bool LAST>
+__device__ __forceinline__ void sh_pair_band(const ShLane &w, ShRegs &st)
 {
     static_assert(M >= 1 && M + 1 <= SH_LMAX, "both columns have sine parts");
     constexpr int K = SH_LMAX + 1 - M, K1 = K - 1;            // entries of column M, of column M + 1
-    double ac[K], as[K], bc[K1], bs[K1];
+    constexpr int NA = (J1 < K ? J1 : K) - J0, NBB = (J1 < K1 ? J1 : K1) - J0;
+    static_assert(NA >= 1 && NBB >= 1 && NA >= NBB, "a band has powers of both columns");
+    double ac[NA], as[NA], bc[NBB], bs[NBB];
     // one neighbour: z^j times (cx, cy) = fc (x+iy)^M into column M, times (dx, dy) = fc (x+iy)^(M+1) into column M + 1
     auto neighbour = [&](auto first, double z, const double cx, const double cy, const double dx, const double dy) {
         constexpr bool FIRST = decltype(first)::value;
-        asm volatile("" : "+v"(z));          // (as in sh_column: the powers are made again per column pair, not kept across all of them)
-        ac[0] = FIRST ? cx : ac[0] + cx; as[0] = FIRST ? cy : as[0] + cy;
-        bc[0] = FIRST ? dx : bc[0] + dx; bs[0] = FIRST ? dy : bs[0] + dy;
-        double P = z;
+        asm volatile("" : "+v"(z));          // (as in sh_column: the powers are made again per sweep, not kept across the columns)
+        double P = sh_zpow<J0>(z);
 #pragma unroll
-        for (int k = 1; k < K; k++) {
-            if (k >= 2) P *= z;
-            ac[k] = FIRST ? P * cx : fma(P, cx, ac[k]);
-            as[k] = FIRST ? P * cy : fma(P, cy, as[k]);
-            if (k < K1) {
-                bc[k] = FIRST ? P * dx : fma(P, dx, bc[k]);
-                bs[k] = FIRST ? P * dy : fma(P, dy, bs[k]);
+        for (int k = 0; k < NA; k++) {
+            if (k > 0) P = (J0 + k == 1) ? z : P * z;
+            if (J0 + k == 0) {
+                ac[k] = FIRST ? cx : ac[k] + cx; as[k] = FIRST ? cy : as[k] + cy;
+                if (k < NBB) { bc[k] = FIRST ? dx : bc[k] + dx; bs[k] = FIRST ? dy : bs[k] + dy; }
+            } else {
+                ac[k] = FIRST ? P * cx : fma(P, cx, ac[k]);
+                as[k] = FIRST ? P * cy : fma(P, cy, as[k]);
+                if (k < NBB) {
+                    bc[k] = FIRST ? P * dx : fma(P, dx, bc[k]);
+                    bs[k] = FIRST ? P * dy : fma(P, dy, bs[k]);
+                }
             }
         }
     };
@@ -354,7 +410,7 @@ __device__ __forceinline__ void sh_column2(const ShLane &w, ShRegs &st)
         const double dx = fma(cx, st.ex[r], -(cy * st.ey[r])), dy = fma(cx, st.ey[r], cy * st.ex[r]);       // fc (x+iy)^(M+1)
         if (r == 0) neighbour(std::true_type{}, st.z[r], cx, cy, dx, dy);
         else neighbour(std::false_type{}, st.z[r], cx, cy, dx, dy);
-        if (M + 1 < SH_LMAX) {      // fc (x+iy)^(M+2)
+        if (LAST && M + 1 < SH_LMAX) {      // fc (x+iy)^(M+2)
             st.pc[r] = fma(dx, st.ex[r], -(dy * st.ey[r]));
             st.ps[r] = fma(dx, st.ey[r], dy * st.ex[r]);
         }
@@ -369,7 +425,7 @@ __device__ __forceinline__ void sh_column2(const ShLane &w, ShRegs &st)
             shf_v2d D;
             D.x = fma(C.x, A.x, -(C.y * A.y)); D.y = fma(C.x, A.y, C.y * A.x);
             neighbour(std::false_type{}, z, C.x, C.y, D.x, D.y);
-            if (M + 1 < SH_LMAX) {
+            if (LAST && M + 1 < SH_LMAX) {
                 shf_v2d E;
                 E.x = fma(D.x, A.x, -(D.y * A.y)); E.y = fma(D.x, A.y, D.y * A.x);
                 *(l2p)(uintptr_t)at = E;
@@ -399,18 +455,37 @@ __device__ __forceinline__ void sh_column2(const ShLane &w, ShRegs &st)
             left -= 2;
         }
     }
-    constexpr int NBA = (2 * K + 15) / 16, NBB = (2 * K1 + 15) / 16;
-    sh_batch<M, 0, false>(w, ac, as);
-    if (NBA > 1) sh_batch<M, (NBA > 1 ? 1 : 0), false>(w, ac, as);
-    sh_batch<M + 1, 0, false>(w, bc, bs);
-    if (NBB > 1) sh_batch<M + 1, (NBB > 1 ? 1 : 0), false>(w, bc, bs);
+    constexpr int NBT = (2 * NA + 2 * NBB + 15) / 16;
+    static_assert(NBT <= 3, "three batches per sweep at most");
+    sh_batch_band<M, J0, J1, 0>(w, ac, as, bc, bs);
+    if (NBT > 1) sh_batch_band<M, J0, J1, (NBT > 1 ? 1 : 0)>(w, ac, as, bc, bs);
+    if (NBT > 2) sh_batch_band<M, J0, J1, (NBT > 2 ? 2 : 0)>(w, ac, as, bc, bs);
+}
+// columns M and M + 1: in one sweep where their 4 K - 2 accumulators fit the registers (M >= SH_PAIR_FROM), in two bands of powers otherwise
+template <int M>
+__device__ __forceinline__ void sh_column2(const ShLane &w, ShRegs &st)
+{
+    constexpr int K = SH_LMAX + 1 - M;
+    if constexpr (M >= SH_PAIR_FROM) sh_pair_band<M, 0, K, true>(w, st);
+    else {
+        constexpr int J = K / 2;            // powers [0, J) and [J, K): 4 J and 4 (K - J) - 2 accumulators
+        sh_pair_band<M, 0, J, false>(w, st);
+        sh_pair_band<M, J, K, true>(w, st);
+    }
+}
+// which columns start a pair: SH_BAND_FROM, SH_BAND_FROM + 2, .. while the pair ends below SH_PAIR_FROM (banded), then SH_PAIR_FROM, + 2, ..
+__host__ __device__ constexpr bool sh_pair_starts(int m)
+{
+    if (m + 1 > SH_LMAX) return false;
+    if (m >= SH_PAIR_FROM) return (m - SH_PAIR_FROM) % 2 == 0;
+    return m >= SH_BAND_FROM && (m - SH_BAND_FROM) % 2 == 0 && m + 1 < SH_PAIR_FROM;
 }
 template <int Q> __device__ __forceinline__ void shg_tail(const ShLane &w);
 template <int M, bool GROUPED>
 struct ShColumns {
     static __device__ __forceinline__ void run(const ShLane &w, ShRegs &st)
     {
-        if constexpr (!GROUPED && M >= SH_PAIR_FROM && M + 1 <= SH_LMAX) {
+        if constexpr (!GROUPED && sh_pair_starts(M)) {
             sh_column2<M>(w, st);
             ShColumns<M + 2, GROUPED>::run(w, st);
             return;
