@@ -47,7 +47,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 #     neighbourhood (fe_sh_kernels.hpp, fe_shf_kernels.hpp), not on its pairs.
 #     Descriptor pass (round 4b: monomial moments), per in-cutoff neighbour: the powers of z of the 19 columns (K - 2 multiplies in
 #     a column of K powers: 1 and z cost nothing; round 6: columns (10,11), (12,13), (14,15), (16,17) share theirs -- 6 + 4 + 2 + 0
-#     multiplies fewer) 153 - 12 = 141; the accumulation behind every power (1 FMA in column 0, 2 elsewhere)
+#     multiplies fewer; columns (5,6) and (7,8) do too, each in two sweeps over the neighbours: 15 multiplies fewer, the second sweep's
+#     fc (x+iy)^(m+1) made again for 6 flop each) 153 - 12 - 15 + 12 = 138; the accumulation behind every power (1 FMA in column 0, 2 elsewhere)
 #     2 x 19 + 4 x 171 = 722; advancing the power (x+iy)^m 18 x 6 = 108; geometry, cutoff function, 9 radial functions 110.
 #     Per atom: lane sums 361 x 15, 19 x 19 product ~ 7 k; the change of basis to the moments of the Pm^(m)_k 1 430 FMAs, power
 #     spectrum 3 x 190.
@@ -56,7 +57,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 #     cosine-only column m = 0 3 + 2 x 16 = 35, Horner's rule in w 12 FMAs per column end (17 of them: behind m = 17 .. 1) and 8 at the end
 #     (212): 825 FMAs = 1 650 flop;
 #     geometry, radial T and T', force assembly 158.  Per atom: B = W kappa A 760, change of basis 1 430 FMAs = 2 860.
-FLOP_PAIR_DESC, FLOP_NBR_DESC, FLOP_ATOM_DESC = 0.0, 141 + (2 * 19 + 4 * 171) + 18 * 6 + 110.0, 7000.0 + 2 * 1430 + 3 * 190
+FLOP_PAIR_DESC, FLOP_NBR_DESC, FLOP_ATOM_DESC = 0.0, 138 + (2 * 19 + 4 * 171) + 18 * 6 + 110.0, 7000.0 + 2 * 1430 + 3 * 190
 FLOP_PAIR_FORCE, FLOP_NBR_FORCE, FLOP_ATOM_FORCE = 0.0, 2 * (16 * 6 + 4 * 120 + 2 + 35 + 12 * 17 + 8) + 158.0, 760.0 + 2860.0
 #     ... and the pair-loop kernels they replaced (ANNP_HIP_FE_DESC=pairs ANNP_HIP_FE_FORCE=pairs, or a system with more than
 #     128 neighbours per atom): pass 1: cos 5, weights 3, T_2..T_18 recurrence + accumulate 68; pass 3: cos 5, Horner P 36 +

@@ -319,12 +319,15 @@ __device__ __forceinline__ void sh_column(const ShLane &w, ShRegs &st)
 // box, alternating (profiles/r06_kernel_experiments.txt): no pairs 4.746-4.755 ms per 1 M atoms, from m = 12 4.680-4.693, from m = 10
 // 4.654-4.667, from m = 8 (with its spills) 4.657-4.674.  Sixteen double-precision multiplies per neighbour fewer (2.6 % of what the
 // columns execute) for 1.9 % of the pass -- where 95 fewer shuffle / select instructions per atom bought nothing: the pass answers to its
-// double-precision work, not to its instruction count.  The long columns would need their powers cut into bands to fit.
+// double-precision work, not to its instruction count.  The long columns only fit cut into bands of powers (sh_column2: a sweep over the
+// neighbours per band, fc (x+iy)^(M+1) made again in each): pairs (5,6) and (7,8) in two bands of at most ANNP_SH_BAND_ACC = 28 accumulators
+// keep the registers and take another 1.1-1.9 % off the pass (4.65 -> 4.60 ms on one box, 4.76 -> 4.67 on a slower one); from m = 3 or m = 1 in two
+// bands the compiler spills 6 / 10 registers and the gain is gone, in three bands the multiplies saved are spent on the sweeps' own start-up.
 #ifndef ANNP_SH_PAIR_FROM
 #define ANNP_SH_PAIR_FROM 10          // (99: no column is paired)
 #endif
 #ifndef ANNP_SH_BAND_FROM
-#define ANNP_SH_BAND_FROM 99          // pairs (m, m+1), m = BAND_FROM, BAND_FROM + 2, .. < PAIR_FROM - 1 go in two bands of powers (99: none)
+#define ANNP_SH_BAND_FROM 5           // pairs (m, m+1), m = BAND_FROM, BAND_FROM + 2, .. < PAIR_FROM - 1 go in two bands of powers (99: none)
 #endif
 constexpr int SH_PAIR_FROM = ANNP_SH_PAIR_FROM, SH_BAND_FROM = ANNP_SH_BAND_FROM;
 // z^J with the fewest multiplies a square-and-multiply chain gives (J is small and known at compile time)
@@ -462,15 +465,28 @@ __device__ __forceinline__ void sh_pair_band(const ShLane &w, ShRegs &st)
     if (NBT > 2) sh_batch_band<M, J0, J1, (NBT > 2 ? 2 : 0)>(w, ac, as, bc, bs);
 }
 // columns M and M + 1: in one sweep where their 4 K - 2 accumulators fit the registers (M >= SH_PAIR_FROM), in two bands of powers otherwise
+#ifndef ANNP_SH_BAND_ACC
+#define ANNP_SH_BAND_ACC 28           // accumulators a sweep of a banded pair may have (the kernel keeps its registers without scratch up to there)
+#endif
+template <int M, int NBAND, int B>
+struct ShBands {
+    static constexpr int K = SH_LMAX + 1 - M;
+    static constexpr int J0 = (K * B + NBAND - 1) / NBAND, J1 = (K * (B + 1) + NBAND - 1) / NBAND;
+    static __device__ __forceinline__ void run(const ShLane &w, ShRegs &st)
+    {
+        sh_pair_band<M, J0, (J1 < K ? J1 : K), B + 1 == NBAND>(w, st);
+        if constexpr (B + 1 < NBAND) ShBands<M, NBAND, B + 1>::run(w, st);
+    }
+};
 template <int M>
 __device__ __forceinline__ void sh_column2(const ShLane &w, ShRegs &st)
 {
     constexpr int K = SH_LMAX + 1 - M;
     if constexpr (M >= SH_PAIR_FROM) sh_pair_band<M, 0, K, true>(w, st);
     else {
-        constexpr int J = K / 2;            // powers [0, J) and [J, K): 4 J and 4 (K - J) - 2 accumulators
-        sh_pair_band<M, 0, J, false>(w, st);
-        sh_pair_band<M, J, K, true>(w, st);
+        // bands of powers [J_b, J_b+1), as few as keep a sweep's accumulators (4 powers' worth per power) within ANNP_SH_BAND_ACC
+        constexpr int NBAND = (4 * K - 2 + ANNP_SH_BAND_ACC - 1) / ANNP_SH_BAND_ACC;
+        ShBands<M, NBAND, 0>::run(w, st);
     }
 }
 // which columns start a pair: SH_BAND_FROM, SH_BAND_FROM + 2, .. while the pair ends below SH_PAIR_FROM (banded), then SH_PAIR_FROM, + 2, ..
