@@ -214,3 +214,38 @@ def test_atoms_without_neighbours(fe_pot):
     assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6 * max(1.0, np.abs(o["eatom"]).max())
     assert np.abs(r["f"] - o["f"]).max() < 1e-9 * max(1.0, np.abs(o["f"]).max())
     assert np.abs(r["f"][23:25]).max() == 0.0 and (r["rows"][23:25] == 0.0).all()
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_grouped_change_of_basis_gives_the_parked_rows(fe_pot, ragged):
+    """ANNP_HIP_SH_TAIL=group (round 6, a developer switch: measured 2 % slower than the default): launches with room for at most 112
+    neighbours change basis in three groups of columns out of LDS instead of parking their totals in the moment row.  Same descriptor
+    rows, energies and forces -- the second evaluation is the one that runs it (the first has room for 128) -- on a box and on a
+    ragged cluster whose atom count 4 does not divide (rows of atoms that do not exist, groups with a single neighbour)."""
+    if ragged:
+        rng = np.random.default_rng(9)
+        pts = []
+        while len(pts) < 203:
+            c = rng.uniform(0, 15.0, 3)
+            if all(np.sum((c - q) ** 2) > 2.0 ** 2 for q in pts):
+                pts.append(c)
+        s = System(np.array(pts) + 20.0, np.array([0, 0, 0, 55.0, 55.0, 55.0]), periodic=(0, 0, 0))
+    else:
+        x0, box = bcc(6, 5, 4, A_FE)
+        s = System(perturb(x0, 21, 0.1), box)
+    out = {}
+    for tail in ("group", "park"):
+        p = make_pair(ANNP_HIP_SH_TAIL=tail)
+        try:
+            evaluate(p, s)
+            p.eatom[:] = 0.0
+            out[tail] = evaluate(p, s)
+        finally:
+            p.close()
+    assert out["group"]["nmax"] <= 112
+    scale = np.maximum(np.abs(out["park"]["rows"]).max(axis=0), 1.0)
+    assert (np.abs(out["group"]["rows"] - out["park"]["rows"]) / scale).max() < 2e-12
+    o = oracle_compute(fe_pot, s, KIND_FE, FAST)
+    for r in out.values():
+        assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6 * max(1.0, np.abs(o["eatom"]).max())
+        assert np.abs(r["f"] - o["f"]).max() < 1e-9 * max(1.0, np.abs(o["f"]).max())
