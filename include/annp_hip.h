@@ -278,13 +278,13 @@ int annp_hip_sync(annp_hip_handle *handle);
 /* Facts about the most recent evaluation (waits for its flag words only):
  *   info4[0] largest in-cutoff neighbour count   info4[1] atoms (Behler: groups of four atoms) that went through the fix-up launch
  *   info4[2] neighbours per atom its force pass had room for (Chebyshev, moment kernels: the state the descriptor and force
- *            passes share, 96..128; pair-loop kernels and Behler: LDS records)   info4[3] what the next evaluation will use */
+ *            passes share, 96..160; pair-loop kernels and Behler: LDS records)   info4[3] what the next evaluation will use */
 int annp_hip_eval_info(annp_hip_handle *handle, int *info4);
 
 /* Which kernels the NEXT evaluation will run (after the most recent one's flag words, which this waits for):
- *   0  Chebyshev passes on the moments of the neighbourhood (the fast path: up to 128 in-cutoff neighbours per atom)
+ *   0  Chebyshev passes on the moments of the neighbourhood (the fast path: up to 160 in-cutoff neighbours per atom)
  *   1  Chebyshev passes pair by pair because the system is denser than that (about half the speed; back to 0 by itself when
- *      the maximum falls under 128 again)
+ *      the maximum falls under 160 again)
  *   2  Chebyshev passes pair by pair because ANNP_HIP_FE_DESC / ANNP_HIP_FE_FORCE ask for it (developer A/B switches)
  *   3  Behler G2/G4 kernels      4  pair_style anna_adp kernels
  * The change 0 -> 1 is also announced once on the stream given to annp_hip_set_notice (annp_gpu_init passes LAMMPS' screen).
