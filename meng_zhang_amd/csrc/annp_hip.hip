@@ -139,6 +139,7 @@ struct annp_hip_handle {
     bool shf_scattered = false, shf_scattered_said = false;       // the caller's atoms are in no spatial order (annp_fe_force_sh's force table)
     int fe_last_inum = 0;
     int sh_wpb = 0;                     // waves per workgroup of annp_fe_desc_sh (ANNP_HIP_SH_WPB; 0 = chosen per launch)
+    bool rp_images_by_dimension = false;    // ANNP_HIP_REPLAN_IMAGES=dims: annp_hip_replan_images waits for every dimension's count (rounds 4-5; A/B switch)
     bool sh_group = false;              // ANNP_HIP_SH_TAIL=group: the descriptor pass changes basis group by group out of LDS where it can (round 6, measured 2 % slower; developer A/B switch)
     int flagact[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // up to max(MLP_MAXL, ANNA_MAXL) weight layers
     static_assert(MLP_MAXL <= 8 && ANNA_MAXL <= 8, "flagact holds 8 layers");
@@ -1143,6 +1144,7 @@ int annp_hip_init(annp_hip_handle **handle, const annp_hip_params *p, int device
     if (const char *e = std::getenv("ANNP_HIP_VIRIAL")) h->virial_tally = std::strcmp(e, "tally") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SHF_PLACES")) h->shf_places_by_number = std::strcmp(e, "number") == 0;
     if (const char *e = std::getenv("ANNP_HIP_SH_WPB")) h->sh_wpb = std::min(4, std::max(0, std::atoi(e)));
+    if (const char *e = std::getenv("ANNP_HIP_REPLAN_IMAGES")) h->rp_images_by_dimension = std::strcmp(e, "dims") == 0;
     if (const char *e = std::getenv("ANNP_HIP_LIST_PARTS")) h->list_parts = std::max(1, std::min((int)annp_hip_handle::kListParts, std::atoi(e)));
     if (const char *e = std::getenv("ANNP_HIP_LIST_PIPE_MIN")) h->list_pipe_min = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("ANNP_HIP_LIST_CHUNK")) h->list_chunk = std::max<size_t>(1024, std::min<size_t>(annp_hip_handle::kListChunk, (size_t)std::atoll(e)));
@@ -1861,6 +1863,38 @@ int annp_hip_replan_images(annp_hip_handle *h, int np0, double *d_x, long long c
     if (np0 == 0) return 0;
     DEVICE_GUARD(h);
     hipStream_t s = (hipStream_t)stream;
+    // With buffers to fill (the usual call) the dimensions follow one another without the host looking at their counts in between
+    // (round 6: one wait per call instead of one per dimension): the kernels take the number of rows held so far from device memory
+    // and cover the buffer's capacity; a dimension that does not fit writes nothing and the caller is told how many rows were wanted.
+    if (d_root && d_shift && capacity_rows <= 0x7fffffffll / 3 && !h->rp_images_by_dimension) {
+        int rc;
+        const int cap = (int)capacity_rows;
+        if ((rc = rp_scratch(h, 2 * (size_t)cap + 8, 2 * (size_t)cap + 8))) return rc;
+        int *flo = h->rp_flag.p, *fhi = flo + cap;
+        long long *plo = h->rp_pos.p, *phi = plo + cap;
+        long long *state = h->rp_tot + 4;
+        h->rp_tot_h[6] = np0; h->rp_tot_h[7] = 0;          // (pinned: the copy may run after this line; the call ends with a wait, so nobody rewrites them before it has)
+        HIP_TRY(h, hipMemcpyAsync(state, h->rp_tot_h + 6, 2 * sizeof(long long), hipMemcpyHostToDevice, s));
+        const int blocks = (cap + 255) / 256;
+        for (int d = 0; d < 3; d++) {
+            if (!((dims_mask >> d) & 1) || !periodic3[d]) continue;
+            hipLaunchKernelGGL(annp_replan_image_flags_dev, dim3(blocks), dim3(256), 0, s, cap, state, d_x, d, box6[d] + rc_halo, box6[3 + d] - rc_halo, flo, fhi);
+            rp_scan(h, flo, cap, plo, h->rp_bs.p, 0, s);
+            rp_scan(h, fhi, cap, phi, h->rp_bs.p, 1, s);
+            hipLaunchKernelGGL(annp_replan_image_make_dev, dim3(blocks), dim3(256), 0, s, cap, state, capacity_rows, np0, d, box6[3 + d] - box6[d], flo, plo, fhi, phi,
+                               h->rp_tot + 0, d_x, d_root, d_shift);
+            hipLaunchKernelGGL(annp_replan_image_advance, dim3(1), dim3(64), 0, s, state, h->rp_tot + 0, capacity_rows);
+        }
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(h->rp_tot_h + 4, state, 2 * sizeof(long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (h->rp_tot_h[5] > 0) {       // not enough room: rows wanted by the first dimension that did not fit, times what the later ones may add
+            *nimg_out = (int)std::min<long long>(0x7fffffffll, (h->rp_tot_h[5] - np0) * 3);
+            return ANNP_HIP_ENEIGHCAP;
+        }
+        *nimg_out = (int)(h->rp_tot_h[4] - np0);
+        return 0;
+    }
     long long cur = np0;
     for (int d = 0; d < 3; d++) {
         if (!((dims_mask >> d) & 1) || !periodic3[d]) continue;

@@ -140,6 +140,57 @@ __global__ __launch_bounds__(256) void annp_replan_image_make(int cur, int np0, 
     }
 }
 
+// The same two with the number of rows held so far in DEVICE memory (round 6): the three periodic dimensions follow one another without the
+// host looking at the counts in between (one wait per re-planning instead of three).  The grid covers the buffer's capacity; rows at
+// and beyond *cur_p raise no flag.  A dimension whose images would not fit the buffer writes nothing and is reported by
+// annp_replan_image_advance (overflow word, rows needed), which otherwise adds the dimension's images to the count.
+__global__ __launch_bounds__(256) void annp_replan_image_flags_dev(int cap, const long long *__restrict__ cur_p, const double *__restrict__ x, int d, double lo_edge,
+                                                                   double hi_edge, int *fl_lo, int *fl_hi)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cap) return;
+    const bool held = k < *cur_p;
+    const double p = held ? x[3 * (size_t)k + d] : 0.0;
+    fl_lo[k] = held && p < lo_edge;
+    fl_hi[k] = held && p >= hi_edge;
+}
+__global__ __launch_bounds__(256) void annp_replan_image_make_dev(int cap, const long long *__restrict__ cur_p, long long capacity_rows, int np0, int d, double L,
+                                                                  const int *__restrict__ fl_lo, const long long *__restrict__ pos_lo, const int *__restrict__ fl_hi,
+                                                                  const long long *__restrict__ pos_hi, const long long *__restrict__ total2, double *x, int *root,
+                                                                  double *shift)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const long long cur = *cur_p;
+    if (k >= cap || k >= cur || cur + total2[0] + total2[1] > capacity_rows) return;
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const bool on = side == 0 ? fl_lo[k] != 0 : fl_hi[k] != 0;
+        if (!on) continue;
+        const long long j = cur + (side == 0 ? pos_lo[k] : total2[0] + pos_hi[k]);
+        const double s = side == 0 ? L : -L;
+        const long long q = j - np0;
+        double sv[3] = {0.0, 0.0, 0.0};
+        int r = k;
+        if (k >= np0) {
+            r = root[k - np0];
+            sv[0] = shift[3 * (size_t)(k - np0)]; sv[1] = shift[3 * (size_t)(k - np0) + 1]; sv[2] = shift[3 * (size_t)(k - np0) + 2];
+        }
+        sv[d] += s;
+        root[q] = r;
+        shift[3 * (size_t)q] = sv[0]; shift[3 * (size_t)q + 1] = sv[1]; shift[3 * (size_t)q + 2] = sv[2];
+#pragma unroll
+        for (int c = 0; c < 3; c++) x[3 * (size_t)j + c] = x[3 * (size_t)k + c] + (c == d ? s : 0.0);
+    }
+}
+// state[0] rows held so far, state[1] rows the buffer would have needed (0: it was large enough), behind the dimension's make kernel
+__global__ void annp_replan_image_advance(long long *state, const long long *__restrict__ total2, long long capacity_rows)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long want = state[0] + total2[0] + total2[1];
+    if (want > capacity_rows) { if (want > state[1]) state[1] = want; }
+    else state[0] = want;
+}
+
 // ---- the plan of annp_hip_reverse_fold: items k = 0..m-1 with targets t[k] in [0, nkeys), grouped by target in ascending k.
 // count -> exclusive scan -> fill through a cursor (any order) -> every target's few entries put in ascending order.
 // (a target outside [0, nkeys) is a caller's mistake the host cannot see: it is left out and reported through the handle's sticky
