@@ -401,6 +401,28 @@ def test_ni_tiny_systems(ni_pot, natoms):
     assert np.allclose(r["virial"], o["virial"], rtol=1e-8, atol=1e-6 * scale)
 
 
+@pytest.mark.parametrize("natoms", [1, 2, 3, 5, 17, 63, 65])
+def test_fe_tiny_systems(fe_pot, natoms):
+    """the same class of system for the Chebyshev kernels (round 6, after the Behler kernels' read of a record nobody wrote): fewer atoms
+    than a group of four, than a workgroup's sixteen; groups whose atoms have no neighbour at all next to groups whose atoms have a few
+    (a sparse cluster: 6.5 A reach in a 26 A box) -- moment rows, tables and force-table slots of atoms that are not there"""
+    x = _random_cluster(300 + natoms, 0.02, 26.0, 1.9)[:natoms]
+    assert x.shape[0] == natoms
+    s = System(x, np.array([0, 0, 0, 26.0, 26.0, 26.0]), periodic=(0, 0, 0))
+    o = oracle_compute(fe_pot, s, KIND_FE, FAST, want_virial=True)
+    p = make_pair(FE_POT, "Fe")
+    try:
+        for _ in range(2):          # the second evaluation runs with the state the first one learned
+            p.eatom = None
+            r = run(p, s, vflag=1)
+    finally:
+        p.close()
+    scale = max(1.0, np.abs(o["f"]).max())
+    assert np.abs(r["eatom"] - o["eatom"]).max() < 1e-6 * max(1.0, np.abs(o["eatom"] + 4479.0).max())
+    assert np.abs(r["f"] - o["f"]).max() < 1e-9 * scale
+    assert np.allclose(r["virial"], o["virial"], rtol=1e-9, atol=1e-6 * scale)
+
+
 def test_special_bits_in_neighbour_indices_are_masked(fe_pair, fe_pot):
     """LAMMPS stores special-bond flags in the top bits of a neighbour index; the pair style masks
     them with NEIGHMASK (fe_v2/src/pair_annp.cpp:136)."""
